@@ -1,0 +1,11 @@
+"""MI355X-native UNETR training hot path (gfx950 HIP kernels behind the reference's nn.Module interface).
+
+The directory name starts with a digit, so import it with
+``importlib.import_module("3dmedicalimagesegmentation_amd")`` -- or put this directory itself on
+``sys.path`` and keep the reference scripts' own ``from unetr import UNETR`` line unchanged.
+"""
+from .unetr import UNETR, UNETRLogits, default_precision  # noqa: F401
+from .losses import DiceCELoss  # noqa: F401
+from . import _capi, functional  # noqa: F401
+
+__all__ = ["UNETR", "UNETRLogits", "DiceCELoss", "default_precision"]

@@ -1,0 +1,88 @@
+"""ctypes binding of libunetr_hip.so (declared in include/unetr_hip.h).
+
+There is NO fallback: if the shared library is missing or a kernel returns non-zero this raises.  The
+library is built in-tree by ``__graft_entry__.build()`` / ``make -C csrc``.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
+
+PREC_F32 = 0
+PREC_BF16 = 1
+
+_ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
+        4: "workspace too small"}
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int),
+        ("a_trans", c_int), ("b_trans", c_int),
+        ("lda", c_long), ("ldb", c_long), ("ldc", c_long),
+        ("strideA", c_long), ("strideB", c_long), ("strideC", c_long),
+        ("bias", c_void_p), ("res", c_void_p),
+        ("ldr", c_long), ("strideR", c_long), ("res_mod", c_int),
+        ("pre", c_void_p), ("aux", c_void_p), ("ldaux", c_long),
+        ("act", c_int), ("accumulate", c_int), ("alpha", c_float), ("prec", c_int),
+    ]
+
+
+P = c_void_p
+_SIGNATURES = {
+    "unetr_abi_version": [],
+    "unetr_gemm": [ctypes.POINTER(GemmDesc), P, P, P, P, c_size_t, P],
+    "unetr_tconv_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_tconv_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_tconv_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_colsum": [P, c_long, c_int, c_int, P, c_int, P, c_size_t, P],
+    "unetr_layernorm_fwd": [P, P, P, P, P, P, c_int, c_int, c_float, P],
+    "unetr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P],
+    "unetr_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P],
+    "unetr_attention_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P],
+    "unetr_conv_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
+    "unetr_conv_gemm_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv_gemm_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_instnorm_stats": [P, c_long, c_int, c_long, c_int, c_float, P, P, c_size_t, P],
+    "unetr_instnorm_apply": [P, c_long, P, P, c_long, P, P, c_long, c_int, c_long, c_int, c_int, P],
+    "unetr_instnorm_bwd": [P, c_long, P, c_long, P, P, c_long, P, P, c_long, P, c_long, c_int, c_long, c_int, c_int, P, c_size_t, P],
+    "unetr_nchw_to_nhwc": [P, P, c_long, c_int, c_int, c_long, P],
+    "unetr_nhwc_to_nchw": [P, c_long, P, c_int, c_int, c_long, c_int, P],
+    "unetr_patch_gather": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_copy_rows": [P, c_long, P, c_long, c_long, c_int, c_int, P],
+    "unetr_outconv_fwd": [P, c_long, P, P, P, c_int, c_long, c_int, c_int, P],
+    "unetr_outconv_bwd": [P, P, c_long, P, P, c_long, P, P, c_int, c_long, c_int, c_int, P, c_size_t, P],
+    "unetr_dicece_fwd": [P, P, c_int, c_int, c_long, c_float, c_float, P, P, P, c_size_t, P],
+    "unetr_dicece_bwd": [P, P, P, P, P, c_int, c_int, c_long, P],
+    "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libunetr_hip.so once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C {os.path.join(_HERE, 'csrc')}`. There is no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,385 @@
+// Multi-head self-attention core for the UNETR ViT encoder (MONAI SABlock between qkv and out_proj),
+// flash-style on gfx950: K/V tiles staged in LDS, QK^T and PV on 16x16 MFMA tiles, online softmax with
+// wave64 shuffles, nothing of size LxL ever touches HBM.
+//
+// Orientation ("query on the lane"): the forward computes S^T = K.Q^T so that the accumulator of a
+// 16(key) x 16(query) tile has the query on lane&15 and four keys per lane in registers; the softmax
+// statistics (running max m, running sum l) are then per-lane scalars, completed across the four lane
+// groups with two __shfl_xor.  The accumulator tile is reused as the B operand of the next product
+// (O^T += V^T . P^T) without any lane movement, because that product sums over the accumulator's ROW
+// index.  The backward uses the same trick twice: a "query on the lane" kernel for dQ and a "key on the
+// lane" kernel for dK/dV (which therefore need no atomics); both recompute P from the saved LSE.
+//
+// Layout: qkv [B*L, 3*Hd], feature = which*Hd + head*DH + j (einops "b h (qkv l d) -> qkv b l h d");
+//         out/dout [B*L, Hd] ("b h l d -> b l (h d)"); lse/delta [B, heads, L].
+#include "common.hpp"
+#include "../../include/unetr_hip.h"
+
+namespace {
+
+constexpr int PT = 80;  // byte pitch of a transposed bf16 image row (32 keys * 2 B + 16 B pad)
+
+template <class P, int DH> struct AttnCfg {
+    static constexpr int CH = P::CH;
+    static constexpr bool BF = (CH == 8);
+    static constexpr int KB = DH / (4 * CH);      // k-blocks over the head dim
+    static constexpr int DT = DH / 16;            // 16-wide tiles over the head dim
+    static constexpr int PC = DH * (16 / CH) + 16;  // byte pitch of a chunk-image row
+    static constexpr int IMG_C = 32 * PC;         // bytes of a 32-row chunk image
+    static constexpr int IMG_T = BF ? DH * PT : 0;  // bytes of the transposed image (bf16 only)
+};
+
+template <class P, int DH> using AccArr = f32x4[AttnCfg<P, DH>::DT];
+template <class P, int DH> using FragArr = u32x4[AttnCfg<P, DH>::KB];
+
+// stage 32 rows x DH fp32 (row i at src + (row0+i)*rs, zero beyond nrows) into a chunk image and, in bf16
+// mode, optionally a transposed image [DH][32].
+template <class P, int DH, bool WANT_C, bool WANT_T>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ src, long rs, int row0, int nrows, char* img_c, char* img_t) {
+    using C = AttnCfg<P, DH>;
+    constexpr int CH = C::CH;
+    const int tid = threadIdx.x;
+    if (WANT_C || !C::BF) {
+        constexpr int NCH = DH / CH;
+        for (int id = tid; id < 32 * NCH; id += 256) {
+            int r = id / NCH, ch = id - r * NCH;
+            float v[CH];
+            if (row0 + r < nrows) {
+                const float* q = src + (long)(row0 + r) * rs + ch * CH;
+#pragma unroll
+                for (int c4 = 0; c4 < CH / 4; ++c4) {
+                    f32x4 t = *(const f32x4*)(q + 4 * c4);
+                    v[4 * c4] = t[0]; v[4 * c4 + 1] = t[1]; v[4 * c4 + 2] = t[2]; v[4 * c4 + 3] = t[3];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) v[j] = 0.f;
+            }
+            *(u32x4*)(img_c + r * C::PC + ch * 16) = P::pack(v);
+        }
+    }
+    if (WANT_T && C::BF) {
+        for (int id = tid; id < DH * 4; id += 256) {
+            int d = id % DH, rg = id / DH;  // 8 rows rg*8 .. rg*8+7 of column d
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int r = row0 + rg * 8 + j;
+                v[j] = r < nrows ? src[(long)r * rs + d] : 0.f;
+            }
+            *(u32x4*)(img_t + d * PT + rg * 16) = PrecBF16::pack(v);
+        }
+    }
+}
+
+// this lane's DH-vector (one token's head slice) as KB MFMA chunks: chunk index kb*4 + (lane>>4)
+template <class P, int DH>
+__device__ __forceinline__ void load_vec_frags(const float* __restrict__ rowptr, FragArr<P, DH>& f) {
+    constexpr int CH = P::CH;
+    const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int kb = 0; kb < AttnCfg<P, DH>::KB; ++kb) {
+        float v[CH];
+        const float* q = rowptr + (kb * 4 + g) * CH;
+#pragma unroll
+        for (int c4 = 0; c4 < CH / 4; ++c4) {
+            f32x4 t = *(const f32x4*)(q + 4 * c4);
+            v[4 * c4] = t[0]; v[4 * c4 + 1] = t[1]; v[4 * c4 + 2] = t[2]; v[4 * c4 + 3] = t[3];
+        }
+        f[kb] = P::pack(v);
+    }
+}
+
+// acc[16 image rows (tile rt) x 16 lane columns] = sum_d Img[row][d] * vec[d][col]
+template <class P, int DH>
+__device__ __forceinline__ f32x4 prod_rows(const char* img_c, int rt, const FragArr<P, DH>& vec) {
+    using C = AttnCfg<P, DH>;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < C::KB; ++kb) {
+        u32x4 a = *(const u32x4*)(img_c + (rt * 16 + c) * C::PC + (kb * 4 + g) * 16);
+        P::mma(acc, a, vec[kb]);
+    }
+    return acc;
+}
+
+// out[dt] (16 d x 16 lane columns) += sum over the 32 tile rows of Img^T[d][row] * X[row][col], where X is
+// held as two accumulator tiles x0 (rows 0..15) and x1 (rows 16..31): row = 16*t + 4*(lane>>4) + reg.
+template <class P, int DH>
+__device__ __forceinline__ void prod_T(AccArr<P, DH>& out, f32x4 x0, f32x4 x1, const char* img_c, const char* img_t) {
+    using C = AttnCfg<P, DH>;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    if constexpr (!C::BF) {
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float a0 = *(const float*)(img_c + (4 * g + t) * C::PC + (dt * 16 + c) * 4);
+                out[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[t], out[dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float a1 = *(const float*)(img_c + (16 + 4 * g + t) * C::PC + (dt * 16 + c) * 4);
+                out[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x1[t], out[dt], 0, 0, 0);
+            }
+        }
+    } else {
+        float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        u32x4 b = PrecBF16::pack(xv);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            const char* row = img_t + (dt * 16 + c) * PT;
+            uint64_t lo = *(const uint64_t*)(row + 8 * g);         // tile rows 4g .. 4g+3
+            uint64_t hi = *(const uint64_t*)(row + 32 + 8 * g);    // tile rows 16+4g .. 16+4g+3
+            u32x4 a = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+            PrecBF16::mma(out[dt], a, b);
+        }
+    }
+}
+
+__device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// ------------------------------------------------------------------------------------------ forward
+template <class P, int DH>
+__global__ void __launch_bounds__(256)
+attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse, int L, int heads, float scale) {
+    using C = AttnCfg<P, DH>;
+    __shared__ __attribute__((aligned(16))) char lds[C::IMG_C + (C::BF ? C::IMG_T : C::IMG_C)];
+    char* kimg = lds;
+    char* vimg = lds + C::IMG_C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z, Hd = heads * DH;
+    const long rs = 3L * Hd;
+    const float* qb = qkv + (long)b * L * rs + head * DH;
+    const float* kb_ = qb + Hd;
+    const float* vb = qb + 2 * Hd;
+    const int q = blockIdx.x * 64 + wave * 16 + c, qc = min(q, L - 1);
+    u32x4 qf[C::KB];
+    load_vec_frags<P, DH>(qb + (long)qc * rs, qf);
+    f32x4 o[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, l = 0.f;
+    for (int k0 = 0; k0 < L; k0 += 32) {
+        __syncthreads();
+        stage_tile<P, DH, true, false>(kb_, rs, k0, L, kimg, nullptr);
+        stage_tile<P, DH, false, true>(vb, rs, k0, L, vimg, vimg);
+        __syncthreads();
+        f32x4 s[2];
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = prod_rows<P, DH>(kimg, t, qf);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = k0 + t * 16 + 4 * g + r;
+                s[t][r] = key < L ? s[t][r] * scale : NEG_BIG;
+                tmax = fmaxf(tmax, s[t][r]);
+            }
+        }
+        tmax = grp_max(tmax);
+        const float mn = fmaxf(m, tmax), alpha = expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[t][r] = expf(s[t][r] - mn); ps += s[t][r]; }
+        ps = grp_sum(ps);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[dt] *= alpha;
+        prod_T<P, DH>(o, s[0], s[1], vimg, vimg);
+    }
+    if (q < L) {
+        const float inv = 1.f / l;
+        float* op = out + ((long)b * L + q) * Hd + head * DH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) *(f32x4*)(op + dt * 16) = o[dt] * inv;
+        if (g == 0) lse[((long)b * heads + head) * L + q] = m + logf(l);
+    }
+}
+
+// delta[b,h,q] = sum_d dout[q, h*DH+d] * out[q, h*DH+d]
+__global__ void attn_delta_kernel(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ delta,
+                                  int B, int L, int heads, int DH) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * heads * L;
+    if (i >= total) return;
+    int q = (int)(i % L); long t = i / L; int h = (int)(t % heads); int b = (int)(t / heads);
+    const float* o = out + ((long)b * L + q) * heads * DH + h * DH;
+    const float* d = dout + ((long)b * L + q) * heads * DH + h * DH;
+    float s = 0.f;
+    for (int j = 0; j < DH; j += 4) {
+        f32x4 a = *(const f32x4*)(o + j), bb = *(const f32x4*)(d + j);
+        s += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
+    }
+    delta[i] = s;
+}
+
+// ------------------------------------------------------------------------------- backward: dQ pass
+template <class P, int DH>
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                   const float* __restrict__ delta, float* __restrict__ dqkv, int L, int heads, float scale) {
+    using C = AttnCfg<P, DH>;
+    __shared__ __attribute__((aligned(16))) char lds[2 * C::IMG_C + C::IMG_T];
+    char* kimg = lds;
+    char* vimg = lds + C::IMG_C;
+    char* ktimg = lds + 2 * C::IMG_C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z, Hd = heads * DH;
+    const long rs = 3L * Hd;
+    const float* qb = qkv + (long)b * L * rs + head * DH;
+    const float* kb_ = qb + Hd;
+    const float* vb = qb + 2 * Hd;
+    const int q = blockIdx.x * 64 + wave * 16 + c, qc = min(q, L - 1);
+    u32x4 qf[C::KB], dof[C::KB];
+    load_vec_frags<P, DH>(qb + (long)qc * rs, qf);
+    load_vec_frags<P, DH>(dout + ((long)b * L + qc) * Hd + head * DH, dof);
+    const float lq = lse[((long)b * heads + head) * L + qc], dq_ = delta[((long)b * heads + head) * L + qc];
+    f32x4 dq[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < L; k0 += 32) {
+        __syncthreads();
+        stage_tile<P, DH, true, true>(kb_, rs, k0, L, kimg, ktimg);
+        stage_tile<P, DH, true, false>(vb, rs, k0, L, vimg, nullptr);
+        __syncthreads();
+        f32x4 ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 s = prod_rows<P, DH>(kimg, t, qf);
+            f32x4 dp = prod_rows<P, DH>(vimg, t, dof);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = k0 + t * 16 + 4 * g + r;
+                float p = key < L ? expf(s[r] * scale - lq) : 0.f;
+                ds[t][r] = p * (dp[r] - dq_);
+            }
+        }
+        prod_T<P, DH>(dq, ds[0], ds[1], kimg, ktimg);
+    }
+    if (q < L) {
+        float* op = dqkv + ((long)b * L + q) * rs + head * DH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) *(f32x4*)(op + dt * 16) = dq[dt] * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------- backward: dK/dV pass
+template <class P, int DH>
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+                    const float* __restrict__ delta, float* __restrict__ dqkv, int L, int heads, float scale) {
+    using C = AttnCfg<P, DH>;
+    __shared__ __attribute__((aligned(16))) char lds[2 * C::IMG_C + 2 * C::IMG_T + 256];
+    char* qimg = lds;
+    char* doimg = lds + C::IMG_C;
+    char* qtimg = lds + 2 * C::IMG_C;
+    char* dotimg = qtimg + C::IMG_T;
+    float* lse_t = (float*)(dotimg + C::IMG_T);  // [32] lse, [32] delta
+    float* del_t = lse_t + 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z, Hd = heads * DH;
+    const long rs = 3L * Hd;
+    const float* qb = qkv + (long)b * L * rs + head * DH;
+    const float* kb_ = qb + Hd;
+    const float* vb = qb + 2 * Hd;
+    const float* dob = dout + (long)b * L * Hd + head * DH;
+    const int key = blockIdx.x * 64 + wave * 16 + c, kc = min(key, L - 1);
+    u32x4 kf[C::KB], vf[C::KB];
+    load_vec_frags<P, DH>(kb_ + (long)kc * rs, kf);
+    load_vec_frags<P, DH>(vb + (long)kc * rs, vf);
+    f32x4 dk[C::DT], dv[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
+    for (int q0 = 0; q0 < L; q0 += 32) {
+        __syncthreads();
+        stage_tile<P, DH, true, true>(qb, rs, q0, L, qimg, qtimg);
+        stage_tile<P, DH, true, true>(dob, (long)Hd, q0, L, doimg, dotimg);
+        if (threadIdx.x < 32) {
+            int qq = q0 + threadIdx.x;
+            lse_t[threadIdx.x] = qq < L ? lse[((long)b * heads + head) * L + qq] : 1.0e30f;
+            del_t[threadIdx.x] = qq < L ? delta[((long)b * heads + head) * L + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x4 p[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 s = prod_rows<P, DH>(qimg, t, kf);
+            f32x4 dp = prod_rows<P, DH>(doimg, t, vf);
+            f32x4 l4 = *(const f32x4*)(lse_t + t * 16 + 4 * g), d4 = *(const f32x4*)(del_t + t * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pv = expf(s[r] * scale - l4[r]);
+                p[t][r] = pv;
+                ds[t][r] = pv * (dp[r] - d4[r]);
+            }
+        }
+        prod_T<P, DH>(dv, p[0], p[1], doimg, dotimg);
+        prod_T<P, DH>(dk, ds[0], ds[1], qimg, qtimg);
+    }
+    if (key < L) {
+        float* kp = dqkv + ((long)b * L + key) * rs + Hd + head * DH + 4 * g;
+        float* vp = kp + Hd;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            *(f32x4*)(kp + dt * 16) = dk[dt] * scale;
+            *(f32x4*)(vp + dt * 16) = dv[dt];
+        }
+    }
+}
+
+template <class P, int DH>
+int launch_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, float scale, hipStream_t st) {
+    hipLaunchKernelGGL((attn_fwd_kernel<P, DH>), dim3(cdiv(L, 64), heads, B), dim3(256), 0, st, qkv, out, lse, L, heads, scale);
+    return unetr_check_launch();
+}
+template <class P, int DH>
+int launch_bwd(const float* qkv, const float* dout, const float* lse, const float* delta, float* dqkv, int B, int L, int heads,
+               float scale, hipStream_t st) {
+    dim3 grid(cdiv(L, 64), heads, B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, L, heads, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, L, heads, scale);
+    return unetr_check_launch();
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(CALL)                                                                   \
+    if (prec == UNETR_PREC_F32) {                                                             \
+        if (dh == 32) return CALL(PrecF32, 32);                                               \
+        if (dh == 64) return CALL(PrecF32, 64);                                               \
+        if (dh == 128) return CALL(PrecF32, 128);                                             \
+    } else if (prec == UNETR_PREC_BF16) {                                                     \
+        if (dh == 32) return CALL(PrecBF16, 32);                                              \
+        if (dh == 64) return CALL(PrecBF16, 64);                                              \
+        if (dh == 128) return CALL(PrecBF16, 128);                                            \
+    }                                                                                         \
+    return UNETR_ERR_UNSUPPORTED;
+
+extern "C" int unetr_attention_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, int dh,
+                                   float scale, int prec, void* stream) {
+    if (!qkv || !out || !lse || B <= 0 || L <= 0 || heads <= 0 || B > 65535 || heads > 65535) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL_FWD(PP, DD) launch_fwd<PP, DD>(qkv, out, lse, B, L, heads, scale, st)
+    ATTN_DISPATCH(CALL_FWD)
+}
+
+extern "C" int unetr_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                                   float* dqkv, float* delta, int B, int L, int heads, int dh, float scale, int prec,
+                                   void* stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || !delta || B <= 0 || L <= 0 || heads <= 0 || B > 65535 || heads > 65535)
+        return UNETR_ERR_ARG;
+    if (dh & 3) return UNETR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    long total = (long)B * heads * L;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, out, dout, delta, B, L, heads, dh);
+#define CALL_BWD(PP, DD) launch_bwd<PP, DD>(qkv, dout, lse, delta, dqkv, B, L, heads, scale, st)
+    ATTN_DISPATCH(CALL_BWD)
+}

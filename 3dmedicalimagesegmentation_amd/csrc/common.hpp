@@ -1,0 +1,88 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) UNETR kernels.
+//
+// Precision policy: every contraction is written once against a "16-byte chunk" abstraction and
+// instantiated twice:
+//   PrecF32  : chunk = 4 x f32, contraction on v_mfma_f32_16x16x4_f32  (bit-exact fp32 fma chains;
+//              the parity mode that must hold 1e-3 against the CPU oracle)
+//   PrecBF16 : chunk = 8 x bf16, contraction on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; perf mode)
+// In both modes a "k-block" is 4 chunks (64 bytes) per row: lane group g = lane>>4 owns chunk g, and the
+// A and B operands use the same lane->k map, so any k permutation inside a k-block cancels out.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define UNETR_OK 0
+#define UNETR_ERR_ARG 1
+#define UNETR_ERR_LAUNCH 2
+#define UNETR_ERR_UNSUPPORTED 3
+#define UNETR_ERR_WORKSPACE 4
+
+#define UNETR_PREC_F32 0
+#define UNETR_PREC_BF16 1
+
+static inline int unetr_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETR_OK : UNETR_ERR_LAUNCH;
+}
+
+struct PrecF32 {
+    static constexpr int CH = 4;   // elements per 16-byte chunk
+    static __device__ __forceinline__ u32x4 pack(const float* v) {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        return __builtin_bit_cast(u32x4, t);
+    }
+    // acc(16x16) += A(16 x 16k) * B(16k x 16): lane group g holds k = 4g+t in element t
+    static __device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
+        f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+    }
+};
+
+struct PrecBF16 {
+    static constexpr int CH = 8;
+    static __device__ __forceinline__ u32x4 pack(const float* v) {
+        f32x8 t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        bf16x8 b = __builtin_convertvector(t, bf16x8);
+        return __builtin_bit_cast(u32x4, b);
+    }
+    static __device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+
+// XOR-swizzled LDS tile of 128-byte rows (8 chunks): conflict-free for the 16x16 fragment read
+// (lane l reads row l&15, chunk (l>>4)+4*kb) under the ds_read_b128 lane grouping.
+__device__ __forceinline__ int lds_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,516 @@
+// Generic MFMA GEMM family for gfx950: C[M,N] = epilogue(A[M,K] * B[K,N]), batched, split-K.
+//
+// One kernel template, parameterised by
+//   P        precision policy (PrecF32 -> v_mfma_f32_16x16x4_f32, PrecBF16 -> v_mfma_f32_16x16x32_bf16)
+//   AL / BL  operand loaders ("give me CH consecutive-k fp32 values of row r"), which is how the same
+//            kernel serves torch Linear fwd / dgrad / wgrad, the 1x1x1 conv, and the 2x2x2 transposed
+//            conv (a GEMM [voxels, Cin] x [Cin, 8*Cout] with a pixel-shuffle store)
+//   EP       epilogue functor (bias, exact GELU, GELU', residual, accumulate, scatter stores)
+//   WM,WN    16x16 MFMA tiles per wave; WVM,WVN waves per block.
+//
+// Data path: fp32 in HBM -> registers (converted to the MFMA operand type) -> XOR-swizzled LDS tile of
+// 128-byte rows (2 k-blocks) -> ds_read_b128 fragments -> MFMA.  Global loads of stage t+1 are issued
+// before the MFMAs of stage t (register prefetch), the LDS tile is single-buffered.
+#include <algorithm>
+#include "common.hpp"
+#include "../../include/unetr_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ loaders
+struct LdRow {  // element(row,k) = p[b*stride + row*ld + k]        (k contiguous)
+    static constexpr bool KCONTIG = true;
+    const float* p; long ld, stride; int rows, vec;
+    template <int CH>
+    __device__ __forceinline__ void load(int b, int row, int k, int kend, float* v) const {
+        if (row < rows && k < kend) {
+            const float* q = p + (long)b * stride + (long)row * ld + k;
+            if (vec && k + CH <= kend) {
+#pragma unroll
+                for (int c = 0; c < CH / 4; ++c) {
+                    f32x4 t = *(const f32x4*)(q + 4 * c);
+                    v[4 * c] = t[0]; v[4 * c + 1] = t[1]; v[4 * c + 2] = t[2]; v[4 * c + 3] = t[3];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) v[j] = (k + j < kend) ? q[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] = 0.f;
+        }
+    }
+};
+
+struct LdCol {  // element(row,k) = p[b*stride + k*ld + row]        (row contiguous)
+    static constexpr bool KCONTIG = false;
+    const float* p; long ld, stride; int rows, vec;
+    template <int CH>
+    __device__ __forceinline__ void load(int b, int row, int k, int kend, float* v) const {
+        const float* q = p + (long)b * stride + row;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = (row < rows && k + j < kend) ? q[(long)(k + j) * ld] : 0.f;
+    }
+};
+
+// geometry of a 2x2x2 stride-2 transposed conv; m indexes the INPUT grid [B,D,H,W]
+struct TcGeom {
+    int D, H, W, Cout;
+    __device__ __forceinline__ long outvox(int m, int tap) const {
+        int x = m % W; int t = m / W; int y = t % H; t /= H; int z = t % D; int b = t / D;
+        int a = tap >> 2, bb = (tap >> 1) & 1, c = tap & 1;
+        return (((long)b * 2 * D + 2 * z + a) * 2 * H + 2 * y + bb) * 2 * W + 2 * x + c;
+    }
+};
+
+struct LdTcGatherA {  // dgrad A: element(m, k = tap*Cout+co) = dy[outvox(m,tap)*ld + co]
+    static constexpr bool KCONTIG = true;
+    const float* p; long ld; int rows; TcGeom g;
+    template <int CH>
+    __device__ __forceinline__ void load(int, int row, int k, int kend, float* v) const {
+        if (row < rows && k < kend) {
+            int tap = k / g.Cout, co = k - tap * g.Cout;
+            if (co + CH <= g.Cout && ((ld | co) & 3) == 0) {
+                const float* q = p + g.outvox(row, tap) * ld + co;
+#pragma unroll
+                for (int c = 0; c < CH / 4; ++c) {
+                    f32x4 t = *(const f32x4*)(q + 4 * c);
+                    v[4 * c] = t[0]; v[4 * c + 1] = t[1]; v[4 * c + 2] = t[2]; v[4 * c + 3] = t[3];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    int kk = k + j; int tp = kk / g.Cout, cc = kk - tp * g.Cout;
+                    v[j] = kk < kend ? p[g.outvox(row, tp) * ld + cc] : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] = 0.f;
+        }
+    }
+};
+
+struct LdTcGatherB {  // wgrad B: element(n = tap*Cout+co, k = m) = dy[outvox(m,tap)*ld + co]
+    static constexpr bool KCONTIG = false;
+    const float* p; long ld; int rows; TcGeom g;
+    template <int CH>
+    __device__ __forceinline__ void load(int, int row, int k, int kend, float* v) const {
+        int tap = row / g.Cout, co = row - tap * g.Cout;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = (row < rows && k + j < kend) ? p[g.outvox(k + j, tap) * ld + co] : 0.f;
+    }
+};
+
+struct LdTcWf {  // fwd B: element(n = tap*Cout+co, k = ci) = w[(ci*Cout+co)*8 + tap]
+    static constexpr bool KCONTIG = false;
+    const float* p; int rows; int Cout;
+    template <int CH>
+    __device__ __forceinline__ void load(int, int row, int k, int kend, float* v) const {
+        int tap = row / Cout, co = row - tap * Cout;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = (row < rows && k + j < kend) ? p[((long)(k + j) * Cout + co) * 8 + tap] : 0.f;
+    }
+};
+
+struct LdTcWd {  // dgrad B: element(n = ci, k = tap*Cout+co) = w[(ci*Cout+co)*8 + tap]
+    static constexpr bool KCONTIG = true;
+    const float* p; int rows; int Cout;
+    template <int CH>
+    __device__ __forceinline__ void load(int, int row, int k, int kend, float* v) const {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            int kk = k + j; int tap = kk / Cout, co = kk - tap * Cout;
+            v[j] = (row < rows && kk < kend) ? p[((long)row * Cout + co) * 8 + tap] : 0.f;
+        }
+    }
+};
+
+
+// geometry of a KSxKSxKS (KS = 1 or 3), stride-1, "same"-padded conv on a channels-last grid
+struct ConvGeom {
+    int D, H, W, Cin, KS;
+    __device__ __forceinline__ long srcvox(int m, int tap) const {  // -1 when the tap falls in the padding
+        if (KS == 1) return m;
+        int x = m % W; int t = m / W; int y = t % H; t /= H; int z = t % D; int b = t / D;
+        int dz = tap / 9, r = tap - dz * 9, dy = r / 3, dx = r - dy * 3;
+        z += dz - 1; y += dy - 1; x += dx - 1;
+        if ((unsigned)z >= (unsigned)D || (unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) return -1;
+        return (((long)b * D + z) * H + y) * W + x;
+    }
+};
+
+struct LdIm2colA {  // conv fwd/dgrad A: element(m = voxel, k = tap*Cin+ci) = x[srcvox(m,tap)*ld + ci]
+    static constexpr bool KCONTIG = true;
+    const float* p; long ld; int rows; ConvGeom g;
+    template <int CH>
+    __device__ __forceinline__ void load(int, int row, int k, int kend, float* v) const {
+        if (row < rows && k < kend) {
+            int tap = k / g.Cin, ci = k - tap * g.Cin;
+            if (ci + CH <= g.Cin && ((ld | ci) & 3) == 0 && k + CH <= kend) {
+                long sv = g.srcvox(row, tap);
+                if (sv >= 0) {
+                    const float* q = p + sv * ld + ci;
+#pragma unroll
+                    for (int c = 0; c < CH / 4; ++c) {
+                        f32x4 t = *(const f32x4*)(q + 4 * c);
+                        v[4 * c] = t[0]; v[4 * c + 1] = t[1]; v[4 * c + 2] = t[2]; v[4 * c + 3] = t[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) v[j] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    int kk = k + j; int tp = kk / g.Cin, cc = kk - tp * g.Cin;
+                    long sv = kk < kend ? g.srcvox(row, tp) : -1;
+                    v[j] = sv >= 0 ? p[sv * ld + cc] : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] = 0.f;
+        }
+    }
+};
+
+struct LdIm2colB {  // conv wgrad B: element(n = tap*Cin+ci, k = voxel) = x[srcvox(k,tap)*ld + ci]
+    static constexpr bool KCONTIG = false;
+    const float* p; long ld; int rows; ConvGeom g;
+    template <int CH>
+    __device__ __forceinline__ void load(int, int row, int k, int kend, float* v) const {
+        int tap = row / g.Cin, ci = row - tap * g.Cin;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            long sv = (row < rows && k + j < kend) ? g.srcvox(k + j, tap) : -1;
+            v[j] = sv >= 0 ? p[sv * ld + ci] : 0.f;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------- epilogues
+struct EpStd {
+    float* C; long ldc, strideC;
+    const float* bias;
+    const float* res; long ldr, strideR; int res_mod;
+    float* pre;
+    const float* aux; long ldaux;
+    int act, accumulate; float alpha;
+    __device__ __forceinline__ void store(int b, int m, int n, float v) const {
+        v *= alpha;
+        if (bias) v += bias[n];
+        long o = (long)b * strideC + (long)m * ldc + n;
+        if (pre) pre[o] = v;
+        if (act == 1) v = gelu_exact(v);
+        else if (act == 2) v *= gelu_grad(aux[(long)b * strideC + (long)m * ldaux + n]);
+        if (res) v += res[(long)b * strideR + (long)(m % res_mod) * ldr + n];
+        if (accumulate) v += C[o];
+        C[o] = v;
+    }
+};
+
+struct EpTcScatter {  // tconv fwd: (m = input voxel, n = tap*Cout+co) -> y[outvox(m,tap)*ld + co]
+    float* y; long ld; TcGeom g;
+    __device__ __forceinline__ void store(int, int m, int n, float v) const {
+        int tap = n / g.Cout, co = n - tap * g.Cout;
+        y[g.outvox(m, tap) * ld + co] = v;
+    }
+};
+
+struct EpTcWgrad {  // (m = ci, n = tap*Cout+co) -> dw[(ci*Cout+co)*8 + tap]
+    float* dw; int Cout;
+    __device__ __forceinline__ void store(int, int m, int n, float v) const {
+        int tap = n / Cout, co = n - tap * Cout;
+        dw[((long)m * Cout + co) * 8 + tap] = v;
+    }
+};
+
+
+struct EpConvWgrad {  // (m = co, n = tap*Cin+ci) -> dw[(co*Cin+ci)*KV + tap]   (torch Conv3d layout)
+    float* dw; int Cin, KV;
+    __device__ __forceinline__ void store(int, int m, int n, float v) const {
+        int tap = n / Cin, ci = n - tap * Cin;
+        dw[((long)m * Cin + ci) * KV + tap] = v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------- kernel
+template <class P, class AL, class BL, class EP, int WM, int WN, int WVM, int WVN>
+__global__ void __launch_bounds__(64 * WVM * WVN)
+gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, float* __restrict__ ws) {
+    constexpr int NT = 64 * WVM * WVN, BM = 16 * WM * WVM, BN = 16 * WN * WVN, CH = P::CH, SK = 8 * CH;
+    constexpr int AIT = (BM * 8 + NT - 1) / NT, BIT = (BN * 8 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * 128];
+    char* ldsA = lds;
+    char* ldsB = lds + BM * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WVN, wn = wave % WVN;
+    const int bz = blockIdx.z, batch = bz / splits, split = bz - batch * splits;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = split * kper, kend = min(K, kbeg + kper);
+    const int nk = (kend - kbeg + SK - 1) / SK;
+
+    u32x4 ra[AIT], rb[BIT];
+    auto gload = [&](int kt) {
+        const int k0 = kbeg + kt * SK;
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            int id = tid + i * NT;
+            if (id < BM * 8) {
+                int row = AL::KCONTIG ? (id >> 3) : (id % BM), c = AL::KCONTIG ? (id & 7) : (id / BM);
+                float v[CH];
+                al.template load<CH>(batch, m0 + row, k0 + c * CH, kend, v);
+                ra[i] = P::pack(v);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            int id = tid + i * NT;
+            if (id < BN * 8) {
+                int row = BL::KCONTIG ? (id >> 3) : (id % BN), c = BL::KCONTIG ? (id & 7) : (id / BN);
+                float v[CH];
+                bl.template load<CH>(batch, n0 + row, k0 + c * CH, kend, v);
+                rb[i] = P::pack(v);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            int id = tid + i * NT;
+            if (id < BM * 8) {
+                int row = AL::KCONTIG ? (id >> 3) : (id % BM), c = AL::KCONTIG ? (id & 7) : (id / BM);
+                *(u32x4*)(ldsA + lds_tile_off(row, c)) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            int id = tid + i * NT;
+            if (id < BN * 8) {
+                int row = BL::KCONTIG ? (id >> 3) : (id % BN), c = BL::KCONTIG ? (id & 7) : (id / BN);
+                *(u32x4*)(ldsB + lds_tile_off(row, c)) = rb[i];
+            }
+        }
+    };
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        lstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                a[i] = *(const u32x4*)(ldsA + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                b[j] = *(const u32x4*)(ldsB + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) P::mma(acc[i][j], a[i], b[j]);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = m0 + (wm * WM + i) * 16 + 4 * (lane >> 4) + r;
+                int n = n0 + (wn * WN + j) * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    if (splits > 1) ws[((long)bz * M + m) * N + n] = acc[i][j][r];
+                    else ep.store(batch, m, n, acc[i][j][r]);
+                }
+            }
+}
+
+template <class EP>
+__global__ void splitk_reduce_kernel(int M, int N, int splits, int batch, const float* __restrict__ ws, EP ep) {
+    long total = (long)batch * M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n = (int)(i % N); long t = i / N; int m = (int)(t % M); int b = (int)(t / M);
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += ws[(((long)b * splits + sp) * M + m) * N + n];
+        ep.store(b, m, n, s);
+    }
+}
+
+// -------------------------------------------------------------------------------------- host launch
+template <class P, class AL, class BL, class EP, int WM, int WN, int WVM, int WVN>
+int launch_cfg(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN, SK = 8 * P::CH;
+    int mt = cdiv(M, BM), nt = cdiv(N, BN);
+    int ksteps = cdiv(K, SK);
+    long tiles = (long)mt * nt * batch;
+    int splits = 1;
+    if (tiles < 256 && ksteps >= 4) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        if (splits > ksteps / 2) splits = ksteps / 2;
+        if (splits < 1) splits = 1;
+    }
+    while (splits > 1 && (size_t)splits * batch * M * N * sizeof(float) > ws_bytes) --splits;
+    if (splits > 1 && ws == nullptr) splits = 1;
+    int kper = cdiv(ksteps, splits) * SK;
+    splits = cdiv(K, kper);
+    if (nt > 65535 || (long)batch * splits > 65535) return UNETR_ERR_ARG;
+    dim3 grid(mt, nt, batch * splits);
+    hipLaunchKernelGGL((gemm_kernel<P, AL, BL, EP, WM, WN, WVM, WVN>), grid, dim3(64 * WVM * WVN), 0, st,
+                       M, N, K, splits, kper, al, bl, ep, ws);
+    if (splits > 1) {
+        long total = (long)batch * M * N;
+        int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL((splitk_reduce_kernel<EP>), dim3(blocks), dim3(256), 0, st, M, N, splits, batch, ws, ep);
+    }
+    return unetr_check_launch();
+}
+
+template <class P, class AL, class BL, class EP>
+int launch_gemm(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return UNETR_ERR_ARG;
+    if (M <= 16 && N <= 16) return launch_cfg<P, AL, BL, EP, 1, 1, 1, 1>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (M <= 16 && N <= 64) return launch_cfg<P, AL, BL, EP, 1, 2, 1, 2>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (M <= 16 && N > 64) return launch_cfg<P, AL, BL, EP, 1, 4, 1, 4>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (M <= 32 && N > 64) return launch_cfg<P, AL, BL, EP, 2, 4, 1, 4>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (N <= 16) return launch_cfg<P, AL, BL, EP, 4, 1, 4, 1>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (N <= 32) return launch_cfg<P, AL, BL, EP, 4, 2, 4, 1>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (M >= 2048 && N >= 128) return launch_cfg<P, AL, BL, EP, 4, 4, 2, 2>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    return launch_cfg<P, AL, BL, EP, 2, 2, 2, 2>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+}
+
+template <class AL, class BL, class EP>
+int launch_prec(int prec, int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (prec == UNETR_PREC_BF16) return launch_gemm<PrecBF16>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (prec == UNETR_PREC_F32) return launch_gemm<PrecF32>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    return UNETR_ERR_ARG;
+}
+
+inline int vec_ok(const float* p, long ld, long stride) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (stride & 3) == 0) ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int unetr_abi_version(void) { return 1; }
+
+extern "C" int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float* B, float* C,
+                          float* ws, size_t ws_bytes, void* stream) {
+    if (!d || !A || !B || !C) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    EpStd ep{C, d->ldc, d->strideC, d->bias, d->res, d->ldr, d->strideR, d->res_mod > 0 ? d->res_mod : d->M,
+             d->pre, d->aux, d->ldaux, d->act, d->accumulate, d->alpha};
+    if (d->act == 2 && !d->aux) return UNETR_ERR_ARG;
+    const int M = d->M, N = d->N, K = d->K, bt = d->batch;
+    if (!d->a_trans && !d->b_trans) {
+        LdRow al{A, d->lda, d->strideA, M, vec_ok(A, d->lda, d->strideA)};
+        LdRow bl{B, d->ldb, d->strideB, N, vec_ok(B, d->ldb, d->strideB)};
+        return launch_prec(d->prec, M, N, K, bt, al, bl, ep, ws, ws_bytes, st);
+    } else if (!d->a_trans && d->b_trans) {
+        LdRow al{A, d->lda, d->strideA, M, vec_ok(A, d->lda, d->strideA)};
+        LdCol bl{B, d->ldb, d->strideB, N, 0};
+        return launch_prec(d->prec, M, N, K, bt, al, bl, ep, ws, ws_bytes, st);
+    } else if (d->a_trans && d->b_trans) {
+        LdCol al{A, d->lda, d->strideA, M, 0};
+        LdCol bl{B, d->ldb, d->strideB, N, 0};
+        return launch_prec(d->prec, M, N, K, bt, al, bl, ep, ws, ws_bytes, st);
+    }
+    return UNETR_ERR_UNSUPPORTED;
+}
+
+extern "C" int unetr_tconv_fwd(const float* x, long ldx, const float* w, float* y, long ldy,
+                               int B, int D, int H, int W, int Cin, int Cout, int prec,
+                               float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y) return UNETR_ERR_ARG;
+    long M = (long)B * D * H * W;
+    if (M > 0x7fffffffL / 8) return UNETR_ERR_ARG;
+    TcGeom g{D, H, W, Cout};
+    LdRow al{x, ldx, 0, (int)M, vec_ok(x, ldx, 0)};
+    LdTcWf bl{w, 8 * Cout, Cout};
+    EpTcScatter ep{y, ldy, g};
+    return launch_prec(prec, (int)M, 8 * Cout, Cin, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int unetr_tconv_dgrad(const float* dy, long ldy, const float* w, float* dx, long ldx, int accumulate,
+                                 int B, int D, int H, int W, int Cin, int Cout, int prec,
+                                 float* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !w || !dx) return UNETR_ERR_ARG;
+    long M = (long)B * D * H * W;
+    if (M > 0x7fffffffL / 8) return UNETR_ERR_ARG;
+    TcGeom g{D, H, W, Cout};
+    LdTcGatherA al{dy, ldy, (int)M, g};
+    LdTcWd bl{w, Cin, Cout};
+    EpStd ep{dx, ldx, 0, nullptr, nullptr, 0, 0, (int)M, nullptr, nullptr, 0, 0, accumulate, 1.0f};
+    return launch_prec(prec, (int)M, Cin, 8 * Cout, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int unetr_tconv_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                                 int B, int D, int H, int W, int Cin, int Cout, int prec,
+                                 float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw) return UNETR_ERR_ARG;
+    long M = (long)B * D * H * W;
+    if (M > 0x7fffffffL / 8) return UNETR_ERR_ARG;
+    TcGeom g{D, H, W, Cout};
+    LdCol al{x, ldx, 0, Cin, 0};
+    LdTcGatherB bl{dy, ldy, 8 * Cout, g};
+    EpTcWgrad ep{dw, Cout};
+    return launch_prec(prec, Cin, 8 * Cout, (int)M, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- 3x3x3 / 1x1x1 conv through the GEMM family (im2col loaders; the general-shape path) -------------
+__global__ void conv_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int Cin, int Cout, int KV, int mode) {
+    long total = (long)Cin * Cout * KV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int tap = (int)(i % KV); long t = i / KV; int ci = (int)(t % Cin); int co = (int)(t / Cin);
+        float v = w[i];
+        if (mode == 0) o[((long)co * KV + tap) * Cin + ci] = v;                 // [Cout][KV][Cin]
+        else o[((long)ci * KV + (KV - 1 - tap)) * Cout + co] = v;               // [Cin][KV flipped][Cout]
+    }
+}
+
+extern "C" int unetr_conv_pack_weight(const float* w, float* wpack, int Cin, int Cout, int KS, int mode, void* stream) {
+    if (!w || !wpack || (KS != 1 && KS != 3)) return UNETR_ERR_ARG;
+    int KV = KS * KS * KS;
+    long total = (long)Cin * Cout * KV;
+    int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(conv_pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout, KV, mode);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_conv_gemm_fwd(const float* x, long ldx, const float* wpack, float* y, long ldy, int accumulate,
+                                   int B, int D, int H, int W, int Cin, int Cout, int KS, int prec,
+                                   float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !wpack || !y || (KS != 1 && KS != 3)) return UNETR_ERR_ARG;
+    long M = (long)B * D * H * W;
+    if (M > 0x7fffffffL) return UNETR_ERR_ARG;
+    int KV = KS * KS * KS, K = KV * Cin;
+    ConvGeom g{D, H, W, Cin, KS};
+    LdIm2colA al{x, ldx, (int)M, g};
+    LdRow bl{wpack, K, 0, Cout, vec_ok(wpack, K, 0)};
+    EpStd ep{y, ldy, 0, nullptr, nullptr, 0, 0, (int)M, nullptr, nullptr, 0, 0, accumulate, 1.0f};
+    return launch_prec(prec, (int)M, Cout, K, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int unetr_conv_gemm_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                                     int B, int D, int H, int W, int Cin, int Cout, int KS, int prec,
+                                     float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw || (KS != 1 && KS != 3)) return UNETR_ERR_ARG;
+    long M = (long)B * D * H * W;
+    if (M > 0x7fffffffL) return UNETR_ERR_ARG;
+    int KV = KS * KS * KS;
+    ConvGeom g{D, H, W, Cin, KS};
+    LdCol al{dy, ldy, 0, Cout, 0};
+    LdIm2colB bl{x, ldx, KV * Cin, g};
+    EpConvWgrad ep{dw, Cin, KV};
+    return launch_prec(prec, Cout, KV * Cin, (int)M, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,644 @@
+// HBM-bound kernels of the UNETR hot path: LayerNorm, InstanceNorm(+LeakyReLU+residual), column sums,
+// layout moves, patch gather, the 1x1x1 output conv (NCDHW logits) and fused AdamW.
+// All reductions are wave64 shuffle reductions + fixed-order partial buffers (bitwise reproducible).
+#include <algorithm>
+#include "common.hpp"
+#include "../../include/unetr_hip.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;  // float4 per lane -> H <= 2048
+
+// --------------------------------------------------------------------------------------- LayerNorm
+__global__ void __launch_bounds__(256)
+layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = H >> 2;
+    const f32x4* xr = (const f32x4*)(x + (long)row * H);
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        int i = lane + 64 * j;
+        v[j] = i < nv ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+    const float mu = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        int i = lane + 64 * j;
+        if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[j][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    f32x4* yr = (f32x4*)(y + (long)row * H);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        int i = lane + 64 * j;
+        if (i < nv) {
+            f32x4 g = ((const f32x4*)gamma)[i], b = ((const f32x4*)beta)[i], o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
+            yr[i] = o;
+        }
+    }
+}
+
+constexpr int LN_RPB = 16;  // rows per block in backward
+__global__ void __launch_bounds__(256)
+layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+                     const float* __restrict__ dres, float* __restrict__ part, int M, int H) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][H]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = H >> 2;
+    f32x4 dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) { dg[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[j] = dg[j]; }
+    for (int rr = wave; rr < LN_RPB; rr += 4) {
+        const int row = blockIdx.x * LN_RPB + rr;
+        if (row >= M) break;
+        const float mu = mean[row], rs = rstd[row];
+        const f32x4* xr = (const f32x4*)(x + (long)row * H);
+        const f32x4* dyr = (const f32x4*)(dy + (long)row * H);
+        f32x4 xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            int i = lane + 64 * j;
+            if (i < nv) {
+                f32x4 xv = xr[i], dv = dyr[i], gm = ((const f32x4*)gamma)[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float h = (xv[e] - mu) * rs;
+                    xh[j][e] = h;
+                    g[j][e] = dv[e] * gm[e];
+                    s1 += g[j][e];
+                    s2 += g[j][e] * h;
+                    dg[j][e] += dv[e] * h;
+                    db[j][e] += dv[e];
+                }
+            } else { xh[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; g[j] = xh[j]; }
+        }
+        const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+        f32x4* dxr = (f32x4*)(dx + (long)row * H);
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            int i = lane + 64 * j;
+            if (i < nv) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
+                if (dres) { f32x4 p = ((const f32x4*)(dres + (long)row * H))[i]; o += p; }
+                dxr[i] = o;
+            }
+        }
+    }
+    // cross-wave reduction of the dgamma/dbeta partials
+    f32x4* l4 = (f32x4*)lds;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        int i = lane + 64 * j;
+        if (i < nv) { l4[(wave * 2 + 0) * nv + i] = dg[j]; l4[(wave * 2 + 1) * nv + i] = db[j]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * nv; i += 256) {
+        int which = i / nv, c = i - which * nv;
+        f32x4 s = l4[(0 * 2 + which) * nv + c];
+        s += l4[(1 * 2 + which) * nv + c];
+        s += l4[(2 * 2 + which) * nv + c];
+        s += l4[(3 * 2 + which) * nv + c];
+        ((f32x4*)part)[((long)blockIdx.x * 2 + which) * nv + c] = s;
+    }
+}
+
+// out[which*H + n] = sum_blocks part[(blk*2+which)*H + n]
+__global__ void ln_finalize_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * H) return;
+    int which = i / H, n = i - which * H;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[((long)b * 2 + which) * H + n];
+    (which ? dbeta : dgamma)[n] = s;
+}
+
+// ------------------------------------------------------------------------------------------ colsum
+// grid (cdiv(N,64), RB): block sums rows rb, rb+RB, ... of 64 columns
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ x, long ld, int M, int N, float* __restrict__ out, int rb_count) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (n < N)
+        for (int m = blockIdx.y * 4 + ty; m < M; m += 4 * rb_count) s += x[(long)m * ld + n];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) out[(long)blockIdx.y * N + n] = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int RB, int N, float* __restrict__ out, int accumulate) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += part[(long)r * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// ------------------------------------------------------------------------------------ InstanceNorm
+// x: [B, V, C] pitch ld.  thread -> (channel vec cv, voxel phase); block covers VPB voxels of one batch item.
+constexpr int IN_VPB = 4096;
+
+template <int NS>  // NS sums per channel
+__device__ __forceinline__ void in_block_reduce(f32x4 (&acc)[NS], int cvn, int nphase, float* lds, float* part_out, int C) {
+    // lds: [NS][nphase][cvn] float4
+    f32x4* l4 = (f32x4*)lds;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    if (ph < nphase)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) l4[(s * nphase + ph) * cvn + cv] = acc[s];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NS * cvn; i += blockDim.x) {
+        int s = i / cvn, c = i - s * cvn;
+        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < nphase; ++p) t += l4[(s * nphase + p) * cvn + c];
+        // part_out: [NS][C]
+        *(f32x4*)(part_out + (long)s * C + 4 * c) = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+in_stats_kernel(const float* __restrict__ x, long ld, long V, int C, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cvn = C >> 2, nphase = 256 / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * IN_VPB, v1 = std::min<long>(V, v0 + IN_VPB);
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    if (ph < nphase)
+        for (long v = v0 + ph; v < v1; v += nphase) {
+            f32x4 t = *(const f32x4*)(x + ((long)b * V + v) * ld + 4 * cv);
+            acc[0] += t;
+            acc[1] += t * t;
+        }
+    in_block_reduce<2>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 2 * C, C);
+}
+
+__global__ void in_stats_final_kernel(const float* __restrict__ part, int nchunk, long V, int C, float eps,
+                                      float* __restrict__ stats, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    int b = i / C, c = i - b * C;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* p = part + ((long)b * nchunk + k) * 2 * C;
+        s += (double)p[c];
+        q += (double)p[C + c];
+    }
+    double mu = s / (double)V, var = q / (double)V - mu * mu;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mu;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : 0.01f * v; }
+
+__global__ void __launch_bounds__(256)
+in_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ sa, const float* __restrict__ x2, long ldx2,
+                const float* __restrict__ sb, float* __restrict__ y, long ldy, int B, long V, int C, int lrelu) {
+    const int cvn = C >> 2;
+    const long total = (long)B * V * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cv = (int)(i % cvn); long vox = i / cvn; int b = (int)(vox / V);
+        f32x4 t = *(const f32x4*)(x + vox * ldx + 4 * cv), o;
+        const float* s = sa + ((long)b * C + 4 * cv) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (t[e] - s[2 * e]) * s[2 * e + 1];
+        if (x2) {
+            f32x4 t2 = *(const f32x4*)(x2 + vox * ldx2 + 4 * cv);
+            const float* s2 = sb + ((long)b * C + 4 * cv) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += (t2[e] - s2[2 * e]) * s2[2 * e + 1];
+        }
+        if (lrelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = lrelu_f(o[e]);
+        }
+        *(f32x4*)(y + vox * ldy + 4 * cv) = o;
+    }
+}
+
+// backward stage 1: per (b,c) sums of g, g*n1, g*n2 with g = dy * lrelu'(n1+n2)
+__global__ void __launch_bounds__(256)
+in_bwd_reduce_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, const float* __restrict__ sa,
+                     const float* __restrict__ x2, long ldx2, const float* __restrict__ sb, long V, int C, int lrelu,
+                     float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cvn = C >> 2, nphase = 256 / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * IN_VPB, v1 = std::min<long>(V, v0 + IN_VPB);
+    f32x4 acc[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ph < nphase) {
+        const float* s1 = sa + ((long)b * C + 4 * cv) * 2;
+        const float* s2 = x2 ? sb + ((long)b * C + 4 * cv) * 2 : nullptr;
+        for (long v = v0 + ph; v < v1; v += nphase) {
+            long vox = (long)b * V + v;
+            f32x4 g = *(const f32x4*)(dy + vox * lddy + 4 * cv);
+            f32x4 t = *(const f32x4*)(x + vox * ldx + 4 * cv), n1, n2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) n1[e] = (t[e] - s1[2 * e]) * s1[2 * e + 1];
+            if (x2) {
+                f32x4 t2 = *(const f32x4*)(x2 + vox * ldx2 + 4 * cv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n2[e] = (t2[e] - s2[2 * e]) * s2[2 * e + 1];
+            }
+            if (lrelu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (n1[e] + n2[e]) > 0.f ? g[e] : 0.01f * g[e];
+            }
+            acc[0] += g;
+            acc[1] += g * n1;
+            acc[2] += g * n2;
+        }
+    }
+    in_block_reduce<3>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 3 * C, C);
+}
+
+__global__ void in_bwd_final_kernel(const float* __restrict__ part, int nchunk, long V, int C, int B, float* __restrict__ sums) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    int b = i / C, c = i - b * C;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < nchunk; ++k) {
+        const float* p = part + ((long)b * nchunk + k) * 3 * C;
+        s[0] += (double)p[c]; s[1] += (double)p[C + c]; s[2] += (double)p[2 * C + c];
+    }
+    for (int j = 0; j < 3; ++j) sums[3 * i + j] = (float)(s[j] / (double)V);
+}
+
+__global__ void __launch_bounds__(256)
+in_bwd_apply_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, const float* __restrict__ sa,
+                    const float* __restrict__ x2, long ldx2, const float* __restrict__ sb, const float* __restrict__ sums,
+                    float* __restrict__ dx, long lddx, float* __restrict__ dx2, long lddx2, int B, long V, int C, int lrelu) {
+    const int cvn = C >> 2;
+    const long total = (long)B * V * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cv = (int)(i % cvn); long vox = i / cvn; int b = (int)(vox / V);
+        const float* s1 = sa + ((long)b * C + 4 * cv) * 2;
+        const float* sm = sums + ((long)b * C + 4 * cv) * 3;
+        f32x4 g = *(const f32x4*)(dy + vox * lddy + 4 * cv);
+        f32x4 t = *(const f32x4*)(x + vox * ldx + 4 * cv), n1, n2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) n1[e] = (t[e] - s1[2 * e]) * s1[2 * e + 1];
+        const float* s2 = nullptr;
+        if (x2) {
+            s2 = sb + ((long)b * C + 4 * cv) * 2;
+            f32x4 t2 = *(const f32x4*)(x2 + vox * ldx2 + 4 * cv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) n2[e] = (t2[e] - s2[2 * e]) * s2[2 * e + 1];
+        }
+        if (lrelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (n1[e] + n2[e]) > 0.f ? g[e] : 0.01f * g[e];
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = s1[2 * e + 1] * (g[e] - sm[3 * e] - n1[e] * sm[3 * e + 1]);
+        *(f32x4*)(dx + vox * lddx + 4 * cv) = o;
+        if (x2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = s2[2 * e + 1] * (g[e] - sm[3 * e] - n2[e] * sm[3 * e + 2]);
+            *(f32x4*)(dx2 + vox * lddx2 + 4 * cv) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ layout moves
+// per batch: src [R, Ccols] (pitch lds_) -> dst [Ccols, R] (pitch ldd)
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float* __restrict__ src, long ld_s, long bs_s, float* __restrict__ dst, long ld_d, long bs_d,
+                 long R, long Cc, int accumulate) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
+    const float* s = src + (long)blockIdx.z * bs_s;
+    float* d = dst + (long)blockIdx.z * bs_d;
+    for (int j = ty; j < 32; j += 8) {
+        long r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < Cc) ? s[r * ld_s + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        long c = c0 + j, r = r0 + tx;
+        if (r < R && c < Cc) {
+            float v = tile[tx][j];
+            if (accumulate) v += d[c * ld_d + r];
+            d[c * ld_d + r] = v;
+        }
+    }
+}
+
+__global__ void patch_gather_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int D, int H, int W, int P) {
+    const int gd = D / P, gh = H / P, gw = W / P;
+    const long pd = (long)P * P * P * C;
+    const long total = (long)B * gd * gh * gw * pd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long f = i % pd; long tok = i / pd;
+        int c = (int)(f % C); long t = f / C; int p3 = (int)(t % P); t /= P; int p2 = (int)(t % P); int p1 = (int)(t / P);
+        int w3 = (int)(tok % gw); t = tok / gw; int w2 = (int)(t % gh); t /= gh; int w1 = (int)(t % gd); int b = (int)(t / gd);
+        out[i] = x[((((long)b * C + c) * D + w1 * P + p1) * H + w2 * P + p2) * W + w3 * P + p3];
+    }
+}
+
+__global__ void add_rows_kernel(float* __restrict__ y, long ldy, const float* __restrict__ a, long lda, long rows, int cols, int accumulate) {
+    const int cvn = cols >> 2;
+    const long total = rows * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cv = (int)(i % cvn); long r = i / cvn;
+        f32x4* yp = (f32x4*)(y + r * ldy + 4 * cv);
+        f32x4 v = *(const f32x4*)(a + r * lda + 4 * cv);
+        if (accumulate) v += *yp;
+        *yp = v;
+    }
+}
+
+// ------------------------------------------------------------------------- out conv (1x1x1 + bias)
+constexpr int OC_MAXCO = 16, OC_MAXCI = 64;
+__global__ void __launch_bounds__(256)
+outconv_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ logits, int B, long V, int Cin, int Cout) {
+    __shared__ float sw[OC_MAXCO * OC_MAXCI + OC_MAXCO];
+    for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[OC_MAXCO * OC_MAXCI + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const long total = (long)B * V;
+    for (long vox = (long)blockIdx.x * blockDim.x + threadIdx.x; vox < total; vox += (long)gridDim.x * blockDim.x) {
+        int b = (int)(vox / V); long v = vox - (long)b * V;
+        float acc[OC_MAXCO];
+#pragma unroll
+        for (int co = 0; co < OC_MAXCO; ++co) acc[co] = sw[OC_MAXCO * OC_MAXCI + co];
+        for (int c4 = 0; c4 < Cin; c4 += 4) {
+            f32x4 t = *(const f32x4*)(x + vox * ldx + c4);
+#pragma unroll
+            for (int co = 0; co < OC_MAXCO; ++co)
+                if (co < Cout) {
+                    const float* ww = sw + co * Cin + c4;
+                    acc[co] += t[0] * ww[0] + t[1] * ww[1] + t[2] * ww[2] + t[3] * ww[3];
+                }
+        }
+#pragma unroll
+        for (int co = 0; co < OC_MAXCO; ++co)
+            if (co < Cout) logits[((long)b * Cout + co) * V + v] = acc[co];
+    }
+}
+
+// dx[vox, ci] = sum_co dl[b,co,v] * w[co,ci];  bias-grad partials per block: part[blk][Cout]
+__global__ void __launch_bounds__(256)
+outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, float* __restrict__ dx, long lddx,
+                   float* __restrict__ part, int B, long V, int Cin, int Cout) {
+    __shared__ float sw[OC_MAXCO * OC_MAXCI];
+    __shared__ float red[4][OC_MAXCO];
+    for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    float bsum[OC_MAXCO];
+#pragma unroll
+    for (int co = 0; co < OC_MAXCO; ++co) bsum[co] = 0.f;
+    const long total = (long)B * V;
+    for (long vox = (long)blockIdx.x * blockDim.x + threadIdx.x; vox < total; vox += (long)gridDim.x * blockDim.x) {
+        int b = (int)(vox / V); long v = vox - (long)b * V;
+        float g[OC_MAXCO];
+#pragma unroll
+        for (int co = 0; co < OC_MAXCO; ++co) {
+            g[co] = co < Cout ? dl[((long)b * Cout + co) * V + v] : 0.f;
+            bsum[co] += g[co];
+        }
+        for (int c4 = 0; c4 < Cin; c4 += 4) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int co = 0; co < OC_MAXCO; ++co)
+                if (co < Cout) {
+                    const float* ww = sw + co * Cin + c4;
+                    o[0] += g[co] * ww[0]; o[1] += g[co] * ww[1]; o[2] += g[co] * ww[2]; o[3] += g[co] * ww[3];
+                }
+            *(f32x4*)(dx + vox * lddx + c4) = o;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int co = 0; co < OC_MAXCO; ++co) {
+        float s = wave_sum(bsum[co]);
+        if (lane == 0) red[wave][co] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < Cout)
+        part[(long)blockIdx.x * Cout + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// -------------------------------------------------------------------------------------------- AdamW
+__global__ void __launch_bounds__(256)
+adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4,
+             long n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ step_dev) {
+    const float step = *step_dev;
+    const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pv[e] * (1.f - lr * wd);
+            float me = b1 * mv[e] + (1.f - b1) * gv[e];
+            float ve = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
+            float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
+            pv[e] = pe - step_size * (me / denom);
+            mv[e] = me; vv[e] = ve;
+        }
+        ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+        long i = n4 * 4 + threadIdx.x;
+        float pe = p[i] * (1.f - lr * wd);
+        float me = b1 * m[i] + (1.f - b1) * g[i];
+        float ve = b2 * v[i] + (1.f - b2) * g[i] * g[i];
+        p[i] = pe - step_size * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
+        m[i] = me; v[i] = ve;
+    }
+}
+
+inline int grid_for(long total, int per_block = 256, int cap = 8192) {
+    long b = (total + per_block - 1) / per_block;
+    return (int)std::max<long>(1, std::min<long>(b, cap));
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                   float* mean, float* rstd, int M, int H, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0) return UNETR_ERR_ARG;
+    if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, M, H, eps);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, float* dx, const float* dres, float* dgamma, float* dbeta,
+                                   int M, int H, float* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0) return UNETR_ERR_ARG;
+    if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
+    int nblk = cdiv(M, LN_RPB);
+    if ((size_t)nblk * 2 * H * sizeof(float) > ws_bytes || !ws) return UNETR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, x, gamma, mean, rstd, dx,
+                       dres, ws, M, H);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 256)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate,
+                            float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !out || M <= 0 || N <= 0) return UNETR_ERR_ARG;
+    int RB = std::max(1, std::min(cdiv(M, 64), 256));
+    if (!ws || (size_t)RB * N * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), RB), dim3(256), 0, st, x, ld, M, N, ws, RB);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, ws, RB, N, out, accumulate);
+    return unetr_check_launch();
+}
+
+static int in_check(int C, long ld) {
+    if ((C & 3) || C > 1024 || (ld & 3) || (256 % (C >> 2)) != 0) return UNETR_ERR_UNSUPPORTED;
+    return UNETR_OK;
+}
+
+extern "C" int unetr_instnorm_stats(const float* x, long ld, int B, long V, int C, float eps, float* stats,
+                                    float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !stats || B <= 0 || V <= 0) return UNETR_ERR_ARG;
+    if (int e = in_check(C, ld)) return e;
+    int nchunk = cdiv(V, IN_VPB);
+    if (!ws || (size_t)B * nchunk * 2 * C * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int cvn = C >> 2, nphase = 256 / cvn;
+    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * nphase * cvn * 16, st, x, ld, V, C, ws);
+    hipLaunchKernelGGL(in_stats_final_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, ws, nchunk, V, C, eps, stats, B);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_instnorm_apply(const float* x, long ldx, const float* sa, const float* x2, long ldx2, const float* sb,
+                                    float* y, long ldy, int B, long V, int C, int lrelu, void* stream) {
+    if (!x || !sa || !y || (x2 && !sb)) return UNETR_ERR_ARG;
+    if ((C & 3) || (ldx & 3) || (ldy & 3) || (x2 && (ldx2 & 3))) return UNETR_ERR_UNSUPPORTED;
+    long total = (long)B * V * (C >> 2);
+    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, sa, x2, ldx2, sb, y, ldy, B, V, C, lrelu);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_instnorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* sa,
+                                  const float* x2, long ldx2, const float* sb, float* dx, long lddx, float* dx2, long lddx2,
+                                  int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !sa || !dx || (x2 && (!sb || !dx2))) return UNETR_ERR_ARG;
+    if (int e = in_check(C, ldx)) return e;
+    if ((lddy & 3) || (lddx & 3) || (x2 && ((ldx2 & 3) || (lddx2 & 3)))) return UNETR_ERR_UNSUPPORTED;
+    int nchunk = cdiv(V, IN_VPB);
+    size_t need = ((size_t)B * nchunk * 3 * C + (size_t)B * C * 3) * sizeof(float);
+    if (!ws || need > ws_bytes) return UNETR_ERR_WORKSPACE;
+    float* sums = ws + (size_t)B * nchunk * 3 * C;
+    hipStream_t st = (hipStream_t)stream;
+    int cvn = C >> 2, nphase = 256 / cvn;
+    hipLaunchKernelGGL(in_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), (size_t)3 * nphase * cvn * 16, st, dy, lddy, x, ldx, sa,
+                       x2, ldx2, sb, V, C, lrelu, ws);
+    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, ws, nchunk, V, C, B, sums);
+    long total = (long)B * V * (C >> 2);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, dy, lddy, x, ldx, sa, x2, ldx2, sb, sums,
+                       dx, lddx, dx2, lddx2, B, V, C, lrelu);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_nchw_to_nhwc(const float* x, float* y, long ldy, int B, int C, long V, void* stream) {
+    if (!x || !y) return UNETR_ERR_ARG;
+    // per batch: src [C rows, V cols] -> dst [V, C]
+    if (cdiv(C, 32) > 65535 || B > 65535) return UNETR_ERR_ARG;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(V, 32), B), dim3(256), 0, (hipStream_t)stream,
+                       x, V, (long)C * V, y, ldy, V * ldy, (long)C, V, 0);
+    return unetr_check_launch();
+}
+extern "C" int unetr_nhwc_to_nchw(const float* x, long ldx, float* y, int B, int C, long V, int accumulate, void* stream) {
+    if (!x || !y) return UNETR_ERR_ARG;
+    if (cdiv(C, 32) > 65535 || B > 65535) return UNETR_ERR_ARG;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(V, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, V * ldx, y, V, (long)C * V, V, (long)C, accumulate);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_patch_gather(const float* x, float* patches, int B, int C, int D, int H, int W, int P, void* stream) {
+    if (!x || !patches || P <= 0 || D % P || H % P || W % P) return UNETR_ERR_ARG;
+    long total = (long)B * C * D * H * W;
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, B, C, D, H, W, P);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_copy_rows(float* y, long ldy, const float* a, long lda, long rows, int cols, int accumulate, void* stream) {
+    if (!y || !a || (cols & 3) || (ldy & 3) || (lda & 3)) return UNETR_ERR_ARG;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (cols >> 2))), dim3(256), 0, (hipStream_t)stream, y, ldy, a, lda, rows, cols, accumulate);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_outconv_fwd(const float* x, long ldx, const float* w, const float* bias, float* logits,
+                                 int B, long V, int Cin, int Cout, void* stream) {
+    if (!x || !w || !logits) return UNETR_ERR_ARG;
+    if (Cout > OC_MAXCO || Cin > OC_MAXCI || (Cin & 3) || (ldx & 3)) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(outconv_fwd_kernel, dim3(grid_for((long)B * V)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, logits, B, V, Cin, Cout);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx, const float* w, float* dx, long lddx,
+                                 float* dw, float* dbias, int B, long V, int Cin, int Cout,
+                                 float* ws, size_t ws_bytes, void* stream) {
+    if (!dlogits || !x || !w || !dx || !dw || !dbias) return UNETR_ERR_ARG;
+    if (Cout > OC_MAXCO || Cin > OC_MAXCI || (Cin & 3) || (ldx & 3) || (lddx & 3)) return UNETR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = grid_for((long)B * V, 256, 1024);
+    size_t part_bytes = (size_t)nblk * Cout * sizeof(float);
+    size_t part_al = (part_bytes + 255) & ~(size_t)255;
+    if (!ws || part_al + 4096 > ws_bytes) return UNETR_ERR_WORKSPACE;
+    hipLaunchKernelGGL(outconv_bwd_kernel, dim3(nblk), dim3(256), 0, st, dlogits, w, dx, lddx, ws, B, V, Cin, Cout);
+    if (int e = unetr_check_launch()) return e;
+    float* ws2 = (float*)((char*)ws + part_al);
+    size_t ws2_bytes = ws_bytes - part_al;
+    // dbias = column sums of the [nblk, Cout] partials (ws2 holds the colsum's own partials)
+    {
+        int RB = std::max(1, std::min(cdiv(nblk, 64), 256));
+        if ((size_t)RB * Cout * sizeof(float) > ws2_bytes) return UNETR_ERR_WORKSPACE;
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(Cout, 64), RB), dim3(256), 0, st, ws, (long)Cout, nblk, Cout, ws2, RB);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, st, ws2, RB, Cout, dbias, 0);
+    }
+    // dw[Cout, Cin] = sum_b dl_b[Cout, V] * x_b[V, Cin]   (exact-fp32 MFMA, split-K over voxels)
+    for (int b = 0; b < B; ++b) {
+        unetr_gemm_desc d{};
+        d.M = Cout; d.N = Cin; d.K = (int)V; d.batch = 1; d.a_trans = 0; d.b_trans = 1;
+        d.lda = V; d.ldb = ldx; d.ldc = Cin; d.res_mod = Cout; d.alpha = 1.f; d.accumulate = b > 0; d.prec = UNETR_PREC_F32;
+        int e = unetr_gemm(&d, dlogits + (long)b * Cout * V, x + (long)b * V * ldx, dw, ws2, ws2_bytes, stream);
+        if (e) return e;
+    }
+    return UNETR_OK;
+}
+
+extern "C" int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, const float* step_dev, void* stream) {
+    if (!p || !g || !m || !v || !step_dev || n <= 0) return UNETR_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+        return UNETR_ERR_ARG;
+    long n4 = n >> 2;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(std::max<long>(n4, 1), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, step_dev);
+    return unetr_check_launch();
+}

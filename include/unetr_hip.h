@@ -1,0 +1,141 @@
+/*
+ * unetr_hip.h -- C ABI of libunetr_hip.so, the MI355X (gfx950) kernels behind UNETR's training hot path.
+ *
+ * The reference (ilkyyldz95/3DmedicalImageSegmentation) has no native code and no FFI: its hot path is
+ * `UNETR(nn.Module)` (unetr.py:21-208) delegating to MONAI 0.6.0 blocks and torch ATen ops.  The boundary
+ * a maintainer binds is therefore the nn.Module; this header is the C-ABI layer that
+ * module calls through ctypes.  Each entry point cites the reference call it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated; nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no host synchronisation;
+ *   - return value 0 = ok, non-zero = UNETR_ERR_* (the Python shim raises RuntimeError);
+ *   - `prec`: 0 = fp32 (v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chains), 1 = bf16 operands with fp32
+ *     accumulation (v_mfma_f32_16x16x32_bf16).  Storage is fp32 in both modes;
+ *   - feature maps are channels-last: [B, D, H, W, C] with a row pitch `ld` (floats between voxels), so a
+ *     producer can write straight into one half of a concatenation buffer (torch.cat at MONAI
+ *     UnetrUpBlock.forward, used by unetr.py:203-206, becomes free);
+ *   - token matrices are [B*L, H] row-major, which IS the channels-last view of unetr.py:177-180 proj_feat.
+ */
+#ifndef UNETR_HIP_H
+#define UNETR_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int unetr_abi_version(void);
+
+/* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
+ * replaces torch.nn.Linear forward/backward inside MONAI ViT (PatchEmbeddingBlock Linear, SABlock.qkv,
+ * SABlock.out_proj, MLPBlock.linear1/2 -- built at unetr.py:78-89) and the 1x1x1 Conv3d of UnetResBlock.conv3
+ * (unetr.py:90-174).  a_trans=0: A[m*lda+k]; a_trans=1: A[k*lda+m].  b_trans=0: B[n*ldb+k] (a torch
+ * Linear weight [N,K]); b_trans=1: B[k*ldb+n]. */
+typedef struct {
+    int M, N, K, batch;
+    int a_trans, b_trans;
+    long lda, ldb, ldc;
+    long strideA, strideB, strideC;   /* per-batch element strides */
+    const float* bias;                /* [N] or NULL */
+    const float* res;                 /* residual added after activation, row index = m % res_mod */
+    long ldr, strideR;
+    int res_mod;
+    float* pre;                       /* optional copy of the pre-activation value (same ld as C) */
+    const float* aux;                 /* act==2: multiply by gelu'(aux[m*ldaux+n]) */
+    long ldaux;
+    int act;                          /* 0 none, 1 exact-erf GELU, 2 GELU backward */
+    int accumulate;                   /* C += result */
+    float alpha;
+    int prec;
+} unetr_gemm_desc;
+int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float* B, float* C,
+               float* ws, size_t ws_bytes, void* stream);
+
+/* ---- 2x2x2 stride-2 transposed conv (nn.ConvTranspose3d, bias=False; unetr.py:99-174) ---------------
+ * x: [B,D,H,W,Cin] pitch ldx; w: torch layout [Cin,Cout,2,2,2]; y: [B,2D,2H,2W,Cout] pitch ldy. */
+int unetr_tconv_fwd(const float* x, long ldx, const float* w, float* y, long ldy,
+                    int B, int D, int H, int W, int Cin, int Cout, int prec,
+                    float* ws, size_t ws_bytes, void* stream);
+int unetr_tconv_dgrad(const float* dy, long ldy, const float* w, float* dx, long ldx, int accumulate,
+                      int B, int D, int H, int W, int Cin, int Cout, int prec,
+                      float* ws, size_t ws_bytes, void* stream);
+int unetr_tconv_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                      int B, int D, int H, int W, int Cin, int Cout, int prec,
+                      float* ws, size_t ws_bytes, void* stream);
+
+/* ---- column sums: out[n] (+)= sum_m x[m*ld+n]  (bias / position-embedding gradients) ---------------- */
+int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate,
+                 float* ws, size_t ws_bytes, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm(H), eps 1e-5, affine; MONAI TransformerBlock.norm1/2, ViT.norm) -------- */
+int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int M, int H, float eps, void* stream);
+int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                        const float* rstd, float* dx, const float* dres /* optional, added to dx */, float* dgamma, float* dbeta,
+                        int M, int H, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- multi-head self-attention core (MONAI SABlock.forward between qkv and out_proj) ----------------
+ * qkv: [B*L, 3*Hd] with feature = which*Hd + head*dh + j;  out: [B*L, Hd] ("b h l d -> b l (h d)");
+ * lse: [B, heads, L] log-sum-exp of the scaled scores (saved for backward). */
+int unetr_attention_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, int dh,
+                        float scale, int prec, void* stream);
+int unetr_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                        float* dqkv, float* delta, int B, int L, int heads, int dh, float scale, int prec,
+                        void* stream);
+
+/* ---- 3x3x3 (pad 1) and 1x1x1 conv, stride 1, no bias (nn.Conv3d in MONAI UnetResBlock.conv1/2/3) ------
+ * General-shape path: implicit GEMM through the MFMA GEMM family (im2col operand loaders, no im2col
+ * buffer).  wpack comes from unetr_conv_pack_weight: mode 0 = forward [Cout][KV][Cin]; mode 1 = data
+ * gradient (taps flipped, in/out swapped) [Cin][KV][Cout], to be used with Cin/Cout swapped. */
+int unetr_conv_pack_weight(const float* w, float* wpack, int Cin, int Cout, int KS, int mode, void* stream);
+int unetr_conv_gemm_fwd(const float* x, long ldx, const float* wpack, float* y, long ldy, int accumulate,
+                        int B, int D, int H, int W, int Cin, int Cout, int KS, int prec,
+                        float* ws, size_t ws_bytes, void* stream);
+int unetr_conv_gemm_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                          int B, int D, int H, int W, int Cin, int Cout, int KS, int prec,
+                          float* ws, size_t ws_bytes, void* stream);
+
+/* ---- InstanceNorm3d(affine=False, eps 1e-5) + LeakyReLU(0.01) + residual add -------------------------
+ * stats: [B, C, 2] = (mean, rstd). */
+int unetr_instnorm_stats(const float* x, long ld, int B, long V, int C, float eps, float* stats,
+                         float* ws, size_t ws_bytes, void* stream);
+/* y = lrelu?(norm(x;sa) [+ norm(x2;sb)]) */
+int unetr_instnorm_apply(const float* x, long ldx, const float* sa, const float* x2, long ldx2, const float* sb,
+                         float* y, long ldy, int B, long V, int C, int lrelu, void* stream);
+/* backward of y = lrelu?(norm(x) [+ norm(x2)]): writes dx (and dx2). */
+int unetr_instnorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* sa,
+                       const float* x2, long ldx2, const float* sb, float* dx, long lddx, float* dx2, long lddx2,
+                       int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- layout moves --------------------------------------------------------------------------------- */
+/* NCDHW [B,C,V] <-> channels-last [B,V,C] (pitch ld) */
+int unetr_nchw_to_nhwc(const float* x, float* y, long ldy, int B, int C, long V, void* stream);
+int unetr_nhwc_to_nchw(const float* x, long ldx, float* y, int B, int C, long V, int accumulate, void* stream);
+/* einops "b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)" (MONAI PatchEmbeddingBlock, perceptron) */
+int unetr_patch_gather(const float* x, float* patches, int B, int C, int D, int H, int W, int P, void* stream);
+/* y[r, 0:cols] (+)= a[r, 0:cols] for row-pitched matrices (skip -> concat buffer, gradient sums) */
+int unetr_copy_rows(float* y, long ldy, const float* a, long lda, long rows, int cols, int accumulate, void* stream);
+
+/* ---- 1x1x1 out conv with bias, NCDHW logits (MONAI UnetOutBlock; unetr.py:175,207) ------------------ */
+int unetr_outconv_fwd(const float* x, long ldx, const float* w, const float* bias, float* logits,
+                      int B, long V, int Cin, int Cout, void* stream);
+int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx, const float* w, float* dx, long lddx,
+                      float* dw, float* dbias, int B, long V, int Cin, int Cout,
+                      float* ws, size_t ws_bytes, void* stream);
+
+/* ---- DiceCELoss(to_onehot_y=True, softmax=True) (unetr_segmentation_3d.py:404) ----------------------
+ * logits [B,C,V] NCDHW, label [B,V] float-valued class ids.  out[0]=loss, out[1]=dice term, out[2]=ce term.
+ * coef: [B*C*2] per-(b,c) Dice gradient coefficients kept for backward. */
+int unetr_dicece_fwd(const float* logits, const float* label, int B, int C, long V, float smooth_nr,
+                     float smooth_dr, float* out, float* coef, float* ws, size_t ws_bytes, void* stream);
+int unetr_dicece_bwd(const float* logits, const float* label, const float* coef, const float* dloss,
+                     float* dlogits, int B, int C, long V, void* stream);
+
+/* ---- fused AdamW over one flat fp32 buffer (torch.optim.AdamW semantics; unetr_segmentation_3d.py:522) */
+int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, const float* step_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
