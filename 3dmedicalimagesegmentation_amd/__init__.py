@@ -6,6 +6,7 @@ The directory name starts with a digit, so import it with
 """
 from .unetr import UNETR, UNETRLogits, default_precision  # noqa: F401
 from .losses import DiceCELoss  # noqa: F401
-from . import _capi, functional  # noqa: F401
+from .optim import AdamW  # noqa: F401
+from . import _capi, ddp, functional  # noqa: F401
 
-__all__ = ["UNETR", "UNETRLogits", "DiceCELoss", "default_precision"]
+__all__ = ["UNETR", "UNETRLogits", "DiceCELoss", "AdamW", "default_precision"]

@@ -1,0 +1,189 @@
+"""bench.py -- UNETR training step throughput on MI355X (the metric of BASELINE.json).
+
+A "step" = forward + DiceCE loss + backward + AdamW on one batch of synthetic 96^3 CT-like volumes
+(config[1]: UNETR(img 96, patch 16, hidden 768, 12 layers, 12 heads, 4 classes), batch 2 per GPU), with
+inputs resident in HBM.  N GPUs = N ranks (one per GPU, RCCL), weak scaling: each rank keeps batch 2 and
+gradients are all-reduced (bucketed, side stream).  Prints ONE JSON line on rank 0.
+
+Extra objects: "roofline" for the dominant kernel (timed live with HIP events on the launch stream) and
+"cpu_baseline" (the CPU oracle = the reference's operator graph in plain PyTorch, timed on the host cores
+on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(in_channels=1, out_channels=4, img_size=(96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072,
+           num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
+    from oracle.unetr_oracle import synthetic_volume  # data generator only (shared with the tests)
+
+    torch.manual_seed(1234)  # same initial weights on every rank
+    model = pkg.UNETRLogits(**CFG).to(dev)
+    model.precision = args.precision
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    x, y = synthetic_volume(args.batch, 1, 96, 4, seed=1234 + rank)
+    x, y = x.to(dev), y.to(dev)
+
+    reducer = None
+    if dist_on:
+        reducer = pkg.ddp.GradAllReducer(model.parameters(), process_group=None)
+
+    def step():
+        logit_map = model(x)
+        loss = crit(logit_map, y)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    use_graph = not args.no_graph and not dist_on
+    # eager warm-up (allocates workspaces / optimizer state; also what graph capture needs beforehand)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            loss = step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    log(f"eager warm-up done, loss {float(loss.item()):.5f}")
+    graph = None
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = step()
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+
+    log("graph captured" if graph is not None else "eager mode")
+    for _ in range(args.warmup):
+        run_step()
+
+    def sync_all():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    out = {
+        "metric": "training volumes/sec (96^3, 4-class)", "value": round(value, 3), "unit": "volumes/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "UNETR(img=96^3,patch=16,hidden=768,layers=12,heads=12,classes=4) fwd+DiceCE+bwd+AdamW, "
+                               f"batch {args.batch}/GPU, configs[1]", "global_batch": world * args.batch,
+                   "launch": "hipGraph" if graph is not None else "eager", "final_loss": float(loss.item())},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        try:
+            from tools.roofline import dominant_kernel_roofline
+            out["roofline"] = dominant_kernel_roofline(pkg, model, crit, x, y, args.precision)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+    log("roofline done")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+        log("cpu baseline done")
+
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(args):
+    """The CPU oracle (plain PyTorch fp32, the reference's operator graph) on this host's cores."""
+    from oracle.unetr_oracle import OracleUNETR, oracle_train_step, synthetic_volume
+    # the GPU box gives one GPU a 16-CPU share; os.cpu_count() reports the whole host and oversubscribes badly
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    ref = OracleUNETR(**CFG)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-5)
+    x, y = synthetic_volume(1, 1, 96, 4, seed=1234)
+    oracle_train_step(ref, opt, x, y)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        oracle_train_step(ref, opt, x, y)
+    dt = time.perf_counter() - t0
+    return {"value": round(args.cpu_steps / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_steps} fwd+DiceCE+bwd+AdamW steps of the same 96^3 UNETR at batch 1 (1 warm-up), torch fp32, "
+                      f"{cores} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,250 @@
+"""GPU parity of every HIP kernel against a plain PyTorch fp32 CPU reference of the same op.
+Everything goes through the C ABI (ctypes) exactly as the product path does."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import TOL, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def g(*shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=gen) * scale
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(432, 768, 768), (37, 50, 44), (432, 2304, 768), (8, 128, 4096), (1000, 16, 32), (300, 32, 256),
+                                   (4096, 128, 64), (16, 300, 5000), (16, 16, 70000), (16, 40, 3000), (24, 200, 2000)])
+def test_gemm_nt_nn_tn(pkg, dev, prec, M, N, K):
+    Fn = pkg.functional
+    x, w = g(M, K, seed=1), g(N, K, seed=2)
+    ref = x @ w.t()
+    y = Fn.linear_fwd(x.to(dev), w.to(dev), None, prec)
+    assert relerr(y, ref) < TOL[prec]
+    dy = g(M, N, seed=3)
+    assert relerr(Fn.linear_dgrad(dy.to(dev), w.to(dev), prec), dy @ w) < TOL[prec]
+    assert relerr(Fn.linear_wgrad(dy.to(dev), x.to(dev), prec), dy.t() @ x) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_epilogues(pkg, dev, prec):
+    Fn = pkg.functional
+    M, N, K, L = 432, 512, 256, 216
+    x, w, b, res, pos = g(M, K, seed=1), g(N, K, seed=2, scale=0.1), g(N, seed=3), g(M, N, seed=4), g(L, N, seed=5)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    assert relerr(Fn.linear_fwd(xd, wd, bd, prec, res=res.to(dev)), x @ w.t() + b + res) < TOL[prec]
+    assert relerr(Fn.linear_fwd(xd, wd, bd, prec, res=pos.to(dev), res_mod=L), x @ w.t() + b + pos.repeat(2, 1)) < TOL[prec]
+    pre = torch.empty(M, N, device=dev)
+    y = Fn.linear_fwd(xd, wd, bd, prec, act=1, pre=pre)
+    u = x @ w.t() + b
+    assert relerr(pre, u) < TOL[prec]
+    assert relerr(y, F.gelu(u)) < TOL[prec]
+    # dgelu epilogue: dx = (dy @ w) * gelu'(aux)
+    dy, aux = g(M, N, seed=6), g(M, K, seed=7)
+    auxr = aux.clone().requires_grad_(True)
+    F.gelu(auxr).backward(dy @ w)
+    assert relerr(Fn.linear_dgrad(dy.to(dev), wd, prec, aux=aux.to(dev)), auxr.grad) < TOL[prec]
+
+
+def test_colsum(pkg, dev):
+    Fn = pkg.functional
+    for M, N in [(432, 768), (2, 216 * 768), (5000, 37)]:
+        x = g(M, N, seed=M)
+        assert relerr(Fn.colsum(x.to(dev), M, N, N), x.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M,H", [(432, 768), (8, 128), (50, 2048)])
+def test_layernorm(pkg, dev, M, H):
+    Fn = pkg.functional
+    x, w, b, dy, dres = g(M, H, seed=1) * 2 + 0.5, g(H, seed=2), g(H, seed=3), g(M, H, seed=4), g(M, H, seed=5)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (H,), wr, br, 1e-5)
+    yr.backward(dy)
+    y, mean, rstd = Fn.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev))
+    assert relerr(y, yr) < 1e-5
+    dx, dw, db = Fn.layernorm_bwd(dy.to(dev), x.to(dev), w.to(dev), mean, rstd, dres=dres.to(dev))
+    assert relerr(dx, xr.grad + dres) < 1e-5
+    assert relerr(dw, wr.grad) < 1e-5
+    assert relerr(db, br.grad) < 1e-5
+
+
+def _attn_ref(qkv, B, L, heads, dh):
+    hd = heads * dh
+    t = qkv.view(B, L, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    att = (torch.einsum("bhxd,bhyd->bhxy", q, k) * dh ** -0.5).softmax(-1)
+    return torch.einsum("bhxy,bhyd->bhxd", att, v).permute(0, 2, 1, 3).reshape(B * L, hd)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,L,heads,dh", [(2, 216, 12, 64), (1, 8, 4, 32), (1, 1000, 2, 64), (2, 100, 3, 128), (1, 33, 2, 32)])
+def test_attention(pkg, dev, prec, B, L, heads, dh):
+    Fn = pkg.functional
+    qkv = g(B * L, 3 * heads * dh, seed=L)
+    dout = g(B * L, heads * dh, seed=L + 1)
+    qr = qkv.clone().requires_grad_(True)
+    ref = _attn_ref(qr, B, L, heads, dh)
+    ref.backward(dout)
+    out, lse = Fn.attention_fwd(qkv.to(dev), B, L, heads, dh, prec)
+    assert relerr(out, ref) < TOL[prec]
+    dqkv = Fn.attention_bwd(qkv.to(dev), out, dout.to(dev), lse, B, L, heads, dh, prec)
+    hd = heads * dh
+    for i, name in enumerate("qkv"):
+        assert relerr(dqkv[:, i * hd:(i + 1) * hd], qr.grad[:, i * hd:(i + 1) * hd]) < TOL[prec], name
+
+
+def cl(x):  # NCDHW -> channels-last
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,S,cin,cout", [(2, 6, 768, 32), (1, 5, 32, 16), (2, 12, 64, 64)])
+def test_tconv(pkg, dev, prec, B, S, cin, cout):
+    Fn = pkg.functional
+    x, w, dy = g(B, cin, S, S, S, seed=1), g(cin, cout, 2, 2, 2, seed=2, scale=0.1), g(B, cout, 2 * S, 2 * S, 2 * S, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, stride=2)
+    yr.backward(dy)
+    dims = (B, S, S, S)
+    xd, wd, dyd = cl(x).to(dev), w.to(dev), cl(dy).to(dev)
+    assert relerr(ncdhw(Fn.tconv_fwd(xd, cin, wd, dims, cin, cout, prec).cpu()), yr) < TOL[prec]
+    assert relerr(ncdhw(Fn.tconv_dgrad(dyd, cout, wd, dims, cin, cout, prec).cpu()), xr.grad) < TOL[prec]
+    assert relerr(Fn.tconv_wgrad(xd, cin, dyd, cout, dims, cin, cout, prec), wr.grad) < TOL[prec]
+    # write into / read from one half of a concat buffer
+    cat = torch.zeros(B, 2 * S, 2 * S, 2 * S, 2 * cout, device=dev)
+    Fn.tconv_fwd(xd, cin, wd, dims, cin, cout, prec, out=cat, ldo=2 * cout)
+    assert relerr(ncdhw(cat[..., :cout].cpu()), yr) < TOL[prec]
+    assert cat[..., cout:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 8), 1, 16), (1, (5, 6, 7), 8, 16), (2, (12, 12, 12), 32, 16), (1, (4, 4, 4), 64, 32),
+                                              (1, (6, 5, 4), 4, 16)])
+def test_conv3(pkg, dev, prec, B, dims3, cin, cout):
+    Fn = pkg.functional
+    D, H, W = dims3
+    x, w, dy = g(B, cin, D, H, W, seed=1), g(cout, cin, 3, 3, 3, seed=2, scale=0.2), g(B, cout, D, H, W, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, padding=1)
+    yr.backward(dy)
+    dims = (B, D, H, W)
+    xd, wd, dyd = cl(x).to(dev), w.to(dev), cl(dy).to(dev)
+    y = Fn.conv_fwd(xd, cin, Fn.conv_pack(wd, 0), dims, cin, cout, 3, prec)
+    assert relerr(ncdhw(y.cpu()), yr) < TOL[prec]
+    dx = Fn.conv_fwd(dyd, cout, Fn.conv_pack(wd, 1), dims, cout, cin, 3, prec)
+    assert relerr(ncdhw(dx.cpu()), xr.grad) < TOL[prec]
+    assert relerr(Fn.conv_wgrad(xd, cin, dyd, cout, dims, cin, cout, 3, prec), wr.grad) < TOL[prec]
+
+
+@pytest.mark.parametrize("B,S,C", [(2, 12, 16), (1, 20, 32), (2, 6, 128)])
+def test_instnorm(pkg, dev, B, S, C):
+    Fn = pkg.functional
+    V = S ** 3
+    x, x2, dy = g(B, C, S, S, S, seed=1) * 1.5 + 0.3, g(B, C, S, S, S, seed=2) * 0.7 - 0.2, g(B, C, S, S, S, seed=3)
+    xd, x2d, dyd = cl(x).to(dev), cl(x2).to(dev), cl(dy).to(dev)
+    # single branch with lrelu
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.01)
+    yr.backward(dy)
+    sa = Fn.instnorm_stats(xd, C, B, V, C)
+    assert relerr(ncdhw(Fn.instnorm_apply(xd, sa, B, V, C, True).cpu()), yr) < 1e-5
+    dx, _ = Fn.instnorm_bwd(dyd, C, xd, sa, B, V, C, True)
+    assert relerr(ncdhw(dx.cpu()), xr.grad) < 2e-5
+    # two branches + lrelu
+    xr, x2r = x.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(xr, eps=1e-5) + F.instance_norm(x2r, eps=1e-5), 0.01)
+    yr.backward(dy)
+    sb = Fn.instnorm_stats(x2d, C, B, V, C)
+    assert relerr(ncdhw(Fn.instnorm_apply(xd, sa, B, V, C, True, x2=x2d, sb=sb).cpu()), yr) < 1e-5
+    dx, dx2 = Fn.instnorm_bwd(dyd, C, xd, sa, B, V, C, True, x2=x2d, sb=sb)
+    assert relerr(ncdhw(dx.cpu()), xr.grad) < 2e-5
+    assert relerr(ncdhw(dx2.cpu()), x2r.grad) < 2e-5
+
+
+def test_outconv_and_layout(pkg, dev):
+    Fn = pkg.functional
+    B, S, cin, cout = 2, 10, 16, 4
+    x, w, b, dl = g(B, cin, S, S, S, seed=1), g(cout, cin, 1, 1, 1, seed=2), g(cout, seed=3), g(B, cout, S, S, S, seed=4)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br)
+    yr.backward(dl)
+    xd = cl(x).to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = Fn.OutConvFn.apply(xd, wd, bd)
+    assert relerr(y, yr) < 1e-5
+    y.backward(dl.to(dev))
+    assert relerr(ncdhw(xd.grad.cpu()), xr.grad) < 1e-5
+    assert relerr(wd.grad, wr.grad) < 1e-4
+    assert relerr(bd.grad, br.grad) < 1e-4
+    # layout moves
+    t = cl(x).to(dev).requires_grad_(True)
+    n = Fn.ToNCDHWFn.apply(t)
+    assert torch.equal(n.cpu(), x)
+    n.backward(x.to(dev) * 2)
+    assert torch.equal(t.grad.cpu(), cl(x) * 2)
+    x4 = g(2, 4, 6, 5, 7, seed=9)
+    assert torch.equal(Fn.to_channels_last(x4.to(dev)).cpu(), cl(x4))
+
+
+def test_patch_embed(pkg, dev):
+    Fn = pkg.functional
+    from oracle.unetr_oracle import _PerceptronPatches
+    for C in (1, 2):
+        x = g(2, C, 32, 32, 48, seed=C)
+        hid, pd = 64, C * 4096
+        L = 2 * 2 * 3
+        w, b, pos = g(hid, pd, seed=5, scale=0.02), g(hid, seed=6), g(1, L, hid, seed=7)
+        wr, br, posr = w.clone().requires_grad_(True), b.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        ref = F.linear(_PerceptronPatches((16, 16, 16))(x), wr, br) + posr
+        dz = g(2, L, hid, seed=8)
+        ref.backward(dz)
+        wd, bd, posd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True), pos.to(dev).requires_grad_(True)
+        z = Fn.PatchEmbedFn.apply(x.to(dev), wd, bd, posd, 16, 0)
+        assert relerr(z, ref.reshape(2 * L, hid)) < 2e-5
+        z.backward(dz.reshape(2 * L, hid).to(dev))
+        assert relerr(wd.grad, wr.grad) < 2e-5
+        assert relerr(bd.grad, br.grad) < 2e-5
+        assert relerr(posd.grad, posr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,S", [(2, 4, 24), (1, 2, 17), (2, 3, 32)])
+def test_dicece(pkg, dev, B, C, S):
+    from oracle.unetr_oracle import oracle_dice_ce_terms
+    logits = g(B, C, S, S, S, seed=1) * 2
+    label = torch.randint(0, C, (B, 1, S, S, S), generator=torch.Generator().manual_seed(2)).float()
+    lr = logits.clone().requires_grad_(True)
+    d, c = oracle_dice_ce_terms(lr, label)
+    (d + c).backward()
+    ld = logits.to(dev).requires_grad_(True)
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    t = crit.terms(ld, label.to(dev))
+    assert relerr(t[1], d) < 1e-5 and relerr(t[2], c) < 1e-5 and relerr(t[0], d + c) < 1e-5
+    (t[0] * 1.0).backward()
+    assert relerr(ld.grad, lr.grad) < 1e-4
+
+
+def test_adamw(pkg, dev):
+    n = 100003
+    p, gr = g(n, seed=1), g(n, seed=2)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=1e-2)
+    pd = torch.zeros(n + 1, device=dev)[:n]  # 16B-aligned base
+    pd.copy_(p)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step = torch.zeros(1, device=dev)
+    for it in range(3):
+        pr.grad = gr * (it + 1)
+        opt.step()
+        step += 1
+        gd = (gr * (it + 1)).to(dev)
+        pkg._capi.call("unetr_adamw", pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2,
+                       step.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert relerr(pd, pr) < 1e-5
