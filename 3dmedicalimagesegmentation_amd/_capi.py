@@ -45,6 +45,10 @@ _SIGNATURES = {
     "unetr_conv_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv_gemm_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv_gemm_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
+    "unetr_conv3_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_conv3_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_debug_tr16": [P, P, P],
     "unetr_instnorm_stats": [P, c_long, c_int, c_long, c_int, c_float, P, P, c_size_t, P],
     "unetr_instnorm_apply": [P, c_long, P, P, c_long, P, P, c_long, c_int, c_long, c_int, c_int, P],
     "unetr_instnorm_bwd": [P, c_long, P, c_long, P, P, c_long, P, P, c_long, P, c_long, c_int, c_long, c_int, c_int, P, c_size_t, P],
@@ -59,7 +63,7 @@ _SIGNATURES = {
     "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P],
 }
 
-EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes",)
 
 _lib = None
 
@@ -78,6 +82,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.unetr_conv3_packed_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.unetr_conv3_packed_bytes.restype = c_size_t
     _lib = lib
     return lib
 

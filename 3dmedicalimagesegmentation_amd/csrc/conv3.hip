@@ -1,0 +1,404 @@
+// 3x3x3 convolution (pad 1, stride 1, no bias) on channels-last feature maps for gfx950, three kernels:
+//
+//   conv3_fwd_kernel    y[v, co] = sum_{tap, ci} x[v + off(tap), ci] * w[co, ci, tap]
+//                       (also the data gradient: same kernel on dy with flipped / transposed packed weights)
+//   conv3_wgrad_kernel  dw[co, ci, tap] = sum_v dy[v, co] * x[v + off(tap), ci]
+//   pack / reduce helpers
+//
+// Forward: a workgroup owns a 4x4x16 (z,y,x) output tile.  The 6x6x18 input halo of one channel slab
+// (one MFMA k-block: 32 bf16 / 16 f32 channels) is staged ONCE in LDS (fp32 in HBM -> MFMA operand type),
+// and all 27 taps read their A fragments straight out of that window with ds_read_b128 at a per-lane
+// voxel offset -- no im2col buffer, each input byte crosses the HBM/L2 -> LDS path once per tile.
+// B fragments (weights, pre-packed [tap][slab][co][k]) are 16-byte loads from L1/L2, double-buffered
+// across taps.  Contraction on 16x16 MFMA tiles (rows = 16 consecutive x voxels, cols = 16 out channels).
+//
+// Weight gradient: the reduction index is the voxel, so both MFMA operands need "k = voxel" fragments of
+// channel-contiguous LDS images.  In bf16 mode that is exactly what ds_read_b64_tr_b16 delivers (each lane
+// supplies the address of one row = one voxel, so the 27 shifted windows cost nothing); in fp32 mode one
+// ds_read_b32 per element does the same.  Accumulators for (tap, ci-tile) pairs stay in registers while the
+// workgroup walks many voxel tiles; per-workgroup partial sums are reduced in a fixed order.
+#include <algorithm>
+#include "common.hpp"
+#include "../../include/unetr_hip.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define LDS_AS __attribute__((address_space(3)))
+
+constexpr int TZ = 4, TY = 4, TX = 16;          // output tile
+constexpr int HZ = 6, HY = 6, HX = 18;          // halo
+constexpr int NHALO = HZ * HY * HX;             // 648
+constexpr int NVOX = TZ * TY * TX;              // 256
+
+template <class P> struct ElemOf;
+template <> struct ElemOf<PrecF32> { typedef float type; };
+template <> struct ElemOf<PrecBF16> { typedef uint16_t type; };
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+template <class T> __device__ __forceinline__ T cvt_elem(float f);
+template <> __device__ __forceinline__ float cvt_elem<float>(float f) { return f; }
+template <> __device__ __forceinline__ uint16_t cvt_elem<uint16_t>(float f) { return f2bf(f); }
+
+// ------------------------------------------------------------------------------------- weight packing
+// fwd  (mode 0): wp[tap][slab][n = co][k = ci % SL]           source w[co][ci][tap]
+// dgrad(mode 1): wp[tap'][slab][n = ci][k = co % SL]          source w[co][ci][26 - tap']   (K = Cout, N = Cin)
+template <class T>
+__global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int mode, int SL) {
+    const int K = mode ? Cout : Cin, N = mode ? Cin : Cout;
+    const int nslab = (K + SL - 1) / SL;
+    const long total = 27L * nslab * N * SL;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int kk = (int)(i % SL); long t = i / SL; int n = (int)(t % N); t /= N; int slab = (int)(t % nslab); int tap = (int)(t / nslab);
+        int k = slab * SL + kk;
+        float v = 0.f;
+        if (k < K) v = mode ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
+        wp[i] = cvt_elem<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- forward
+template <class P>
+__device__ __forceinline__ void stage_halo(const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0, int D, int H, int W,
+                                           int c0, int Cin, int nch /*chunks per voxel*/, int pitch, char* halo, int vec) {
+    constexpr int CH = P::CH;
+    for (int id = threadIdx.x; id < NHALO * nch; id += 256) {
+        int hv = id / nch, ch = id - hv * nch;
+        int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        float v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = 0.f;
+        int c = c0 + ch * CH;
+        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
+            const float* q = x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + c;
+            if (vec && c + CH <= Cin) {
+#pragma unroll
+                for (int c4 = 0; c4 < CH / 4; ++c4) {
+                    f32x4 t = *(const f32x4*)(q + 4 * c4);
+                    v[4 * c4] = t[0]; v[4 * c4 + 1] = t[1]; v[4 * c4 + 2] = t[2]; v[4 * c4 + 3] = t[3];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) v[j] = (c + j < Cin) ? q[j] : 0.f;
+            }
+        }
+        *(u32x4*)(halo + hv * pitch + ch * 16) = P::pack(v);
+    }
+}
+
+constexpr int FPITCH = 80;  // 64 B of channels (one k-block) + 16 B pad per halo voxel
+
+template <class P, int NTB>
+__global__ void __launch_bounds__(256)
+conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
+                 int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int vec) {
+    constexpr int CH = P::CH, SL = 4 * CH;
+    __shared__ __attribute__((aligned(16))) char halo[NHALO * FPITCH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % ntx; t /= ntx; const int ty = t % nty; t /= nty; const int tz = t % ntz; const int b = t / ntz;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+    const int nt0 = blockIdx.y * NTB;
+    const int nslab = (Cin + SL - 1) / SL;
+    f32x4 acc[4][NTB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int slab = 0; slab < nslab; ++slab) {
+        __syncthreads();
+        stage_halo<P>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, 4, FPITCH, halo, vec);
+        __syncthreads();
+        // B fragment of (tap, slab, n-tile j): 16 bytes at wp[((tap*nslab+slab)*Cout + n)*64 + g*16]
+        const char* wbase = wp + ((long)slab * Cout + nt0 * 16 + r) * 64 + g * 16;
+        const long wtap = (long)nslab * Cout * 64;
+        u32x4 bcur[NTB], bnxt[NTB];
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) bcur[j] = *(const u32x4*)(wbase + j * 16 * 64);
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) bnxt[j] = *(const u32x4*)(wbase + (tap + 1) * wtap + j * 16 * 64);
+            }
+            const int dz = tap / 9, rem = tap - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+            const char* hbase = halo + ((((wv + dz) * HY + dy) * HX) + (r + dx)) * FPITCH + g * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4 a = *(const u32x4*)(hbase + i * HX * FPITCH);
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, bcur[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) bcur[j] = bnxt[j];
+        }
+    }
+    const int zo = z0 + wv;
+    if (zo < D) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yo = y0 + i;
+            if (yo >= H) continue;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int xo = x0 + 4 * g + rr;
+                if (xo >= W) continue;
+                float* yp = y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r;
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) {
+                    float v = acc[i][j][rr];
+                    if (accumulate) v += yp[j * 16];
+                    yp[j * 16] = v;
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------- weight grad
+// workgroup = (voxel-tile group, 32-channel ci slab, 16-channel co tile); 54 (tap, ci-tile) units over 4 waves
+template <class P> struct WgCfg {
+    typedef typename ElemOf<P>::type T;
+    static constexpr int ES = sizeof(T);
+    static constexpr int PX = 32 * ES + 16;   // halo image pitch (32 channels)
+    static constexpr int PY = 16 * ES + 16;   // dy image pitch (16 channels)
+    static constexpr int KV = 4 * P::CH;      // voxels per MFMA k-block (32 bf16 / 16 f32)
+    static constexpr int NKB = NVOX / KV;
+};
+constexpr int WG_UNITS = 54, WG_UPW = 14;  // units per wave (ceil(54/4))
+
+template <class P>
+__global__ void __launch_bounds__(256)
+conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
+                   int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles, int vecx, int vecy) {
+    using C = WgCfg<P>;
+    typedef typename C::T T;
+    constexpr int CH = P::CH;
+    __shared__ __attribute__((aligned(16))) char lds[NHALO * C::PX + NVOX * C::PY];
+    char* ximg = lds;
+    char* yimg = lds + NHALO * C::PX;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 16;
+    // per-unit LDS byte offsets of the shifted window (wave-uniform)
+    int uoff[WG_UPW];
+#pragma unroll
+    for (int ui = 0; ui < WG_UPW; ++ui) {
+        int u = wv + 4 * ui;
+        int tap = u >> 1, cit = u & 1;
+        int dz = tap / 9, rem = tap - dz * 9, dyy = rem / 3, dx = rem - dyy * 3;
+        uoff[ui] = ((dz * HY + dyy) * HX + dx) * C::PX + cit * 16 * C::ES;
+    }
+    f32x4 acc[WG_UPW];
+#pragma unroll
+    for (int ui = 0; ui < WG_UPW; ++ui) acc[ui] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % ntx; t /= ntx; const int ty = t % nty; t /= nty; const int tz = t % ntz; const int b = t / ntz;
+        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+        __syncthreads();
+        stage_halo<P>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, 32 / CH, C::PX, ximg, vecx);
+        // dy tile: 256 voxels x 16 channels
+        for (int id = threadIdx.x; id < NVOX * (16 / CH); id += 256) {
+            int v = id / (16 / CH), ch = id - v * (16 / CH);
+            int vz = v >> 6, vy = (v >> 4) & 3, vx = v & 15;
+            int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+            float vals[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) vals[j] = 0.f;
+            int cc = co0 + ch * CH;
+            if (gz < D && gy < H && gx < W && cc < Cout) {
+                const float* q = dy + ((((long)b * D + gz) * H + gy) * W + gx) * lddy + cc;
+                if (vecy && cc + CH <= Cout) {
+#pragma unroll
+                    for (int c4 = 0; c4 < CH / 4; ++c4) {
+                        f32x4 tt = *(const f32x4*)(q + 4 * c4);
+                        vals[4 * c4] = tt[0]; vals[4 * c4 + 1] = tt[1]; vals[4 * c4 + 2] = tt[2]; vals[4 * c4 + 3] = tt[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) vals[j] = (cc + j < Cout) ? q[j] : 0.f;
+                }
+            }
+            *(u32x4*)(yimg + v * C::PY + ch * 16) = P::pack(vals);
+        }
+        __syncthreads();
+
+        for (int kb = 0; kb < C::NKB; ++kb) {
+            if constexpr (CH == 8) {
+                // bf16: k-block = 32 voxels; lane (c = 4q+p, g) addresses voxel rows 8g+q and 8g+4+q
+                const int q = c >> 2, p = c & 3;
+                const int v0 = kb * 32 + 8 * g + q, v1 = v0 + 4;
+                LDS_AS s16x4* ya0 = (LDS_AS s16x4*)(yimg + v0 * C::PY + 8 * p);
+                LDS_AS s16x4* ya1 = (LDS_AS s16x4*)(yimg + v1 * C::PY + 8 * p);
+                s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ya0);
+                s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ya1);
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                const u32x4 afrag = __builtin_bit_cast(u32x4, a8);
+                const int h0 = (((v0 >> 6) * HY + ((v0 >> 4) & 3)) * HX + (v0 & 15)) * C::PX + 8 * p;
+                const int h1 = (((v1 >> 6) * HY + ((v1 >> 4) & 3)) * HX + (v1 & 15)) * C::PX + 8 * p;
+#pragma unroll
+                for (int ui = 0; ui < WG_UPW; ++ui) {
+                    if (wv + 4 * ui < WG_UNITS) {
+                        s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + h0 + uoff[ui]));
+                        s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + h1 + uoff[ui]));
+                        s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                        P::mma(acc[ui], afrag, __builtin_bit_cast(u32x4, b8));
+                    }
+                }
+            } else {
+                // f32: k-block = 16 voxels; lane (c, g) holds voxels 4g+t for channel c
+                float av[4];
+                int hb[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    int v = kb * 16 + 4 * g + tt;
+                    av[tt] = *(const float*)(yimg + v * C::PY + c * 4);
+                    hb[tt] = (((v >> 6) * HY + ((v >> 4) & 3)) * HX + (v & 15)) * C::PX + c * 4;
+                }
+#pragma unroll
+                for (int ui = 0; ui < WG_UPW; ++ui) {
+                    if (wv + 4 * ui < WG_UNITS) {
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            float bv = *(const float*)(ximg + hb[tt] + uoff[ui]);
+                            acc[ui] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], bv, acc[ui], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // partial sums: part[blockIdx.x][co][ci][tap]
+#pragma unroll
+    for (int ui = 0; ui < WG_UPW; ++ui) {
+        int u = wv + 4 * ui;
+        if (u < WG_UNITS) {
+            int tap = u >> 1, cit = u & 1;
+            int ci = ci0 + cit * 16 + c;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int co = co0 + 4 * g + rr;
+                if (ci < Cin && co < Cout) part[(((long)blockIdx.x * Cout + co) * Cin + ci) * 27 + tap] = acc[ui][rr];
+            }
+        }
+    }
+}
+
+__global__ void conv3_wgrad_reduce_kernel(const float* __restrict__ part, int G, long n, float* __restrict__ dw) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int gI = 0; gI < G; ++gI) s += part[(long)gI * n + i];
+        dw[i] = s;
+    }
+}
+
+// probe of the ds_read_b64_tr_b16 lane map (documented in cdna_hip_programming.md T10); used by a GPU test
+__global__ void tr16_probe_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[64 * 64];
+    for (int i = threadIdx.x; i < 64 * 64; i += 64) lds[i] = in[i];
+    __syncthreads();
+    const int l = threadIdx.x, grp = l >> 4, i = l & 15, q = i >> 2, p = i & 3;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(lds + (grp * 4 + q) * 64 + 4 * p));
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)v[j];
+}
+
+template <class P>
+int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st) {
+    typedef typename ElemOf<P>::type T;
+    const int SL = 4 * P::CH, K = mode ? Cout : Cin, N = mode ? Cin : Cout;
+    long total = 27L * ((K + SL - 1) / SL) * N * SL;
+    int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL((conv3_pack_kernel<T>), dim3(blocks), dim3(256), 0, st, w, (T*)wp, Cin, Cout, mode, SL);
+    return unetr_check_launch();
+}
+
+template <class P>
+int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accumulate, int B, int D, int H, int W, int Cin, int Cout,
+          hipStream_t st) {
+    const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
+    const long spatial = (long)B * ntx * nty * ntz;
+    const int ntn = Cout / 16;
+    int ntb = 1;
+    if ((ntn & (ntn - 1)) == 0) {  // power of two
+        ntb = std::min(ntn, 8);
+        while (ntb > 1 && spatial * (ntn / ntb) < 512) ntb >>= 1;
+    }
+    const int vec = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
+    dim3 grid((unsigned)spatial, ntn / ntb);
+#define LAUNCH_FWD(NTB_) hipLaunchKernelGGL((conv3_fwd_kernel<P, NTB_>), grid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
+                                           accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, vec)
+    switch (ntb) {
+        case 1: LAUNCH_FWD(1); break;
+        case 2: LAUNCH_FWD(2); break;
+        case 4: LAUNCH_FWD(4); break;
+        case 8: LAUNCH_FWD(8); break;
+        default: return UNETR_ERR_UNSUPPORTED;
+    }
+    return unetr_check_launch();
+}
+
+template <class P>
+int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int D, int H, int W, int Cin, int Cout,
+            float* ws, size_t ws_bytes, hipStream_t st) {
+    const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
+    const long ntiles = (long)B * ntx * nty * ntz;
+    const int nci = cdiv(Cin, 32), nco = cdiv(Cout, 16);
+    const long n = 27L * Cin * Cout;
+    long G = std::max<long>(1, 1024 / ((long)nci * nco));
+    G = std::min(G, ntiles);
+    while (G > 1 && (size_t)G * n * sizeof(float) > ws_bytes) G >>= 1;
+    if (!ws || (size_t)G * n * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    if (nci > 65535 || nco > 65535) return UNETR_ERR_ARG;
+    const int vecx = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
+    const int vecy = (((uintptr_t)dy & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((conv3_wgrad_kernel<P>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, ws, D, H, W, Cin, Cout,
+                       ntx, nty, ntz, (int)ntiles, vecx, vecy);
+    int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, (int)G, n, dw);
+    return unetr_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t unetr_conv3_packed_bytes(int Cin, int Cout, int mode, int prec) {
+    const int SL = prec == UNETR_PREC_BF16 ? 32 : 16, es = prec == UNETR_PREC_BF16 ? 2 : 4;
+    const int K = mode ? Cout : Cin, N = mode ? Cin : Cout;
+    return (size_t)27 * ((K + SL - 1) / SL) * N * SL * es;
+}
+
+extern "C" int unetr_conv3_pack_weight(const float* w, void* wpack, int Cin, int Cout, int mode, int prec, void* stream) {
+    if (!w || !wpack || Cin <= 0 || Cout <= 0) return UNETR_ERR_ARG;
+    if (prec == UNETR_PREC_BF16) return pack_t<PrecBF16>(w, wpack, Cin, Cout, mode, (hipStream_t)stream);
+    if (prec == UNETR_PREC_F32) return pack_t<PrecF32>(w, wpack, Cin, Cout, mode, (hipStream_t)stream);
+    return UNETR_ERR_ARG;
+}
+
+extern "C" int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, float* y, long ldy, int accumulate,
+                               int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream) {
+    if (!x || !wpack || !y || B <= 0) return UNETR_ERR_ARG;
+    if (Cout % 16) return UNETR_ERR_UNSUPPORTED;
+    if (prec == UNETR_PREC_BF16) return fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, accumulate, B, D, H, W, Cin, Cout, (hipStream_t)stream);
+    if (prec == UNETR_PREC_F32) return fwd_t<PrecF32>(x, ldx, wpack, y, ldy, accumulate, B, D, H, W, Cin, Cout, (hipStream_t)stream);
+    return UNETR_ERR_ARG;
+}
+
+extern "C" int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                                 int B, int D, int H, int W, int Cin, int Cout, int prec,
+                                 float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw || B <= 0) return UNETR_ERR_ARG;
+    if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_F32) return wgrad_t<PrecF32>(x, ldx, dy, ldy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    return UNETR_ERR_ARG;
+}
+
+extern "C" int unetr_debug_tr16(const void* in, void* out, void* stream) {
+    if (!in || !out) return UNETR_ERR_ARG;
+    hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out);
+    return unetr_check_launch();
+}

@@ -150,6 +150,43 @@ def attention_bwd(qkv, out, dout, lse, B, L, heads, dh, prec):
     return dqkv
 
 
+def _use_gemm_conv():
+    """UNETR_AMD_CONV=gemm routes 3x3x3 convs through the generic im2col-loader GEMM family instead of the
+    dedicated LDS-halo kernels (kept for cross-checking one HIP path against the other)."""
+    import os
+    return os.environ.get("UNETR_AMD_CONV", "halo") == "gemm"
+
+
+def conv3(x, ldx, w, dims, prec, mode=0, out=None, ldo=None, accumulate=False):
+    """3x3x3 conv (mode 0: w[Cout,Cin,3,3,3] applied to x with Cin channels) or its data gradient
+    (mode 1: x carries Cout channels, result has Cin channels)."""
+    B, D, H, W = dims
+    cout_w, cin_w = w.shape[0], w.shape[1]
+    cin, cout = (cin_w, cout_w) if mode == 0 else (cout_w, cin_w)
+    if _use_gemm_conv() or cout % 16 != 0:
+        return conv_fwd(x, ldx, conv_pack(w, mode), dims, cin, cout, 3, prec, out=out, ldo=ldo, accumulate=accumulate)
+    lib = _capi.load()
+    nbytes = lib.unetr_conv3_packed_bytes(cin_w, cout_w, mode, prec)
+    wp = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    call("unetr_conv3_pack_weight", w.data_ptr(), wp.data_ptr(), cin_w, cout_w, mode, prec, _stream())
+    if out is None:
+        out = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
+        ldo = cout
+    call("unetr_conv3_fwd", x.data_ptr(), ldx, wp.data_ptr(), out.data_ptr(), ldo, int(accumulate), B, D, H, W, cin, cout, prec, _stream())
+    return out
+
+
+def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec):
+    if _use_gemm_conv():
+        return conv_wgrad(x, ldx, dy, lddy, dims, cin, cout, 3, prec)
+    B, D, H, W = dims
+    dw = torch.empty(cout, cin, 3, 3, 3, dtype=torch.float32, device=x.device)
+    ws = workspace(x.device)
+    call("unetr_conv3_wgrad", x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), B, D, H, W, cin, cout, prec,
+         ws.data_ptr(), ws.numel() * 4, _stream())
+    return dw
+
+
 def conv_pack(w, mode):
     """torch Conv3d weight [Cout,Cin,k,k,k] -> GEMM operand layout (mode 0 fwd, mode 1 dgrad)."""
     cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
@@ -329,10 +366,10 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec):
     """MONAI UnetResBlock (instance norm, in != out): lrelu(IN(conv2(lrelu(IN(conv1 x)))) + IN(conv3 x))."""
     B, D, H, W = dims
     V = D * H * W
-    c1 = conv_fwd(x, ldx, conv_pack(w1, 0), dims, cin, cout, 3, prec)
+    c1 = conv3(x, ldx, w1, dims, prec)
     s1 = instnorm_stats(c1, cout, B, V, cout)
     a1 = instnorm_apply(c1, s1, B, V, cout, True)
-    c2 = conv_fwd(a1, cout, conv_pack(w2, 0), dims, cout, cout, 3, prec)
+    c2 = conv3(a1, cout, w2, dims, prec)
     s2 = instnorm_stats(c2, cout, B, V, cout)
     c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
     gemm(x, w3, c3, B * V, cout, cin, lda=ldx, ldb=cin, ldc=cout, prec=prec)
@@ -351,15 +388,15 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     dw3 = torch.empty(cout, cin, 1, 1, 1, dtype=torch.float32, device=x.device)
     gemm(dc3, x, dw3, cout, cin, B * V, lda=cout, ldb=ldx, ldc=cin, prec=_capi.PREC_F32, a_trans=True, b_trans=True)
     # conv2
-    dw2 = conv_wgrad(a1, cout, dc2, cout, dims, cout, cout, 3, prec)
-    da1 = conv_fwd(dc2, cout, conv_pack(w2, 1), dims, cout, cout, 3, prec)
+    dw2 = conv3_wgrad(a1, cout, dc2, cout, dims, cout, cout, prec)
+    da1 = conv3(dc2, cout, w2, dims, prec, mode=1)
     dc1, _ = instnorm_bwd(da1, cout, c1, s1, B, V, cout, True)
-    dw1 = conv_wgrad(x, ldx, dc1, cout, dims, cin, cout, 3, prec)
+    dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec)
     dx = None
     if need_dx:
         dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=x.device)
         gemm(dc3, w3, dx, B * V, cin, cout, lda=cout, ldb=cin, ldc=cin, prec=prec, b_trans=True)
-        conv_fwd(dc1, cout, conv_pack(w1, 1), dims, cout, cin, 3, prec, out=dx, ldo=cin, accumulate=True)
+        conv3(dc1, cout, w1, dims, prec, mode=1, out=dx, ldo=cin, accumulate=True)
     return dx, dw1, dw2, dw3
 
 

@@ -95,6 +95,19 @@ int unetr_conv_gemm_wgrad(const float* x, long ldx, const float* dy, long ldy, f
                           int B, int D, int H, int W, int Cin, int Cout, int KS, int prec,
                           float* ws, size_t ws_bytes, void* stream);
 
+/* Dedicated 3x3x3 path (csrc/conv3.hip): LDS-staged halo windows, one HBM/L2 read per tile for all 27 taps.
+ * wpack (element type follows prec) comes from unetr_conv3_pack_weight, sized by unetr_conv3_packed_bytes;
+ * mode 0 = forward, mode 1 = data gradient (then call unetr_conv3_fwd with Cin/Cout swapped).  Cout % 16 == 0. */
+size_t unetr_conv3_packed_bytes(int Cin, int Cout, int mode, int prec);
+int unetr_conv3_pack_weight(const float* w, void* wpack, int Cin, int Cout, int mode, int prec, void* stream);
+int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, float* y, long ldy, int accumulate,
+                    int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream);
+int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                      int B, int D, int H, int W, int Cin, int Cout, int prec,
+                      float* ws, size_t ws_bytes, void* stream);
+/* probe of the ds_read_b64_tr_b16 lane map used by the bf16 weight-gradient kernel (test hook) */
+int unetr_debug_tr16(const void* in_u16_64x64, void* out_u16_64x4, void* stream);
+
 /* ---- InstanceNorm3d(affine=False, eps 1e-5) + LeakyReLU(0.01) + residual add -------------------------
  * stats: [B, C, 2] = (mean, rstd). */
 int unetr_instnorm_stats(const float* x, long ld, int B, long V, int C, float eps, float* stats,

@@ -144,6 +144,42 @@ def test_conv3(pkg, dev, prec, B, dims3, cin, cout):
     assert relerr(Fn.conv_wgrad(xd, cin, dyd, cout, dims, cin, cout, 3, prec), wr.grad) < TOL[prec]
 
 
+def test_tr16_probe(pkg, dev):
+    """ds_read_b64_tr_b16: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block of
+    16-bit elements; lane i receives column i of the 4 rows (element q = row q)."""
+    src = torch.arange(64 * 64, dtype=torch.int32).to(torch.int16)
+    out = torch.zeros(64 * 4, dtype=torch.int16, device=dev)
+    pkg._capi.call("unetr_debug_tr16", src.to(dev).data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    out = out.cpu().view(64, 4)
+    for lane in range(64):
+        grp, i = lane >> 4, lane & 15
+        for q in range(4):
+            assert out[lane, q].item() == (grp * 4 + q) * 64 + i, (lane, q)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 8), 1, 16), (1, (5, 6, 7), 8, 16), (2, (12, 12, 12), 32, 16), (1, (4, 4, 4), 64, 32),
+                                              (1, (6, 5, 20), 4, 16), (1, (12, 12, 12), 256, 128), (1, (9, 17, 33), 16, 16), (1, (8, 8, 16), 48, 48)])
+def test_conv3_halo(pkg, dev, prec, B, dims3, cin, cout):
+    Fn = pkg.functional
+    D, H, W = dims3
+    x, w, dy = g(B, cin, D, H, W, seed=1), g(cout, cin, 3, 3, 3, seed=2, scale=0.2), g(B, cout, D, H, W, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, padding=1)
+    yr.backward(dy)
+    dims = (B, D, H, W)
+    xd, wd, dyd = cl(x).to(dev), w.to(dev), cl(dy).to(dev)
+    assert relerr(ncdhw(Fn.conv3(xd, cin, wd, dims, prec).cpu()), yr) < TOL[prec]
+    if cin % 16 == 0:
+        assert relerr(ncdhw(Fn.conv3(dyd, cout, wd, dims, prec, mode=1).cpu()), xr.grad) < TOL[prec]
+        # accumulate into an existing buffer with a wider pitch
+        buf = torch.ones(B, D, H, W, 2 * cin, device=dev)
+        Fn.conv3(dyd, cout, wd, dims, prec, mode=1, out=buf, ldo=2 * cin, accumulate=True)
+        assert relerr(ncdhw(buf[..., :cin].cpu()), xr.grad + 1) < TOL[prec]
+        assert (buf[..., cin:] == 1).all()
+    assert relerr(Fn.conv3_wgrad(xd, cin, dyd, cout, dims, cin, cout, prec), wr.grad) < TOL[prec]
+
+
 @pytest.mark.parametrize("B,S,C", [(2, 12, 16), (1, 20, 32), (2, 6, 128)])
 def test_instnorm(pkg, dev, B, S, C):
     Fn = pkg.functional
