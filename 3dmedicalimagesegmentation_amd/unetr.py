@@ -19,8 +19,19 @@ from typing import Tuple, Union
 import torch
 import torch.nn as nn
 
-from . import _capi
-from . import functional as Fn
+try:
+    from . import _capi
+    from . import functional as Fn
+except ImportError:
+    # imported as the top-level module `unetr` -- the reference scripts' own `from unetr import UNETR`
+    # (unetr_ranking_pretraining_3d.py:34) with this directory on sys.path: load the package by its real name
+    import importlib
+    import sys
+    _here = os.path.dirname(os.path.abspath(__file__))
+    if os.path.dirname(_here) not in sys.path:
+        sys.path.insert(0, os.path.dirname(_here))
+    _pkg = importlib.import_module(os.path.basename(_here))
+    _capi, Fn = _pkg._capi, _pkg.functional
 
 _PRECISIONS = {"fp32": _capi.PREC_F32, "bf16": _capi.PREC_BF16}
 
@@ -208,9 +219,7 @@ class UNETR(nn.Module):
 
         f = feature_size
         self.vit = _ViT(in_channels, img_size, self.patch_size, hidden_size, mlp_dim, self.num_layers)
-        for blk in self.vit.blocks:
-            for lin in (blk.attn.qkv, blk.attn.out_proj, blk.mlp.linear1, blk.mlp.linear2):
-                pass  # MONAI leaves these at torch's default Linear init (only PatchEmbeddingBlock applies trunc-normal)
+        # (MONAI leaves the transformer Linears at torch's default init; only PatchEmbeddingBlock applies trunc-normal)
         self.encoder1 = _BasicBlock(in_channels, f)
         self.encoder2 = _PrUpBlock(hidden_size, f * 2, 2)
         self.encoder3 = _PrUpBlock(hidden_size, f * 4, 1)

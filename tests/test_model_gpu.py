@@ -91,6 +91,35 @@ def test_freeze_encoder(pkg, dev):
     assert gh["vit.blocks.0.attn.qkv.weight"].grad is None and gh["decoder2.transp_conv.conv.weight"].grad is not None
 
 
+def test_against_committed_golden(pkg, dev):
+    """HIP path vs tests/golden/c1_seed0.npz (fp64-oracle vectors, see make_golden.py) -- nothing from oracle/ runs."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_seed0.npz"))
+    torch.manual_seed(0)
+    hip = pkg.UNETR(**C1)   # MONAI-equivalent seeded initialisation order is shared with the oracle's constructor
+    assert abs(sum(p.double().sum().item() for p in hip.parameters()) - float(g["weight_checksum"])) < 1e-6
+    hip = hip.to(dev)
+    hip.precision = "fp32"
+    x = torch.from_numpy(g["x"]).to(dev)
+    y = torch.from_numpy(g["y"].astype(np.float32)).to(dev)
+    enc4, logits = hip(x)
+    t = pkg.DiceCELoss(to_onehot_y=True, softmax=True).terms(logits, y)
+    t[0].backward()
+    ls = logits.detach()[0, :, ::4, ::4, ::4].cpu().numpy()
+    es = enc4.detach()[0, ::16, ::2, ::2, ::2].cpu().numpy()
+    assert np.abs(ls - g["logits_sub"]).max() < 1e-3 * float(g["logits_absmax"])
+    assert np.abs(es - g["enc4_sub"]).max() < 1e-3 * float(g["enc4_absmax"])
+    assert abs(t[1].item() - float(g["dice"])) < 1e-3 * float(g["dice"])
+    assert abs(t[2].item() - float(g["ce"])) < 1e-3 * float(g["ce"])
+    gh = dict(hip.named_parameters())
+    for k in g.files:
+        if k.startswith("grad:"):
+            ref = g[k]
+            got = gh[k[5:]].grad.flatten()[::7].cpu().numpy()
+            assert np.abs(got - ref).max() <= 1e-2 * np.abs(ref).max(), k
+
+
 def test_logits_only_and_train_step(pkg, dev):
     """monai.networks.nets.UNETR call convention + two AdamW steps reduce the loss and track the oracle."""
     from oracle.unetr_oracle import OracleUNETR, oracle_train_step, synthetic_volume

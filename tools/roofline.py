@@ -1,8 +1,15 @@
-"""Live roofline measurement for bench.py: times the hot kernels of one training step with HIP events on
-the stream they are launched on, picks the dominant kernel family and prices it against its roofline.
+"""Live roofline measurement for bench.py.
 
-Algorithmic work per launch comes from the shapes (SURVEY.md 8d / DESIGN.md): FLOPs = 2*M*N*K of the
-implicit GEMM for MFMA-bound kernels, bytes = operands read once + result written once for HBM-bound ones.
+Times the hot kernels of training steps with HIP events recorded on the stream the kernels are launched on
+(torch's current stream -- the C ABI receives exactly that stream), groups launches by (kernel family,
+shape), picks the group with the largest total time (the dominant kernel) and prices it:
+
+  algorithmic bytes  = input feature map read once + output written once + weights (fp32 storage)
+  algorithmic flops  = 2 * voxels * Cout * Cin * 27
+  bound              = "mfma" if flops/bytes exceeds the ridge (peak_flops / peak_bw) else "hbm"
+
+Peaks from /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s; dense MFMA 2.5 PFLOP/s bf16, 157.3 TFLOP/s
+fp32.  `traffic` (PMC HBM bytes) is collected offline with rocprofv3 --pmc (profiles/), null here.
 """
 import collections
 
@@ -14,7 +21,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
 def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
     Fn = pkg.functional
-    records = collections.defaultdict(list)   # family -> [(ms, flops, bytes, label)]
+    pending = []
 
     def wrap(name, fam_fn):
         orig = getattr(Fn, name)
@@ -24,26 +31,27 @@ def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
             e0.record()
             r = orig(*a, **k)
             e1.record()
-            fam, flops, nbytes, label = fam_fn(*a, **k)
-            pending.append((fam, e0, e1, flops, nbytes, label))
+            pending.append((e0, e1) + fam_fn(*a, **k))
             return r
         setattr(Fn, name, timed)
         return orig
 
-    def fam_conv_fwd(xt, ldx, wpack, dims, cin, cout, ks, prec, out=None, ldo=None, accumulate=False):
+    def fam_conv3(xt, ldx, w, dims, prec, mode=0, out=None, ldo=None, accumulate=False):
         B, D, H, W = dims
         v = B * D * H * W
-        return (f"conv{ks}x{ks}x{ks}_igemm", 2.0 * v * cout * cin * ks ** 3, 4.0 * v * (cin + cout) + 4.0 * cin * cout * ks ** 3,
-                f"{cin}->{cout}@{D}^3 B={B}")
+        cout_w, cin_w = w.shape[0], w.shape[1]
+        cin, cout = (cin_w, cout_w) if mode == 0 else (cout_w, cin_w)
+        nbytes = 4.0 * v * (cin + cout) + 4.0 * w.numel() + (4.0 * v * cout if accumulate else 0.0)
+        return ("conv3_fwd_kernel (3x3x3 LDS-halo implicit GEMM, " + ("dgrad" if mode else "fwd") + ")",
+                f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27, nbytes)
 
-    def fam_conv_wgrad(xt, ldx, dy, lddy, dims, cin, cout, ks, prec):
+    def fam_wgrad(xt, ldx, dy, lddy, dims, cin, cout, prec):
         B, D, H, W = dims
         v = B * D * H * W
-        return (f"conv{ks}x{ks}x{ks}_wgrad", 2.0 * v * cout * cin * ks ** 3, 4.0 * v * (cin + cout) + 4.0 * cin * cout * ks ** 3,
-                f"{cin}->{cout}@{D}^3 B={B}")
+        return ("conv3_wgrad_kernel (+reduce)", f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27,
+                4.0 * v * (cin + cout) + 4.0 * cin * cout * 27)
 
-    pending = []
-    saved = {"conv_fwd": wrap("conv_fwd", fam_conv_fwd), "conv_wgrad": wrap("conv_wgrad", fam_conv_wgrad)}
+    saved = {"conv3": wrap("conv3", fam_conv3), "conv3_wgrad": wrap("conv3_wgrad", fam_wgrad)}
     try:
         for _ in range(reps):
             loss = crit(model(x), y)
@@ -53,18 +61,22 @@ def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
     finally:
         for k, v in saved.items():
             setattr(Fn, k, v)
-    per_label = collections.defaultdict(list)
-    for fam, e0, e1, flops, nbytes, label in pending:
-        per_label[(fam, label)].append((e0.elapsed_time(e1), flops, nbytes))
-    # dominant = the (family, shape) with the largest total time
-    tot = {k: sum(t for t, _, _ in v) for k, v in per_label.items()}
+    groups = collections.defaultdict(list)
+    for e0, e1, fam, label, flops, nbytes in pending:
+        groups[(fam, label)].append((e0.elapsed_time(e1), flops, nbytes))
+    tot = {k: sum(t for t, _, _ in v) for k, v in groups.items()}
     (fam, label), _ = max(tot.items(), key=lambda kv: kv[1])
-    rows = per_label[(fam, label)]
+    rows = groups[(fam, label)]
     avg_ms = sum(t for t, _, _ in rows) / len(rows)
-    flops = rows[0][1]
-    achieved = flops / (avg_ms * 1e-3) / 1e12
-    peak = MFMA_PEAK_TFLOPS[precision] if "wgrad" not in fam or precision == "fp32" else MFMA_PEAK_TFLOPS[precision]
-    return {"kernel": f"{fam} {label}", "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+    flops, nbytes = rows[0][1], rows[0][2]
+    peak_tf = MFMA_PEAK_TFLOPS[precision]
+    ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if flops / nbytes > ridge:
+        bound, achieved, peak, unit = "mfma", flops / (avg_ms * 1e-3) / 1e12, peak_tf, "TFLOP/s"
+    else:
+        bound, achieved, peak, unit = "hbm", nbytes / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+    return {"kernel": fam, "shape": label, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 5), "traffic": None, "avg_ms_per_launch": round(avg_ms, 4),
-            "launches_per_step": len(rows) // reps, "algorithmic_flops_per_launch": flops,
-            "share_of_timed_kernels": round(tot[(fam, label)] / max(sum(tot.values()), 1e-9), 4)}
+            "launches_per_step": len(rows) // reps, "algorithmic_bytes_per_launch": nbytes,
+            "algorithmic_flops_per_launch": flops,
+            "share_of_conv_time": round(tot[(fam, label)] / max(sum(tot.values()), 1e-9), 4)}
