@@ -61,32 +61,48 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 }
 
 // ------------------------------------------------------------------------------------------- forward
-template <class P>
+// Stage the 6x6x18 halo of one channel slab (NCH 16-byte chunks per voxel) into LDS.  Loads are issued in
+// batches of SB chunks per thread with no dependent instruction in between, so a batch costs ONE memory
+// round trip instead of SB (the first version looped load -> convert -> ds_write per chunk and ran the
+// 96^3 convs at 1.1 TB/s).  vec: 16-byte loads (aligned, Cin % 4 == 0); otherwise predicated scalar loads.
+template <class P, int NCH>
 __device__ __forceinline__ void stage_halo(const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0, int D, int H, int W,
-                                           int c0, int Cin, int nch /*chunks per voxel*/, int pitch, char* halo, int vec) {
-    constexpr int CH = P::CH;
-    for (int id = threadIdx.x; id < NHALO * nch; id += 256) {
-        int hv = id / nch, ch = id - hv * nch;
-        int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
-        int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        float v[CH];
+                                           int c0, int Cin, int pitch, char* halo, int vec) {
+    constexpr int CH = P::CH, TOTAL = NHALO * NCH, ITERS = (TOTAL + 255) / 256, SB = 6, NQ = CH / 4;
+    for (int it0 = 0; it0 < ITERS; it0 += SB) {
+        f32x4 buf[SB][NQ];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) v[j] = 0.f;
-        int c = c0 + ch * CH;
-        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
+        for (int j = 0; j < SB; ++j) {
+            const int id = threadIdx.x + (it0 + j) * 256;
+            const int hv = id / NCH, ch = id - hv * NCH;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const int c = c0 + ch * CH;
+            const bool ok = (it0 + j < ITERS) && id < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
+                            (unsigned)gx < (unsigned)W && c < Cin;
             const float* q = x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + c;
-            if (vec && c + CH <= Cin) {
+            if (vec) {
 #pragma unroll
-                for (int c4 = 0; c4 < CH / 4; ++c4) {
-                    f32x4 t = *(const f32x4*)(q + 4 * c4);
-                    v[4 * c4] = t[0]; v[4 * c4 + 1] = t[1]; v[4 * c4 + 2] = t[2]; v[4 * c4 + 3] = t[3];
-                }
+                for (int c4 = 0; c4 < NQ; ++c4)
+                    buf[j][c4] = (ok && c + 4 * c4 + 4 <= Cin) ? *(const f32x4*)(q + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
             } else {
 #pragma unroll
-                for (int j = 0; j < CH; ++j) v[j] = (c + j < Cin) ? q[j] : 0.f;
+                for (int c4 = 0; c4 < NQ; ++c4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) buf[j][c4][e] = (ok && c + 4 * c4 + e < Cin) ? q[4 * c4 + e] : 0.f;
             }
         }
-        *(u32x4*)(halo + hv * pitch + ch * 16) = P::pack(v);
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const int id = threadIdx.x + (it0 + j) * 256;
+            if (it0 + j < ITERS && id < TOTAL) {
+                const int hv = id / NCH, ch = id - hv * NCH;
+                float v[CH];
+#pragma unroll
+                for (int c4 = 0; c4 < NQ; ++c4) { v[4 * c4] = buf[j][c4][0]; v[4 * c4 + 1] = buf[j][c4][1]; v[4 * c4 + 2] = buf[j][c4][2]; v[4 * c4 + 3] = buf[j][c4][3]; }
+                *(u32x4*)(halo + hv * pitch + ch * 16) = P::pack(v);
+            }
+        }
     }
 }
 
@@ -112,29 +128,42 @@ conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__
 
     for (int slab = 0; slab < nslab; ++slab) {
         __syncthreads();
-        stage_halo<P>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, 4, FPITCH, halo, vec);
+        stage_halo<P, 4>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, FPITCH, halo, vec);
         __syncthreads();
-        // B fragment of (tap, slab, n-tile j): 16 bytes at wp[((tap*nslab+slab)*Cout + n)*64 + g*16]
+        // B fragment of (tap, slab, n-tile j): 16 bytes at wp[((tap*nslab+slab)*Cout + n)*64 + g*16].
+        // Fragments are prefetched one GROUP of GT taps ahead (L1/L2 latency ~ a few hundred cycles must hide
+        // behind GT*4*NTB MFMAs).
+        constexpr int GT = NTB == 1 ? 9 : (NTB == 2 ? 3 : 1), NG = 27 / GT;
         const char* wbase = wp + ((long)slab * Cout + nt0 * 16 + r) * 64 + g * 16;
         const long wtap = (long)nslab * Cout * 64;
-        u32x4 bcur[NTB], bnxt[NTB];
+        u32x4 bcur[GT][NTB], bnxt[GT][NTB];
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) bcur[j] = *(const u32x4*)(wbase + j * 16 * 64);
-        for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) {
+        for (int t = 0; t < GT; ++t)
 #pragma unroll
-                for (int j = 0; j < NTB; ++j) bnxt[j] = *(const u32x4*)(wbase + (tap + 1) * wtap + j * 16 * 64);
-            }
-            const int dz = tap / 9, rem = tap - dz * 9, dy = rem / 3, dx = rem - dy * 3;
-            const char* hbase = halo + ((((wv + dz) * HY + dy) * HX) + (r + dx)) * FPITCH + g * 16;
+            for (int j = 0; j < NTB; ++j) bcur[t][j] = *(const u32x4*)(wbase + t * wtap + j * 16 * 64);
+        for (int tg = 0; tg < NG; ++tg) {
+            if (tg + 1 < NG) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u32x4 a = *(const u32x4*)(hbase + i * HX * FPITCH);
+                for (int t = 0; t < GT; ++t)
 #pragma unroll
-                for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, bcur[j]);
+                    for (int j = 0; j < NTB; ++j) bnxt[t][j] = *(const u32x4*)(wbase + ((tg + 1) * GT + t) * wtap + j * 16 * 64);
             }
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) bcur[j] = bnxt[j];
+            for (int t = 0; t < GT; ++t) {
+                const int tap = tg * GT + t;
+                const int dz = tap / 9, rem = tap - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+                const char* hbase = halo + ((((wv + dz) * HY + dy) * HX) + (r + dx)) * FPITCH + g * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32x4 a = *(const u32x4*)(hbase + i * HX * FPITCH);
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, bcur[t][j]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) bcur[t][j] = bnxt[t][j];
         }
     }
     const int zo = z0 + wv;
@@ -201,30 +230,39 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
         const int tx = t % ntx; t /= ntx; const int ty = t % nty; t /= nty; const int tz = t % ntz; const int b = t / ntz;
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
-        stage_halo<P>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, 32 / CH, C::PX, ximg, vecx);
-        // dy tile: 256 voxels x 16 channels
-        for (int id = threadIdx.x; id < NVOX * (16 / CH); id += 256) {
-            int v = id / (16 / CH), ch = id - v * (16 / CH);
-            int vz = v >> 6, vy = (v >> 4) & 3, vx = v & 15;
-            int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-            float vals[CH];
+        stage_halo<P, 32 / CH>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg, vecx);
+        // dy tile: 256 voxels x 16 channels, all loads of a thread in flight together
+        {
+            constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
+            f32x4 buf[YIT][NQ];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) vals[j] = 0.f;
-            int cc = co0 + ch * CH;
-            if (gz < D && gy < H && gx < W && cc < Cout) {
+            for (int j = 0; j < YIT; ++j) {
+                const int id = threadIdx.x + j * 256;
+                const int v = id / YCH, ch = id - v * YCH;
+                const int gz = z0 + (v >> 6), gy = y0 + ((v >> 4) & 3), gx = x0 + (v & 15);
+                const int cc = co0 + ch * CH;
+                const bool ok = gz < D && gy < H && gx < W && cc < Cout;
                 const float* q = dy + ((((long)b * D + gz) * H + gy) * W + gx) * lddy + cc;
-                if (vecy && cc + CH <= Cout) {
+                if (vecy) {
 #pragma unroll
-                    for (int c4 = 0; c4 < CH / 4; ++c4) {
-                        f32x4 tt = *(const f32x4*)(q + 4 * c4);
-                        vals[4 * c4] = tt[0]; vals[4 * c4 + 1] = tt[1]; vals[4 * c4 + 2] = tt[2]; vals[4 * c4 + 3] = tt[3];
-                    }
+                    for (int c4 = 0; c4 < NQ; ++c4)
+                        buf[j][c4] = (ok && cc + 4 * c4 + 4 <= Cout) ? *(const f32x4*)(q + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 } else {
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) vals[j] = (cc + j < Cout) ? q[j] : 0.f;
+                    for (int c4 = 0; c4 < NQ; ++c4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) buf[j][c4][e] = (ok && cc + 4 * c4 + e < Cout) ? q[4 * c4 + e] : 0.f;
                 }
             }
-            *(u32x4*)(yimg + v * C::PY + ch * 16) = P::pack(vals);
+#pragma unroll
+            for (int j = 0; j < YIT; ++j) {
+                const int id = threadIdx.x + j * 256;
+                const int v = id / YCH, ch = id - v * YCH;
+                float vals[CH];
+#pragma unroll
+                for (int c4 = 0; c4 < NQ; ++c4) { vals[4 * c4] = buf[j][c4][0]; vals[4 * c4 + 1] = buf[j][c4][1]; vals[4 * c4 + 2] = buf[j][c4][2]; vals[4 * c4 + 3] = buf[j][c4][3]; }
+                *(u32x4*)(yimg + v * C::PY + ch * 16) = P::pack(vals);
+            }
         }
         __syncthreads();
 
@@ -290,11 +328,25 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
     }
 }
 
-__global__ void conv3_wgrad_reduce_kernel(const float* __restrict__ part, int G, long n, float* __restrict__ dw) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+// dw[i] = sum_g part[g][i]: 16 outputs x 16 g-phases per workgroup, fixed summation order (reproducible)
+__global__ void __launch_bounds__(256)
+conv3_wgrad_reduce_kernel(const float* __restrict__ part, int G, long n, float* __restrict__ dw) {
+    __shared__ float sm[16][17];
+    const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    for (long i0 = (long)blockIdx.x * 16; i0 < n; i0 += (long)gridDim.x * 16) {
+        const long i = i0 + o;
         float s = 0.f;
-        for (int gI = 0; gI < G; ++gI) s += part[(long)gI * n + i];
-        dw[i] = s;
+        if (i < n)
+            for (int gI = ph; gI < G; gI += 16) s += part[(long)gI * n + i];
+        sm[ph][o] = s;
+        __syncthreads();
+        if (ph == 0 && i < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) t += sm[p][o];
+            dw[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -359,7 +411,7 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, int
     const int vecy = (((uintptr_t)dy & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
     hipLaunchKernelGGL((conv3_wgrad_kernel<P>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, ws, D, H, W, Cin, Cout,
                        ntx, nty, ntz, (int)ntiles, vecx, vecy);
-    int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+    int blocks = (int)std::min<long>((n + 15) / 16, 16384);
     hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, (int)G, n, dw);
     return unetr_check_launch();
 }

@@ -250,17 +250,20 @@ gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, floa
     const int kbeg = split * kper, kend = min(K, kbeg + kper);
     const int nk = (kend - kbeg + SK - 1) / SK;
 
-    u32x4 ra[AIT], rb[BIT];
-    auto gload = [&](int kt) {
+    // Prefetch ring of PF stages held as RAW fp32 registers: the loads of stage kt+PF are issued right after
+    // stage kt has been written to LDS, and the fp32 -> MFMA-operand conversion happens at LDS-store time, so
+    // no instruction between a load and the MFMAs of the PF-1 stages in front of it depends on it.
+    constexpr int RAWF = (AIT + BIT) * CH;                       // raw floats per thread per stage
+    constexpr int PF = RAWF <= 32 ? 3 : (RAWF <= 48 ? 2 : 1);
+    float raw[PF][AIT + BIT][CH];
+    auto gload = [&](int kt, int slot) {
         const int k0 = kbeg + kt * SK;
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             int id = tid + i * NT;
             if (id < BM * 8) {
                 int row = AL::KCONTIG ? (id >> 3) : (id % BM), c = AL::KCONTIG ? (id & 7) : (id / BM);
-                float v[CH];
-                al.template load<CH>(batch, m0 + row, k0 + c * CH, kend, v);
-                ra[i] = P::pack(v);
+                al.template load<CH>(batch, m0 + row, k0 + c * CH, kend, raw[slot][i]);
             }
         }
 #pragma unroll
@@ -268,19 +271,17 @@ gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, floa
             int id = tid + i * NT;
             if (id < BN * 8) {
                 int row = BL::KCONTIG ? (id >> 3) : (id % BN), c = BL::KCONTIG ? (id & 7) : (id / BN);
-                float v[CH];
-                bl.template load<CH>(batch, n0 + row, k0 + c * CH, kend, v);
-                rb[i] = P::pack(v);
+                bl.template load<CH>(batch, n0 + row, k0 + c * CH, kend, raw[slot][AIT + i]);
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             int id = tid + i * NT;
             if (id < BM * 8) {
                 int row = AL::KCONTIG ? (id >> 3) : (id % BM), c = AL::KCONTIG ? (id & 7) : (id / BM);
-                *(u32x4*)(ldsA + lds_tile_off(row, c)) = ra[i];
+                *(u32x4*)(ldsA + lds_tile_off(row, c)) = P::pack(raw[slot][i]);
             }
         }
 #pragma unroll
@@ -288,7 +289,7 @@ gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, floa
             int id = tid + i * NT;
             if (id < BN * 8) {
                 int row = BL::KCONTIG ? (id >> 3) : (id % BN), c = BL::KCONTIG ? (id & 7) : (id / BN);
-                *(u32x4*)(ldsB + lds_tile_off(row, c)) = rb[i];
+                *(u32x4*)(ldsB + lds_tile_off(row, c)) = P::pack(raw[slot][AIT + i]);
             }
         }
     };
@@ -299,26 +300,34 @@ gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, floa
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) gload(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        lstore();
-        __syncthreads();
-        if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            u32x4 a[WM], b[WN];
+    for (int s = 0; s < PF; ++s)
+        if (s < nk) gload(s, s);
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
-                a[i] = *(const u32x4*)(ldsA + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+        for (int s = 0; s < PF; ++s) {
+            const int kt = kt0 + s;
+            if (kt < nk) {
+                lstore(s);
+                __syncthreads();
+                if (kt + PF < nk) gload(kt + PF, s);
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-                b[j] = *(const u32x4*)(ldsB + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+                for (int kb = 0; kb < 2; ++kb) {
+                    u32x4 a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                    for (int i = 0; i < WM; ++i)
+                        a[i] = *(const u32x4*)(ldsA + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
 #pragma unroll
-                for (int j = 0; j < WN; ++j) P::mma(acc[i][j], a[i], b[j]);
+                    for (int j = 0; j < WN; ++j)
+                        b[j] = *(const u32x4*)(ldsB + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) P::mma(acc[i][j], a[i], b[j]);
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
 
 #pragma unroll
@@ -355,8 +364,8 @@ int launch_cfg(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, s
     int ksteps = cdiv(K, SK);
     long tiles = (long)mt * nt * batch;
     int splits = 1;
-    if (tiles < 256 && ksteps >= 4) {
-        splits = (int)((512 + tiles - 1) / tiles);
+    if (tiles < 512 && ksteps >= 4) {
+        splits = (int)((768 + tiles - 1) / tiles);
         if (splits > ksteps / 2) splits = ksteps / 2;
         if (splits < 1) splits = 1;
     }

@@ -153,7 +153,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int RB, int 
 
 // ------------------------------------------------------------------------------------ InstanceNorm
 // x: [B, V, C] pitch ld.  thread -> (channel vec cv, voxel phase); block covers VPB voxels of one batch item.
-constexpr int IN_VPB = 4096;
+constexpr int IN_VPB = 1024;
 
 template <int NS>  // NS sums per channel
 __device__ __forceinline__ void in_block_reduce(f32x4 (&acc)[NS], int cvn, int nphase, float* lds, float* part_out, int C) {
@@ -192,19 +192,24 @@ in_stats_kernel(const float* __restrict__ x, long ld, long V, int C, float* __re
 
 __global__ void in_stats_final_kernel(const float* __restrict__ part, int nchunk, long V, int C, float eps,
                                       float* __restrict__ stats, int B) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per (b, c): lanes stride over the chunk partials, fixed-order shuffle tree in double
+    const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= B * C) return;
-    int b = i / C, c = i - b * C;
+    const int b = i / C, c = i - b * C;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = lane; k < nchunk; k += 64) {
         const float* p = part + ((long)b * nchunk + k) * 2 * C;
         s += (double)p[c];
         q += (double)p[C + c];
     }
-    double mu = s / (double)V, var = q / (double)V - mu * mu;
-    if (var < 0.0) var = 0.0;
-    stats[2 * i] = (float)mu;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) {
+        double mu = s / (double)V, var = q / (double)V - mu * mu;
+        if (var < 0.0) var = 0.0;
+        stats[2 * i] = (float)mu;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 __device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : 0.01f * v; }
@@ -274,15 +279,18 @@ in_bwd_reduce_kernel(const float* __restrict__ dy, long lddy, const float* __res
 }
 
 __global__ void in_bwd_final_kernel(const float* __restrict__ part, int nchunk, long V, int C, int B, float* __restrict__ sums) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= B * C) return;
-    int b = i / C, c = i - b * C;
+    const int b = i / C, c = i - b * C;
     double s[3] = {0.0, 0.0, 0.0};
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = lane; k < nchunk; k += 64) {
         const float* p = part + ((long)b * nchunk + k) * 3 * C;
         s[0] += (double)p[c]; s[1] += (double)p[C + c]; s[2] += (double)p[2 * C + c];
     }
-    for (int j = 0; j < 3; ++j) sums[3 * i + j] = (float)(s[j] / (double)V);
+    for (int j = 0; j < 3; ++j) {
+        double t = wave_sum_d(s[j]);
+        if (lane == 0) sums[3 * i + j] = (float)(t / (double)V);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -529,7 +537,7 @@ extern "C" int unetr_instnorm_stats(const float* x, long ld, int B, long V, int 
     hipStream_t st = (hipStream_t)stream;
     int cvn = C >> 2, nphase = 256 / cvn;
     hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * nphase * cvn * 16, st, x, ld, V, C, ws);
-    hipLaunchKernelGGL(in_stats_final_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, ws, nchunk, V, C, eps, stats, B);
+    hipLaunchKernelGGL(in_stats_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, eps, stats, B);
     return unetr_check_launch();
 }
 
@@ -556,7 +564,7 @@ extern "C" int unetr_instnorm_bwd(const float* dy, long lddy, const float* x, lo
     int cvn = C >> 2, nphase = 256 / cvn;
     hipLaunchKernelGGL(in_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), (size_t)3 * nphase * cvn * 16, st, dy, lddy, x, ldx, sa,
                        x2, ldx2, sb, V, C, lrelu, ws);
-    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, st, ws, nchunk, V, C, B, sums);
+    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, B, sums);
     long total = (long)B * V * (C >> 2);
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, dy, lddy, x, ldx, sa, x2, ldx2, sb, sums,
                        dx, lddx, dx2, lddx2, B, V, C, lrelu);
