@@ -1,3 +1,4 @@
+#pragma once
 // Generic MFMA GEMM family for gfx950: C[M,N] = epilogue(A[M,K] * B[K,N]), batched, split-K.
 //
 // One kernel template, parameterised by
@@ -18,38 +19,50 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ loaders
-struct LdRow {  // element(row,k) = p[b*stride + row*ld + k]        (k contiguous)
+template <bool VEC>
+struct LdRowT {  // element(row,k) = p[b*stride + row*ld + k]        (k contiguous)
+    // Branch-free on purpose: out-of-range chunks load from a clamped in-range address and are zeroed by a
+    // select, so every load is issued unconditionally and hipcc can keep counted vmcnt waits for the prefetch
+    // ring (the first version's nested branches compiled to 537 branches / 89 vmcnt(0) per kernel).
+    // VEC requires 16-byte aligned base, ld % 4 == 0 and K % CH == 0 (checked on the host).
     static constexpr bool KCONTIG = true;
     const float* p; long ld, stride; int rows, vec;
     template <int CH>
     __device__ __forceinline__ void load(int b, int row, int k, int kend, float* v) const {
-        if (row < rows && k < kend) {
-            const float* q = p + (long)b * stride + (long)row * ld + k;
-            if (vec && k + CH <= kend) {
+        const bool ok = row < rows && k < kend;
+        const float* q = p + (long)b * stride + (long)(ok ? row : 0) * ld + (ok ? k : 0);
+        if constexpr (VEC) {
 #pragma unroll
-                for (int c = 0; c < CH / 4; ++c) {
-                    f32x4 t = *(const f32x4*)(q + 4 * c);
-                    v[4 * c] = t[0]; v[4 * c + 1] = t[1]; v[4 * c + 2] = t[2]; v[4 * c + 3] = t[3];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < CH; ++j) v[j] = (k + j < kend) ? q[j] : 0.f;
+            for (int c = 0; c < CH / 4; ++c) {
+                f32x4 t = *(const f32x4*)(q + 4 * c);
+                v[4 * c] = ok ? t[0] : 0.f; v[4 * c + 1] = ok ? t[1] : 0.f; v[4 * c + 2] = ok ? t[2] : 0.f; v[4 * c + 3] = ok ? t[3] : 0.f;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) v[j] = 0.f;
+            for (int j = 0; j < CH; ++j) {
+                const bool okj = ok && (k + j < kend);
+                float t = q[okj ? j : 0];
+                v[j] = okj ? t : 0.f;
+            }
         }
     }
 };
+typedef LdRowT<true> LdRow;
+typedef LdRowT<false> LdRowS;
 
 struct LdCol {  // element(row,k) = p[b*stride + k*ld + row]        (row contiguous)
     static constexpr bool KCONTIG = false;
     const float* p; long ld, stride; int rows, vec;
     template <int CH>
     __device__ __forceinline__ void load(int b, int row, int k, int kend, float* v) const {
-        const float* q = p + (long)b * stride + row;
+        const bool okr = row < rows;
+        const float* q = p + (long)b * stride + (okr ? row : 0);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) v[j] = (row < rows && k + j < kend) ? q[(long)(k + j) * ld] : 0.f;
+        for (int j = 0; j < CH; ++j) {
+            const bool ok = okr && (k + j < kend);
+            float t = q[(long)(ok ? k + j : 0) * ld];
+            v[j] = ok ? t : 0.f;
+        }
     }
 };
 
@@ -345,14 +358,31 @@ gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, floa
             }
 }
 
-template <class EP>
-__global__ void splitk_reduce_kernel(int M, int N, int splits, int batch, const float* __restrict__ ws, EP ep) {
-    long total = (long)batch * M * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int n = (int)(i % N); long t = i / N; int m = (int)(t % M); int b = (int)(t / M);
+// Split-K reduce + epilogue, fixed summation order.  grid (cdiv(N,64), cdiv(M,RPB), batch), 256 threads:
+// DEEP = false: the 4 waves own 4 different rows and loop over the (few) slabs;
+// DEEP = true : the 4 waves split the (many) slabs of ONE row and combine through LDS (tiny outputs whose
+//               K was cut hundreds of ways -- the weight gradients of the conv-side layers).
+template <class EP, bool DEEP>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(int M, int N, int splits, const float* __restrict__ ws, EP ep) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx, b = blockIdx.z;
+    if (DEEP) {
+        const int m = blockIdx.y;
         float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += ws[(((long)b * splits + sp) * M + m) * N + n];
-        ep.store(b, m, n, s);
+        if (n < N)
+            for (int sp = wv; sp < splits; sp += 4) s += ws[(((long)b * splits + sp) * M + m) * N + n];
+        sm[wv][tx] = s;
+        __syncthreads();
+        if (wv == 0 && n < N) ep.store(b, m, n, (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+    } else {
+        const int m = blockIdx.y * 4 + wv;
+        if (m < M && n < N) {
+            float s = 0.f;
+            for (int sp = 0; sp < splits; ++sp) s += ws[(((long)b * splits + sp) * M + m) * N + n];
+            ep.store(b, m, n, s);
+        }
     }
 }
 
@@ -378,9 +408,10 @@ int launch_cfg(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, s
     hipLaunchKernelGGL((gemm_kernel<P, AL, BL, EP, WM, WN, WVM, WVN>), grid, dim3(64 * WVM * WVN), 0, st,
                        M, N, K, splits, kper, al, bl, ep, ws);
     if (splits > 1) {
-        long total = (long)batch * M * N;
-        int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL((splitk_reduce_kernel<EP>), dim3(blocks), dim3(256), 0, st, M, N, splits, batch, ws, ep);
+        if (splits > 24 && M <= 65535)
+            hipLaunchKernelGGL((splitk_reduce_kernel<EP, true>), dim3(cdiv(N, 64), M, batch), dim3(256), 0, st, M, N, splits, ws, ep);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<EP, false>), dim3(cdiv(N, 64), cdiv(M, 4), batch), dim3(256), 0, st, M, N, splits, ws, ep);
     }
     return unetr_check_launch();
 }
@@ -405,121 +436,11 @@ int launch_prec(int prec, int M, int N, int K, int batch, AL al, BL bl, EP ep, f
     return UNETR_ERR_ARG;
 }
 
+template <class P> inline bool kvec_ok(int K) { return K % P::CH == 0; }
+
 inline int vec_ok(const float* p, long ld, long stride) {
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (stride & 3) == 0) ? 1 : 0;
 }
 
 }  // namespace
 
-extern "C" int unetr_abi_version(void) { return 1; }
-
-extern "C" int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float* B, float* C,
-                          float* ws, size_t ws_bytes, void* stream) {
-    if (!d || !A || !B || !C) return UNETR_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    EpStd ep{C, d->ldc, d->strideC, d->bias, d->res, d->ldr, d->strideR, d->res_mod > 0 ? d->res_mod : d->M,
-             d->pre, d->aux, d->ldaux, d->act, d->accumulate, d->alpha};
-    if (d->act == 2 && !d->aux) return UNETR_ERR_ARG;
-    const int M = d->M, N = d->N, K = d->K, bt = d->batch;
-    if (!d->a_trans && !d->b_trans) {
-        LdRow al{A, d->lda, d->strideA, M, vec_ok(A, d->lda, d->strideA)};
-        LdRow bl{B, d->ldb, d->strideB, N, vec_ok(B, d->ldb, d->strideB)};
-        return launch_prec(d->prec, M, N, K, bt, al, bl, ep, ws, ws_bytes, st);
-    } else if (!d->a_trans && d->b_trans) {
-        LdRow al{A, d->lda, d->strideA, M, vec_ok(A, d->lda, d->strideA)};
-        LdCol bl{B, d->ldb, d->strideB, N, 0};
-        return launch_prec(d->prec, M, N, K, bt, al, bl, ep, ws, ws_bytes, st);
-    } else if (d->a_trans && d->b_trans) {
-        LdCol al{A, d->lda, d->strideA, M, 0};
-        LdCol bl{B, d->ldb, d->strideB, N, 0};
-        return launch_prec(d->prec, M, N, K, bt, al, bl, ep, ws, ws_bytes, st);
-    }
-    return UNETR_ERR_UNSUPPORTED;
-}
-
-extern "C" int unetr_tconv_fwd(const float* x, long ldx, const float* w, float* y, long ldy,
-                               int B, int D, int H, int W, int Cin, int Cout, int prec,
-                               float* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !y) return UNETR_ERR_ARG;
-    long M = (long)B * D * H * W;
-    if (M > 0x7fffffffL / 8) return UNETR_ERR_ARG;
-    TcGeom g{D, H, W, Cout};
-    LdRow al{x, ldx, 0, (int)M, vec_ok(x, ldx, 0)};
-    LdTcWf bl{w, 8 * Cout, Cout};
-    EpTcScatter ep{y, ldy, g};
-    return launch_prec(prec, (int)M, 8 * Cout, Cin, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
-}
-
-extern "C" int unetr_tconv_dgrad(const float* dy, long ldy, const float* w, float* dx, long ldx, int accumulate,
-                                 int B, int D, int H, int W, int Cin, int Cout, int prec,
-                                 float* ws, size_t ws_bytes, void* stream) {
-    if (!dy || !w || !dx) return UNETR_ERR_ARG;
-    long M = (long)B * D * H * W;
-    if (M > 0x7fffffffL / 8) return UNETR_ERR_ARG;
-    TcGeom g{D, H, W, Cout};
-    LdTcGatherA al{dy, ldy, (int)M, g};
-    LdTcWd bl{w, Cin, Cout};
-    EpStd ep{dx, ldx, 0, nullptr, nullptr, 0, 0, (int)M, nullptr, nullptr, 0, 0, accumulate, 1.0f};
-    return launch_prec(prec, (int)M, Cin, 8 * Cout, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
-}
-
-extern "C" int unetr_tconv_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
-                                 int B, int D, int H, int W, int Cin, int Cout, int prec,
-                                 float* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dy || !dw) return UNETR_ERR_ARG;
-    long M = (long)B * D * H * W;
-    if (M > 0x7fffffffL / 8) return UNETR_ERR_ARG;
-    TcGeom g{D, H, W, Cout};
-    LdCol al{x, ldx, 0, Cin, 0};
-    LdTcGatherB bl{dy, ldy, 8 * Cout, g};
-    EpTcWgrad ep{dw, Cout};
-    return launch_prec(prec, Cin, 8 * Cout, (int)M, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
-}
-
-// ---- 3x3x3 / 1x1x1 conv through the GEMM family (im2col loaders; the general-shape path) -------------
-__global__ void conv_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int Cin, int Cout, int KV, int mode) {
-    long total = (long)Cin * Cout * KV;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int tap = (int)(i % KV); long t = i / KV; int ci = (int)(t % Cin); int co = (int)(t / Cin);
-        float v = w[i];
-        if (mode == 0) o[((long)co * KV + tap) * Cin + ci] = v;                 // [Cout][KV][Cin]
-        else o[((long)ci * KV + (KV - 1 - tap)) * Cout + co] = v;               // [Cin][KV flipped][Cout]
-    }
-}
-
-extern "C" int unetr_conv_pack_weight(const float* w, float* wpack, int Cin, int Cout, int KS, int mode, void* stream) {
-    if (!w || !wpack || (KS != 1 && KS != 3)) return UNETR_ERR_ARG;
-    int KV = KS * KS * KS;
-    long total = (long)Cin * Cout * KV;
-    int blocks = (int)std::min<long>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(conv_pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout, KV, mode);
-    return unetr_check_launch();
-}
-
-extern "C" int unetr_conv_gemm_fwd(const float* x, long ldx, const float* wpack, float* y, long ldy, int accumulate,
-                                   int B, int D, int H, int W, int Cin, int Cout, int KS, int prec,
-                                   float* ws, size_t ws_bytes, void* stream) {
-    if (!x || !wpack || !y || (KS != 1 && KS != 3)) return UNETR_ERR_ARG;
-    long M = (long)B * D * H * W;
-    if (M > 0x7fffffffL) return UNETR_ERR_ARG;
-    int KV = KS * KS * KS, K = KV * Cin;
-    ConvGeom g{D, H, W, Cin, KS};
-    LdIm2colA al{x, ldx, (int)M, g};
-    LdRow bl{wpack, K, 0, Cout, vec_ok(wpack, K, 0)};
-    EpStd ep{y, ldy, 0, nullptr, nullptr, 0, 0, (int)M, nullptr, nullptr, 0, 0, accumulate, 1.0f};
-    return launch_prec(prec, (int)M, Cout, K, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
-}
-
-extern "C" int unetr_conv_gemm_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
-                                     int B, int D, int H, int W, int Cin, int Cout, int KS, int prec,
-                                     float* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dy || !dw || (KS != 1 && KS != 3)) return UNETR_ERR_ARG;
-    long M = (long)B * D * H * W;
-    if (M > 0x7fffffffL) return UNETR_ERR_ARG;
-    int KV = KS * KS * KS;
-    ConvGeom g{D, H, W, Cin, KS};
-    LdCol al{dy, ldy, 0, Cout, 0};
-    LdIm2colB bl{x, ldx, KV * Cin, g};
-    EpConvWgrad ep{dw, Cin, KV};
-    return launch_prec(prec, Cout, KV * Cin, (int)M, 1, al, bl, ep, ws, ws_bytes, (hipStream_t)stream);
-}
