@@ -33,9 +33,20 @@ class _Bucket:
         self.launched = False
 
 
+class _FlatBucket:
+    """A contiguous slice of the model's flat gradient arena (UNETR.use_flat_buffers): reduced in place."""
+    __slots__ = ("params", "flat", "pending", "launched")
+
+    def __init__(self, params, flat_slice):
+        self.params = params
+        self.flat = flat_slice
+        self.pending = len(params)
+        self.launched = False
+
+
 class GradAllReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group: Optional[dist.ProcessGroup] = None,
-                 bucket_bytes: int = 32 << 20):
+                 bucket_bytes: int = 32 << 20, flat=None):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradAllReducer needs an initialised torch.distributed process group")
         self.group = process_group
@@ -43,6 +54,10 @@ class GradAllReducer:
         plist = [p for p in params if p.requires_grad]
         if not plist:
             raise ValueError("no trainable parameters")
+        self.flat = flat
+        if flat is not None:
+            self._init_flat(plist, flat, bucket_bytes)
+            return
         self.buckets: List[_Bucket] = []
         cur, cur_bytes = [], 0
         for p in reversed(plist):
@@ -61,6 +76,33 @@ class GradAllReducer:
         self.stream = torch.cuda.Stream(device=plist[0].device) if self.is_cuda else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in plist]
 
+    def _init_flat(self, plist, flat, bucket_bytes):
+        """Zero-copy mode: buckets are contiguous arena slices (built from the END of the parameter list, the order
+        in which backward fills them); readiness comes from functional._ret, not from autograd hooks."""
+        from . import functional as Fn
+        fparams, offs, fg = flat["params"], flat["offsets"], flat["grad"]
+        if [id(p) for p in fparams] != [id(p) for p in plist]:
+            raise ValueError("flat= needs model.parameters() in order (all trainable)")
+        self.buckets = []
+        hi = len(fparams) - 1
+        while hi >= 0:
+            lo, nbytes = hi, fparams[hi].numel() * 4
+            while lo > 0 and nbytes < bucket_bytes:
+                lo -= 1
+                nbytes += fparams[lo].numel() * 4
+            end = offs[hi] + (fparams[hi].numel() + 3) // 4 * 4
+            self.buckets.append(_FlatBucket(fparams[lo:hi + 1], fg[offs[lo]:end]))
+            hi = lo - 1
+        self._where = {}
+        for b in self.buckets:
+            for p in b.params:
+                self._where[p] = b
+        self.is_cuda = fg.is_cuda
+        self.stream = torch.cuda.Stream(device=fg.device) if self.is_cuda else None
+        self._hooks = []
+        self._cb = self._on_grad
+        Fn._GRAD_READY_CB.append(self._cb)
+
     # broadcast rank 0's parameters so every rank starts from the same weights
     def broadcast_parameters(self, params: Iterable[torch.nn.Parameter]):
         for p in params:
@@ -72,8 +114,19 @@ class GradAllReducer:
         if b.pending == 0 and not b.launched:
             self._launch(b)
 
-    def _launch(self, b: _Bucket):
+    def _launch(self, b):
         b.launched = True
+        if self.flat is not None:
+            if self.is_cuda:
+                self.stream.wait_stream(torch.cuda.current_stream())
+                ctx = torch.cuda.stream(self.stream)
+            else:
+                ctx = _null()
+            with ctx, torch.no_grad():
+                work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work.wait()
+                b.flat.div_(self.world)
+            return
         have = [p.grad is not None for p in b.params]
         if self.is_cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -110,6 +163,10 @@ class GradAllReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self.flat is not None:
+            from . import functional as Fn
+            if self._cb in Fn._GRAD_READY_CB:
+                Fn._GRAD_READY_CB.remove(self._cb)
 
 
 class _null:

@@ -3,19 +3,41 @@ betas (0.9, 0.999), eps 1e-8, amsgrad off) running on the HIP kernel ``unetr_ada
 
 Per-parameter step counters (a parameter whose grad is None does not step, as in torch) live in one device
 tensor and are advanced by a single masked add, so ``step()`` never synchronises with the host and can be
-captured in a hipGraph together with forward and backward."""
+captured in a hipGraph together with forward and backward.
+
+``flat=model.use_flat_buffers()``: parameters, gradients and both moments live in flat arenas, and one kernel
+launch covers every contiguous run of parameters that received a gradient (2 launches for the full model:
+MONAI's unused ``cls_token`` splits the arena), instead of one launch per tensor."""
 import torch
 
 from ._capi import call
 
 
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flat=None):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._steps = {}   # group index -> flat device tensor of per-parameter step counts
         self._masks = {}   # (group index, pattern) -> 0/1 increment tensor
+        self._flat = flat
+        self._flat_state = None
+        if flat is not None:
+            if len(self.param_groups) != 1 or [id(p) for p in self.param_groups[0]["params"]] != [id(p) for p in flat["params"]]:
+                raise ValueError("flat= needs a single param group holding model.parameters() in order")
+            self._host_steps = [0] * len(flat["params"])
+
+    def _advance_steps(self, gi, params, pattern, dev):
+        steps = self._steps.get(gi)
+        if steps is None:
+            steps = torch.zeros(len(params), dtype=torch.float32, device=dev)
+            self._steps[gi] = steps
+        mask = self._masks.get((gi, pattern))
+        if mask is None:
+            mask = torch.tensor([1.0 if f else 0.0 for f in pattern], dtype=torch.float32, device=dev)
+            self._masks[(gi, pattern)] = mask
+        steps += mask
+        return steps
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -31,15 +53,9 @@ class AdamW(torch.optim.Optimizer):
             if not any(pattern):
                 continue
             dev = next(p for p in params if p.grad is not None).device
-            steps = self._steps.get(gi)
-            if steps is None:
-                steps = torch.zeros(len(params), dtype=torch.float32, device=dev)
-                self._steps[gi] = steps
-            mask = self._masks.get((gi, pattern))
-            if mask is None:
-                mask = torch.tensor([1.0 if f else 0.0 for f in pattern], dtype=torch.float32, device=dev)
-                self._masks[(gi, pattern)] = mask
-            steps += mask
+            if self._flat is not None and self._flat_step(group, params, pattern, dev, stream):
+                continue
+            steps = self._advance_steps(gi, params, pattern, dev)
             for i, p in enumerate(params):
                 g = p.grad
                 if g is None:
@@ -57,3 +73,33 @@ class AdamW(torch.optim.Optimizer):
                 call("unetr_adamw", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                      group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i, stream)
         return loss
+
+    def _flat_step(self, group, params, pattern, dev, stream):
+        """One launch per contiguous run of parameters with arena gradients and equal step counts."""
+        flat = self._flat
+        fg, fp, offs = flat["grad"], flat["param"], flat["offsets"]
+        gbase, esz = fg.data_ptr(), 4
+        for p, o, has in zip(params, offs, pattern):
+            if has and p.grad.data_ptr() != gbase + o * esz:
+                return False          # some gradient is not in the arena (e.g. accumulated): per-tensor path
+        if self._flat_state is None:
+            self._flat_state = (torch.zeros_like(fp), torch.zeros_like(fp))
+        m, v = self._flat_state
+        steps = self._advance_steps(0, params, pattern, dev)
+        b1, b2 = group["betas"]
+        i, n = 0, len(params)
+        while i < n:
+            if not pattern[i]:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and pattern[j + 1] and self._host_steps[j + 1] == self._host_steps[i]:
+                j += 1
+            lo = offs[i]
+            hi = offs[j] + (params[j].numel() + 3) // 4 * 4
+            call("unetr_adamw", fp.data_ptr() + lo * esz, gbase + lo * esz, m.data_ptr() + lo * esz, v.data_ptr() + lo * esz, hi - lo,
+                 group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i, stream)
+            for k in range(i, j + 1):
+                self._host_steps[k] += 1
+            i = j + 1
+        return True

@@ -231,6 +231,34 @@ class UNETR(nn.Module):
         self.out = _OutBlock(f, out_channels)  # type: ignore
 
     # ------------------------------------------------------------------------------------------------
+    def use_flat_buffers(self):
+        """Optional fast path (call once, AFTER ``.to(device)``): move every parameter into one flat fp32 arena
+        and allocate a matching gradient arena.  Parameters stay ordinary ``nn.Parameter`` views (state_dict,
+        load_state_dict, optimisers keep working); backward then writes each gradient straight into its arena
+        slice, so ``AdamW(..., flat=...)`` is a single kernel launch per contiguous run and the data-parallel
+        all-reduce runs in place on arena slices (no flatten / unflatten copies).  Do not call ``.to()`` after."""
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("use_flat_buffers() needs the module on a ROCm device (call .to(device) first)")
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every slice 16-byte aligned
+        flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        views = []
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                v = flat_p[o:o + p.numel()].view_as(p)
+                v.copy_(p)
+                p.data = v
+                p.grad = None
+                views.append((p, flat_g[o:o + p.numel()].view_as(p)))
+        Fn.register_grad_sinks(views)
+        self._flat = dict(param=flat_p, grad=flat_g, offsets=offs, params=params, total=n)
+        return self._flat
+
     def _prec(self) -> int:
         try:
             return _PRECISIONS[self.precision]

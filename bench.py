@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--no-flat", action="store_true", help="per-tensor grads/AdamW instead of the flat arenas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -65,13 +66,14 @@ def main():
     model = pkg.UNETRLogits(**CFG).to(dev)
     model.precision = args.precision
     crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
-    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    flat = None if args.no_flat else model.use_flat_buffers()
+    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
     x, y = synthetic_volume(args.batch, 1, 96, 4, seed=1234 + rank)
     x, y = x.to(dev), y.to(dev)
 
     reducer = None
     if dist_on:
-        reducer = pkg.ddp.GradAllReducer(model.parameters(), process_group=None)
+        reducer = pkg.ddp.GradAllReducer(model.parameters(), process_group=None, flat=flat)
 
     def step():
         logit_map = model(x)

@@ -143,3 +143,38 @@ def test_logits_only_and_train_step(pkg, dev):
         assert relerr(loss, l_ref) < 1e-3
     sd_r, sd_h = ref.state_dict(), hip.state_dict()
     assert relerr(sd_h["decoder2.conv_block.conv1.conv.weight"], sd_r["decoder2.conv_block.conv1.conv.weight"]) < 1e-3
+
+
+def test_flat_buffers_match_per_tensor_path(pkg, dev):
+    """use_flat_buffers(): gradients land in the arena (param.grad is an arena view), flat AdamW == per-tensor AdamW
+    == torch.optim.AdamW on the same gradients; cls_token (never used) keeps grad None and is not decayed."""
+    from oracle.unetr_oracle import synthetic_volume
+    torch.manual_seed(3)
+    a = pkg.UNETRLogits(**C1).to(dev)
+    b = pkg.UNETRLogits(**C1).to(dev)
+    b.load_state_dict(a.state_dict())
+    flat = b.use_flat_buffers()
+    oa = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-2)
+    ob = pkg.AdamW(b.parameters(), lr=1e-3, weight_decay=1e-2, flat=flat)
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    x, y = synthetic_volume(1, 1, 32, 2, seed=5)
+    x, y = x.to(dev), y.to(dev)
+    for it in range(3):
+        la = crit(a(x), y); la.backward()
+        lb = crit(b(x), y); lb.backward()
+        pb = dict(b.named_parameters())
+        for k, p in a.named_parameters():
+            if p.grad is None:
+                assert pb[k].grad is None, k
+            else:
+                if it == 0:   # identical weights -> bitwise identical gradients (all kernels are deterministic)
+                    assert torch.equal(la, lb) and torch.equal(p.grad, pb[k].grad), k
+                lo = flat["grad"].data_ptr()
+                assert lo <= pb[k].grad.data_ptr() < lo + flat["grad"].numel() * 4, k
+        oa.step(); oa.zero_grad()
+        ob.step(); ob.zero_grad()
+    pb = dict(b.named_parameters())
+    for k, p in a.named_parameters():
+        assert relerr(pb[k], p) < 1e-5, k
+    assert torch.equal(pb["vit.patch_embedding.cls_token"], torch.zeros_like(pb["vit.patch_embedding.cls_token"]))
+    pkg.functional.clear_grad_sinks()

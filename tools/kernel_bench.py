@@ -1,0 +1,105 @@
+"""Micro-benchmarks of single hot kernels through the C ABI (for rocprofv3 --pmc runs and A/B timing).
+
+    python tools/kernel_bench.py conv3_fwd --cin 16 --cout 16 --size 96 --batch 2 --prec bf16 --iters 20
+    python tools/kernel_bench.py conv3_wgrad ... | gemm --m 432 --n 768 --k 3072 | instnorm ...
+
+Prints one JSON line with the average launch time (HIP events on the launch stream) and the algorithmic
+bytes / flops of the launch, so the PMC FETCH_SIZE / WRITE_SIZE of the same command can be compared.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "gemm", "gemm_dgrad", "gemm_wgrad", "instnorm", "encoder_fwd"])
+    ap.add_argument("--cin", type=int, default=16)
+    ap.add_argument("--cout", type=int, default=16)
+    ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--m", type=int, default=432)
+    ap.add_argument("--n", type=int, default=768)
+    ap.add_argument("--k", type=int, default=3072)
+    ap.add_argument("--prec", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
+    Fn = pkg.functional
+    dev = torch.device("cuda:0")
+    prec = {"fp32": 0, "bf16": 1}[a.prec]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    S, B = a.size, a.batch
+    dims = (B, S, S, S)
+    v = B * S ** 3
+    if a.kernel.startswith("conv3"):
+        x = torch.randn(B, S, S, S, a.cin, generator=g).to(dev)
+        w = (torch.randn(a.cout, a.cin, 3, 3, 3, generator=g) * 0.1).to(dev)
+        dy = torch.randn(B, S, S, S, a.cout, generator=g).to(dev)
+        flops = 2.0 * v * a.cin * a.cout * 27
+        nbytes = 4.0 * v * (a.cin + a.cout) + 4.0 * w.numel()
+        if a.kernel == "conv3_fwd":
+            fn = lambda: Fn.conv3(x, a.cin, w, dims, prec)
+        elif a.kernel == "conv3_dgrad":
+            fn = lambda: Fn.conv3(dy, a.cout, w, dims, prec, mode=1)
+        else:
+            fn = lambda: Fn.conv3_wgrad(x, a.cin, dy, a.cout, dims, a.cin, a.cout, prec)
+        label = f"{a.kernel} {a.cin}->{a.cout} @ {S}^3 B={B} {a.prec}"
+    elif a.kernel.startswith("gemm"):
+        M, N, K = a.m, a.n, a.k
+        x = torch.randn(M, K, generator=g).to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+        dy = torch.randn(M, N, generator=g).to(dev)
+        flops = 2.0 * M * N * K
+        nbytes = 4.0 * (M * K + N * K + M * N)
+        fn = {"gemm": lambda: Fn.linear_fwd(x, w, None, prec), "gemm_dgrad": lambda: Fn.linear_dgrad(dy, w, prec),
+              "gemm_wgrad": lambda: Fn.linear_wgrad(dy, x, prec)}[a.kernel]
+        label = f"{a.kernel} M={M} N={N} K={K} {a.prec}"
+    elif a.kernel == "instnorm":
+        x = torch.randn(B, S, S, S, a.cout, generator=g).to(dev)
+        flops, nbytes = 0.0, 4.0 * v * a.cout
+        fn = lambda: Fn.instnorm_stats(x, a.cout, B, S ** 3, a.cout)
+        label = f"instnorm_stats C={a.cout} @ {S}^3 B={B}"
+    else:  # encoder_fwd: ViT encoder forward (patch-embed + 12 blocks + final norm) at batch B
+        cfg = dict(in_channels=1, out_channels=4, img_size=(96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072,
+                   num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True)
+        model = pkg.UNETR(**cfg).to(dev)
+        model.precision = a.prec
+        xin = torch.rand(B, 1, 96, 96, 96, generator=g).to(dev)
+        pe = model.vit.patch_embedding
+
+        def fn():
+            with torch.no_grad():
+                z = Fn.PatchEmbedFn.apply(xin, pe.patch_embeddings[1].weight, pe.patch_embeddings[1].bias, pe.position_embeddings, 16, prec)
+                for blk in model.vit.blocks:
+                    z = Fn.TransformerBlockFn.apply(
+                        z, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
+                        blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
+                        blk.mlp.linear2.bias, B, 216, 12, prec)
+                return Fn.LayerNormFn.apply(z, model.vit.norm.weight, model.vit.norm.bias)
+        flops = 39.771e9 * B       # encoder forward per volume
+        nbytes = 4.0 * 88341504    # fp32 encoder weights streamed once
+        label = f"ViT encoder forward B={B} {a.prec}"
+    for _ in range(a.warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    print(json.dumps({"kernel": label, "ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "TFLOP/s": round(flops / ms / 1e9, 2),
+                      "algorithmic_bytes": nbytes, "algorithmic_flops": flops}))
+
+
+if __name__ == "__main__":
+    main()
