@@ -30,10 +30,20 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class GroupedProblem(ctypes.Structure):
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int)]
+
+
+class ColsumProblem(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("ld", c_long), ("M", c_int), ("N", c_int)]
+
+
 P = c_void_p
 _SIGNATURES = {
     "unetr_abi_version": [],
     "unetr_gemm": [ctypes.POINTER(GemmDesc), P, P, P, P, c_size_t, P],
+    "unetr_gemm_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, c_int, P],
+    "unetr_colsum_grouped": [ctypes.POINTER(ColsumProblem), c_int, P],
     "unetr_tconv_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],

@@ -68,7 +68,7 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 template <class P, int NCH>
 __device__ __forceinline__ void stage_halo(const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0, int D, int H, int W,
                                            int c0, int Cin, int pitch, char* halo, int vec) {
-    constexpr int CH = P::CH, TOTAL = NHALO * NCH, ITERS = (TOTAL + 255) / 256, SB = (ITERS * NCH <= 48 ? ITERS : (ITERS + 1) / 2), NQ = CH / 4;
+    constexpr int CH = P::CH, TOTAL = NHALO * NCH, ITERS = (TOTAL + 255) / 256, SB = 6, NQ = CH / 4;   // SB = ITERS (one batch) costs 40 more VGPRs and a wave of occupancy: slower
     for (int it0 = 0; it0 < ITERS; it0 += SB) {
         f32x4 buf[SB][NQ];
 #pragma unroll

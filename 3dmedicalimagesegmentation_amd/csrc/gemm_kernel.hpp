@@ -249,18 +249,15 @@ struct EpConvWgrad {  // (m = co, n = tap*Cin+ci) -> dw[(co*Cin+ci)*KV + tap]   
 };
 
 // ------------------------------------------------------------------------------------------- kernel
+// one BM x BN output tile of C = A*B over k in [kbeg, kend): the body shared by the plain and grouped kernels
 template <class P, class AL, class BL, class EP, int WM, int WN, int WVM, int WVN>
-__global__ void __launch_bounds__(64 * WVM * WVN)
-gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, float* __restrict__ ws) {
+__device__ __forceinline__ void gemm_tile(int M, int N, int m0, int n0, int kbeg, int kend, int batch, int splits, int bz,
+                                          const AL& al, const BL& bl, const EP& ep, float* __restrict__ ws, char* lds) {
     constexpr int NT = 64 * WVM * WVN, BM = 16 * WM * WVM, BN = 16 * WN * WVN, CH = P::CH, SK = 8 * CH;
     constexpr int AIT = (BM * 8 + NT - 1) / NT, BIT = (BN * 8 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * 128];
     char* ldsA = lds;
     char* ldsB = lds + BM * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WVN, wn = wave % WVN;
-    const int bz = blockIdx.z, batch = bz / splits, split = bz - batch * splits;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = split * kper, kend = min(K, kbeg + kper);
     const int nk = (kend - kbeg + SK - 1) / SK;
 
     // Prefetch ring of PF stages held as RAW fp32 registers: the loads of stage kt+PF are issued right after
@@ -356,6 +353,41 @@ gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, floa
                     else ep.store(batch, m, n, acc[i][j][r]);
                 }
             }
+}
+
+template <class P, class AL, class BL, class EP, int WM, int WN, int WVM, int WVN>
+__global__ void __launch_bounds__(64 * WVM * WVN)
+gemm_kernel(int M, int N, int K, int splits, int kper, AL al, BL bl, EP ep, float* __restrict__ ws) {
+    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN;
+    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * 128];
+    const int bz = blockIdx.z, batch = bz / splits, split = bz - batch * splits;
+    const int kbeg = split * kper, kend = min(K, kbeg + kper);
+    gemm_tile<P, AL, BL, EP, WM, WN, WVM, WVN>(M, N, blockIdx.x * BM, blockIdx.y * BN, kbeg, kend, batch, splits, bz, al, bl, ep, ws, lds);
+}
+
+// ---- grouped weight-gradient GEMM: many independent dW[N,K] = dY[M,N]^T * X[M,K] problems in ONE launch ----------
+// At batch 2 the reduction length is only M = 432 tokens, so a single problem cannot fill 256 CUs without
+// split-K slabs; the 48 weight gradients of the 12 transformer blocks can.  Problems travel in the kernel
+// argument block (no device-side descriptor memory, hipGraph-capturable).
+constexpr int GROUP_MAX = 48;
+struct GroupedProblem { const float* dy; const float* x; float* dw; int M, N, K, tile0, mtiles; };
+struct GroupedArgs { int n; GroupedProblem p[GROUP_MAX]; };
+
+template <class P, int WM, int WN, int WVM, int WVN>
+__global__ void __launch_bounds__(64 * WVM * WVN)
+gemm_grouped_wgrad_kernel(GroupedArgs ga) {
+    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN;
+    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * 128];
+    int pi = 0;
+    const int t = blockIdx.x;
+    for (int i = 1; i < ga.n; ++i) pi = (t >= ga.p[i].tile0) ? i : pi;     // uniform scan, <= 48 entries
+    const GroupedProblem& pr = ga.p[pi];
+    const int lt = t - pr.tile0, tm = lt % pr.mtiles, tn = lt / pr.mtiles;
+    // output rows = dy columns (N), output cols = x columns (K), reduction over the M tokens
+    LdCol al{pr.dy, pr.N, 0, pr.N, 0};
+    LdCol bl{pr.x, pr.K, 0, pr.K, 0};
+    EpStd ep{pr.dw, pr.K, 0, nullptr, nullptr, 0, 0, pr.N, nullptr, nullptr, 0, 0, 0, 1.0f};
+    gemm_tile<P, LdCol, LdCol, EpStd, WM, WN, WVM, WVN>(pr.N, pr.K, tm * BM, tn * BN, 0, pr.M, 0, 1, 0, al, bl, ep, nullptr, lds);
 }
 
 // Split-K reduce + epilogue, fixed summation order.  grid (cdiv(N,64), cdiv(M,RPB), batch), 256 threads:

@@ -36,3 +36,30 @@ extern "C" int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float*
     }
     return UNETR_ERR_UNSUPPORTED;
 }
+
+// dw_i[N_i, K_i] = dy_i[M_i, N_i]^T * x_i[M_i, K_i] for i < n, one launch per <= GROUP_MAX problems
+extern "C" int unetr_gemm_grouped_wgrad(const unetr_grouped_problem* probs, int n, int prec, void* stream) {
+    if (!probs || n <= 0) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int BM = 128, BN = 128;
+    for (int base = 0; base < n; base += GROUP_MAX) {
+        GroupedArgs ga;
+        ga.n = std::min(GROUP_MAX, n - base);
+        int tiles = 0;
+        for (int i = 0; i < ga.n; ++i) {
+            const unetr_grouped_problem& q = probs[base + i];
+            if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N <= 0 || q.K <= 0) return UNETR_ERR_ARG;
+            GroupedProblem& g = ga.p[i];
+            g.dy = q.dy; g.x = q.x; g.dw = q.dw; g.M = q.M; g.N = q.N; g.K = q.K;
+            g.tile0 = tiles; g.mtiles = cdiv(q.N, BM);
+            tiles += g.mtiles * cdiv(q.K, BN);
+        }
+        if (prec == UNETR_PREC_BF16)
+            hipLaunchKernelGGL((gemm_grouped_wgrad_kernel<PrecBF16, 4, 4, 2, 2>), dim3(tiles), dim3(256), 0, st, ga);
+        else if (prec == UNETR_PREC_F32)
+            hipLaunchKernelGGL((gemm_grouped_wgrad_kernel<PrecF32, 4, 4, 2, 2>), dim3(tiles), dim3(256), 0, st, ga);
+        else
+            return UNETR_ERR_ARG;
+    }
+    return unetr_check_launch();
+}

@@ -151,6 +151,26 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int RB, int 
     out[n] = accumulate ? out[n] + s : s;
 }
 
+// grouped column sums: up to CS_MAX independent [M_i, N_i] -> [N_i] problems in one launch (descriptors in kernargs)
+constexpr int CS_MAX = 64;
+struct ColsumProblem { const float* x; float* out; long ld; int M, N, blk0; };
+struct ColsumArgs { int n; ColsumProblem p[CS_MAX]; };
+__global__ void __launch_bounds__(256)
+colsum_grouped_kernel(ColsumArgs a) {
+    __shared__ float sm[4][64];
+    int pi = 0;
+    for (int i = 1; i < a.n; ++i) pi = ((int)blockIdx.x >= a.p[i].blk0) ? i : pi;
+    const ColsumProblem& pr = a.p[pi];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = ((int)blockIdx.x - pr.blk0) * 64 + tx;
+    float s = 0.f;
+    if (n < pr.N)
+        for (int m = ty; m < pr.M; m += 4) s += pr.x[(long)m * pr.ld + n];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < pr.N) pr.out[n] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
+}
+
 // ------------------------------------------------------------------------------------ InstanceNorm
 // x: [B, V, C] pitch ld.  thread -> (channel vec cv, voxel phase); block covers VPB voxels of one batch item.
 constexpr int IN_VPB = 1024;
@@ -520,6 +540,23 @@ extern "C" int unetr_colsum(const float* x, long ld, int M, int N, float* out, i
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), RB), dim3(256), 0, st, x, ld, M, N, ws, RB);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, ws, RB, N, out, accumulate);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_colsum_grouped(const unetr_colsum_problem* probs, int n, void* stream) {
+    if (!probs || n <= 0) return UNETR_ERR_ARG;
+    for (int base = 0; base < n; base += CS_MAX) {
+        ColsumArgs a;
+        a.n = std::min(CS_MAX, n - base);
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const unetr_colsum_problem& q = probs[base + i];
+            if (!q.x || !q.out || q.M <= 0 || q.N <= 0) return UNETR_ERR_ARG;
+            a.p[i] = ColsumProblem{q.x, q.out, q.ld, q.M, q.N, blocks};
+            blocks += cdiv(q.N, 64);
+        }
+        hipLaunchKernelGGL(colsum_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return unetr_check_launch();
 }
 

@@ -63,16 +63,74 @@ def _gout(w):
 _GRAD_READY_CB = []
 
 
-def _ret(w, g):
-    """What a Function.backward returns for parameter `w`: when `g` was written into w's arena slice, attach the
-    slice as .grad directly (autograd would clone it: the arena keeps a second reference) and return None."""
+def _ret(w, g, deferred=False):
+    """What a Function.backward returns for parameter `w`: when `g` was (or, if deferred, will be) written into
+    w's arena slice, attach the slice as .grad directly (autograd would clone it: the arena keeps a second
+    reference) and return None.  Readiness callbacks (data-parallel buckets) fire now, or at flush if deferred."""
     ent = _GRAD_SINK.get(w.data_ptr())
     if ent is not None and g is not None and g.data_ptr() == ent[1].data_ptr():
         ent[0].grad = ent[1]
-        for cb in _GRAD_READY_CB:
-            cb(ent[0])
+        if deferred:
+            _DEFER["params"].append(ent[0])
+        else:
+            for cb in _GRAD_READY_CB:
+                cb(ent[0])
         return None
     return g
+
+
+# ---- deferred, grouped weight gradients -------------------------------------------------------------------
+# In arena mode the Linear weight/bias gradients of the ViT are not needed by anything inside backward, so they
+# are queued and executed at the end of the backward pass as ONE grouped GEMM launch + ONE grouped column-sum
+# launch (csrc: gemm_grouped_wgrad_kernel, colsum_grouped_kernel) instead of ~90 small latency-bound launches.
+_DEFER = {"wgrad": [], "colsum": [], "params": [], "armed": False, "prec": 0}
+
+
+def _arm_flush():
+    if not _DEFER["armed"]:
+        _DEFER["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+
+
+def wgrad_or_defer(dy, x, prec, w):
+    """dw[N,K] = dy^T x for Linear weight `w`; returns (grad_or_None_for_autograd)."""
+    out = _gout(w)
+    if out is None:
+        return linear_wgrad(dy, x, prec)
+    _DEFER["wgrad"].append((dy, x, out))
+    _DEFER["prec"] = prec
+    _arm_flush()
+    return _ret(w, out, deferred=True)
+
+
+def colsum_or_defer(x, M, N, ld, b, view_shape=None):
+    out = _gout(b)
+    if out is None:
+        r = colsum(x, M, N, ld)
+        return r.view(view_shape) if view_shape is not None else r
+    _DEFER["colsum"].append((x, out, M, N, ld))
+    _arm_flush()
+    return _ret(b, out, deferred=True)
+
+
+def flush_deferred():
+    """Runs at the end of the backward pass (autograd engine callback) on the backward stream."""
+    wq, cq, params = _DEFER["wgrad"], _DEFER["colsum"], _DEFER["params"]
+    _DEFER["wgrad"], _DEFER["colsum"], _DEFER["params"], _DEFER["armed"] = [], [], [], False
+    if wq:
+        arr = (_capi.GroupedProblem * len(wq))()
+        for i, (dy, x, out) in enumerate(wq):
+            arr[i].dy, arr[i].x, arr[i].dw = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+            arr[i].M, arr[i].N, arr[i].K = dy.shape[0], dy.shape[1], x.shape[1]
+        call("unetr_gemm_grouped_wgrad", arr, len(wq), _DEFER["prec"], _stream())
+    if cq:
+        arr = (_capi.ColsumProblem * len(cq))()
+        for i, (x, out, M, N, ld) in enumerate(cq):
+            arr[i].x, arr[i].out, arr[i].ld, arr[i].M, arr[i].N = x.data_ptr(), out.data_ptr(), ld, M, N
+        call("unetr_colsum_grouped", arr, len(cq), _stream())
+    for p in params:
+        for cb in _GRAD_READY_CB:
+            cb(p)
 
 
 def _require_gpu(t):
@@ -335,11 +393,10 @@ class PatchEmbedFn(torch.autograd.Function):
         patches, w, b, pos = ctx.saved_tensors
         B, L, hid, prec = ctx.meta
         dz = dz.contiguous()
-        dw = linear_wgrad(dz, patches, prec, out=_gout(w))
-        db = colsum(dz, B * L, hid, hid, out=_gout(b))
-        gp = _gout(pos)
-        dpos = colsum(dz, B, L * hid, L * hid, out=gp.view(-1) if gp is not None else None).view(1, L, hid)
-        return None, _ret(w, dw), _ret(b, db), _ret(pos, dpos), None, None
+        dw = wgrad_or_defer(dz, patches, prec, w)
+        db = colsum_or_defer(dz, B * L, hid, hid, b)
+        dpos = colsum_or_defer(dz, B, L * hid, L * hid, pos, view_shape=(1, L, hid))
+        return None, dw, db, dpos, None, None
 
 
 class TransformerBlockFn(torch.autograd.Function):
@@ -373,22 +430,22 @@ class TransformerBlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         # MLP
         du = linear_dgrad(dx2, w2, prec, aux=u)
-        dw2 = linear_wgrad(dx2, a, prec, out=_gout(w2))
-        db2 = colsum(dx2, M, hid, hid, out=_gout(b2))
-        dw1 = linear_wgrad(du, y2, prec, out=_gout(w1))
-        db1 = colsum(du, M, du.shape[1], du.shape[1], out=_gout(b1))
+        dw2 = wgrad_or_defer(dx2, a, prec, w2)
+        db2 = colsum_or_defer(dx2, M, hid, hid, b2)
+        dw1 = wgrad_or_defer(du, y2, prec, w1)
+        db1 = colsum_or_defer(du, M, du.shape[1], du.shape[1], b1)
         dy2 = linear_dgrad(du, w1, prec)
         dx1, dn2w, dn2b = layernorm_bwd(dy2, x1, n2w, m2, r2, dres=dx2, out_w=_gout(n2w), out_b=_gout(n2b))
         # attention
         datt = linear_dgrad(dx1, wp, prec)
-        dwp = linear_wgrad(dx1, att, prec, out=_gout(wp))
-        dbp = colsum(dx1, M, hid, hid, out=_gout(bp))
+        dwp = wgrad_or_defer(dx1, att, prec, wp)
+        dbp = colsum_or_defer(dx1, M, hid, hid, bp)
         dqkv = attention_bwd(qkv, att, datt, lse, B, L, heads, dh, prec)
-        dwqkv = linear_wgrad(dqkv, y1, prec, out=_gout(wqkv))
+        dwqkv = wgrad_or_defer(dqkv, y1, prec, wqkv)
         dy1 = linear_dgrad(dqkv, wqkv, prec)
         dx, dn1w, dn1b = layernorm_bwd(dy1, x, n1w, m1, r1, dres=dx1, out_w=_gout(n1w), out_b=_gout(n1b))
-        return (dx, _ret(n1w, dn1w), _ret(n1b, dn1b), _ret(wqkv, dwqkv), _ret(wp, dwp), _ret(bp, dbp), _ret(n2w, dn2w),
-                _ret(n2b, dn2b), _ret(w1, dw1), _ret(b1, db1), _ret(w2, dw2), _ret(b2, db2), None, None, None, None)
+        return (dx, _ret(n1w, dn1w), _ret(n1b, dn1b), dwqkv, dwp, dbp, _ret(n2w, dn2w),
+                _ret(n2b, dn2b), dw1, db1, dw2, db2, None, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):

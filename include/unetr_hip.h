@@ -51,6 +51,15 @@ typedef struct {
 int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float* B, float* C,
                float* ws, size_t ws_bytes, void* stream);
 
+/* Grouped launches for the work that is OFF the critical path of backward at batch 2: the weight gradients
+ * dW_i[N_i,K_i] = dY_i[M_i,N_i]^T * X_i[M_i,K_i] of all transformer blocks (torch.nn.Linear backward, MONAI
+ * ViT built at unetr.py:78-89) and the bias / position-embedding gradient column sums.  One launch covers up to
+ * 48 problems (descriptors travel in the kernel-argument block), filling the chip without split-K slabs. */
+typedef struct { const float* dy; const float* x; float* dw; int M, N, K; } unetr_grouped_problem;
+int unetr_gemm_grouped_wgrad(const unetr_grouped_problem* probs, int n, int prec, void* stream);
+typedef struct { const float* x; float* out; long ld; int M, N; } unetr_colsum_problem;
+int unetr_colsum_grouped(const unetr_colsum_problem* probs, int n, void* stream);
+
 /* ---- 2x2x2 stride-2 transposed conv (nn.ConvTranspose3d, bias=False; unetr.py:99-174) ---------------
  * x: [B,D,H,W,Cin] pitch ldx; w: torch layout [Cin,Cout,2,2,2]; y: [B,2D,2H,2W,Cout] pitch ldy. */
 int unetr_tconv_fwd(const float* x, long ldx, const float* w, float* y, long ldy,

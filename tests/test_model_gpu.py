@@ -146,35 +146,42 @@ def test_logits_only_and_train_step(pkg, dev):
 
 
 def test_flat_buffers_match_per_tensor_path(pkg, dev):
-    """use_flat_buffers(): gradients land in the arena (param.grad is an arena view), flat AdamW == per-tensor AdamW
-    == torch.optim.AdamW on the same gradients; cls_token (never used) keeps grad None and is not decayed."""
+    """use_flat_buffers(): gradients land in the arena (param.grad is an arena view; Linear weight grads come from the
+    grouped end-of-backward launch), the unused cls_token keeps grad None, and flat AdamW == torch.optim.AdamW when fed
+    the same gradients (Adam amplifies rounding differences, so it is checked step by step on identical inputs)."""
     from oracle.unetr_oracle import synthetic_volume
     torch.manual_seed(3)
     a = pkg.UNETRLogits(**C1).to(dev)
     b = pkg.UNETRLogits(**C1).to(dev)
     b.load_state_dict(a.state_dict())
     flat = b.use_flat_buffers()
-    oa = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-2)
-    ob = pkg.AdamW(b.parameters(), lr=1e-3, weight_decay=1e-2, flat=flat)
     crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
     x, y = synthetic_volume(1, 1, 32, 2, seed=5)
     x, y = x.to(dev), y.to(dev)
+    la = crit(a(x), y); la.backward()
+    lb = crit(b(x), y); lb.backward()
+    assert torch.equal(la, lb)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    lo = flat["grad"].data_ptr()
+    for k, p in pa.items():
+        if p.grad is None:
+            assert pb[k].grad is None, k
+        else:
+            assert relerr(pb[k].grad, p.grad) < 2e-5, k       # grouped wgrad: other tile shape, no split-K
+            assert lo <= pb[k].grad.data_ptr() < lo + flat["grad"].numel() * 4, k
+    # optimiser: torch reference on clones, fed b's own gradients every step
+    ref = {k: p.detach().clone().requires_grad_(True) for k, p in pb.items()}
+    o_ref = torch.optim.AdamW(list(ref.values()), lr=1e-3, weight_decay=1e-2)
+    o_b = pkg.AdamW(b.parameters(), lr=1e-3, weight_decay=1e-2, flat=flat)
     for it in range(3):
-        la = crit(a(x), y); la.backward()
-        lb = crit(b(x), y); lb.backward()
-        pb = dict(b.named_parameters())
-        for k, p in a.named_parameters():
-            if p.grad is None:
-                assert pb[k].grad is None, k
-            else:
-                if it == 0:   # identical weights -> bitwise identical gradients (all kernels are deterministic)
-                    assert torch.equal(la, lb) and torch.equal(p.grad, pb[k].grad), k
-                lo = flat["grad"].data_ptr()
-                assert lo <= pb[k].grad.data_ptr() < lo + flat["grad"].numel() * 4, k
-        oa.step(); oa.zero_grad()
-        ob.step(); ob.zero_grad()
-    pb = dict(b.named_parameters())
-    for k, p in a.named_parameters():
-        assert relerr(pb[k], p) < 1e-5, k
+        if it:
+            crit(b(x), y).backward()
+        for k, p in pb.items():
+            ref[k].grad = None if p.grad is None else p.grad.detach().clone()
+        o_ref.step()
+        o_b.step()
+        o_b.zero_grad()
+        for k, p in pb.items():
+            assert relerr(p, ref[k]) < 1e-5, (it, k)
     assert torch.equal(pb["vit.patch_embedding.cls_token"], torch.zeros_like(pb["vit.patch_embedding.cls_token"]))
     pkg.functional.clear_grad_sinks()
