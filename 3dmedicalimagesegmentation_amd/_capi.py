@@ -57,7 +57,7 @@ _SIGNATURES = {
     "unetr_conv_gemm_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
-    "unetr_conv3_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_wgrad": [P, c_long, P, c_long, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_debug_tr16": [P, P, P],
     "unetr_instnorm_stats": [P, c_long, c_int, c_long, c_int, c_float, P, P, c_size_t, P],
     "unetr_instnorm_apply": [P, c_long, P, P, c_long, P, P, c_long, c_int, c_long, c_int, c_int, P],

@@ -222,13 +222,18 @@ constexpr int WG_UNITS = 54, WG_UPW = 14;  // units per wave (ceil(54/4))
 template <class P>
 __global__ void __launch_bounds__(256)
 conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
-                   int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles, int vecx, int vecy) {
+                   const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
+                   int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles, int vecx, int vecy, int vecy3) {
     using C = WgCfg<P>;
     typedef typename C::T T;
     constexpr int CH = P::CH;
-    __shared__ __attribute__((aligned(16))) char lds[NHALO * C::PX + NVOX * C::PY];
+    // dy3 != nullptr: also accumulate the 1x1x1 conv's weight gradient dw3[co][ci] = sum_v dy3[v,co] x[v,ci] of the
+    // same residual block (MONAI UnetResBlock.conv3 shares its input with conv1): units 54/55 = centre tap fed by dy3.
+    __shared__ __attribute__((aligned(16))) char lds[NHALO * C::PX + 2 * NVOX * C::PY];
     char* ximg = lds;
     char* yimg = lds + NHALO * C::PX;
+    char* y3img = yimg + NVOX * C::PY;
+    const int nunits = dy3 ? WG_UNITS + 2 : WG_UNITS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 16;
     // per-unit LDS byte offsets of the shifted window (wave-uniform)
@@ -236,7 +241,7 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
 #pragma unroll
     for (int ui = 0; ui < WG_UPW; ++ui) {
         int u = wv + 4 * ui;
-        int tap = u >> 1, cit = u & 1;
+        int tap = u >= WG_UNITS ? 13 : (u >> 1), cit = u & 1;      // units 54/55: centre tap (the 1x1x1 conv)
         int dz = tap / 9, rem = tap - dz * 9, dyy = rem / 3, dx = rem - dyy * 3;
         uoff[ui] = ((dz * HY + dyy) * HX + dx) * C::PX + cit * 16 * C::ES;
     }
@@ -250,8 +255,8 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
         stage_halo<P, 32 / CH>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg, vecx);
-        // dy tile: 256 voxels x 16 channels, all loads of a thread in flight together
-        {
+        // dy tile(s): 256 voxels x 16 channels, all loads of a thread in flight together
+        auto stage_dy = [&](const float* __restrict__ src, long ld, int vec, char* img) {
             constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
             f32x4 buf[YIT][NQ];
 #pragma unroll
@@ -261,8 +266,8 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
                 const int gz = z0 + (v >> 6), gy = y0 + ((v >> 4) & 3), gx = x0 + (v & 15);
                 const int cc = co0 + ch * CH;
                 const bool ok = gz < D && gy < H && gx < W && cc < Cout;
-                const float* q = dy + ((((long)b * D + gz) * H + gy) * W + gx) * lddy + cc;
-                if (vecy) {
+                const float* q = src + ((((long)b * D + gz) * H + gy) * W + gx) * ld + cc;
+                if (vec) {
 #pragma unroll
                     for (int c4 = 0; c4 < NQ; ++c4)
                         buf[j][c4] = (ok && cc + 4 * c4 + 4 <= Cout) ? *(const f32x4*)(q + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -280,9 +285,11 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
                 float vals[CH];
 #pragma unroll
                 for (int c4 = 0; c4 < NQ; ++c4) { vals[4 * c4] = buf[j][c4][0]; vals[4 * c4 + 1] = buf[j][c4][1]; vals[4 * c4 + 2] = buf[j][c4][2]; vals[4 * c4 + 3] = buf[j][c4][3]; }
-                *(u32x4*)(yimg + v * C::PY + ch * 16) = P::pack(vals);
+                *(u32x4*)(img + v * C::PY + ch * 16) = P::pack(vals);
             }
-        }
+        };
+        stage_dy(dy, lddy, vecy, yimg);
+        if (dy3) stage_dy(dy3, lddy3, vecy3, y3img);
         __syncthreads();
 
         for (int kb = 0; kb < C::NKB; ++kb) {
@@ -297,34 +304,43 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
                 typedef short s16x8 __attribute__((ext_vector_type(8)));
                 s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
                 const u32x4 afrag = __builtin_bit_cast(u32x4, a8);
+                u32x4 afrag3 = afrag;
+                if (dy3) {
+                    s16x4 clo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + v0 * C::PY + 8 * p));
+                    s16x4 chi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + v1 * C::PY + 8 * p));
+                    s16x8 c8 = {clo[0], clo[1], clo[2], clo[3], chi[0], chi[1], chi[2], chi[3]};
+                    afrag3 = __builtin_bit_cast(u32x4, c8);
+                }
                 const int h0 = (((v0 >> 6) * HY + ((v0 >> 4) & 3)) * HX + (v0 & 15)) * C::PX + 8 * p;
                 const int h1 = (((v1 >> 6) * HY + ((v1 >> 4) & 3)) * HX + (v1 & 15)) * C::PX + 8 * p;
 #pragma unroll
                 for (int ui = 0; ui < WG_UPW; ++ui) {
-                    if (wv + 4 * ui < WG_UNITS) {
+                    if (wv + 4 * ui < nunits) {
                         s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + h0 + uoff[ui]));
                         s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + h1 + uoff[ui]));
                         s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-                        P::mma(acc[ui], afrag, __builtin_bit_cast(u32x4, b8));
+                        P::mma(acc[ui], (ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS) ? afrag3 : afrag, __builtin_bit_cast(u32x4, b8));
                     }
                 }
             } else {
                 // f32: k-block = 16 voxels; lane (c, g) holds voxels 4g+t for channel c
-                float av[4];
+                float av[4], av3[4];
                 int hb[4];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     int v = kb * 16 + 4 * g + tt;
                     av[tt] = *(const float*)(yimg + v * C::PY + c * 4);
+                    av3[tt] = dy3 ? *(const float*)(y3img + v * C::PY + c * 4) : 0.f;
                     hb[tt] = (((v >> 6) * HY + ((v >> 4) & 3)) * HX + (v & 15)) * C::PX + c * 4;
                 }
 #pragma unroll
                 for (int ui = 0; ui < WG_UPW; ++ui) {
-                    if (wv + 4 * ui < WG_UNITS) {
+                    if (wv + 4 * ui < nunits) {
+                        const bool ext = (ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS);
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             float bv = *(const float*)(ximg + hb[tt] + uoff[ui]);
-                            acc[ui] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], bv, acc[ui], 0, 0, 0);
+                            acc[ui] = __builtin_amdgcn_mfma_f32_16x16x4f32(ext ? av3[tt] : av[tt], bv, acc[ui], 0, 0, 0);
                         }
                     }
                 }
@@ -335,13 +351,16 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
 #pragma unroll
     for (int ui = 0; ui < WG_UPW; ++ui) {
         int u = wv + 4 * ui;
-        if (u < WG_UNITS) {
+        if (u < nunits) {
             int tap = u >> 1, cit = u & 1;
             int ci = ci0 + cit * 16 + c;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 int co = co0 + 4 * g + rr;
-                if (ci < Cin && co < Cout) part[(((long)blockIdx.x * Cout + co) * Cin + ci) * 27 + tap] = acc[ui][rr];
+                if (ci < Cin && co < Cout) {
+                    if (u < WG_UNITS) part[(((long)blockIdx.x * Cout + co) * Cin + ci) * 27 + tap] = acc[ui][rr];
+                    else part3[((long)blockIdx.x * Cout + co) * Cin + ci] = acc[ui][rr];
+                }
             }
         }
     }
@@ -415,23 +434,27 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
 }
 
 template <class P>
-int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int D, int H, int W, int Cin, int Cout,
-            float* ws, size_t ws_bytes, hipStream_t st) {
+int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, const float* dy3, long lddy3, float* dw3,
+            int B, int D, int H, int W, int Cin, int Cout, float* ws, size_t ws_bytes, hipStream_t st) {
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long ntiles = (long)B * ntx * nty * ntz;
     const int nci = cdiv(Cin, 32), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
     long G = std::max<long>(1, 1024 / ((long)nci * nco));
     G = std::min(G, ntiles);
-    while (G > 1 && (size_t)G * n * sizeof(float) > ws_bytes) G >>= 1;
-    if (!ws || (size_t)G * n * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    const long n3 = dy3 ? (long)Cin * Cout : 0;
+    while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;
+    if (!ws || (size_t)G * (n + n3) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    float* ws3 = ws + (size_t)G * n;
+    const int vecy3 = (dy3 && ((uintptr_t)dy3 & 15) == 0 && (lddy3 & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
     if (nci > 65535 || nco > 65535) return UNETR_ERR_ARG;
     const int vecx = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
     const int vecy = (((uintptr_t)dy & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((conv3_wgrad_kernel<P>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, ws, D, H, W, Cin, Cout,
-                       ntx, nty, ntz, (int)ntiles, vecx, vecy);
+    hipLaunchKernelGGL((conv3_wgrad_kernel<P>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, ws, dy3, lddy3, ws3, D, H, W, Cin, Cout,
+                       ntx, nty, ntz, (int)ntiles, vecx, vecy, vecy3);
     int blocks = (int)std::min<long>((n + 15) / 16, 16384);
     hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, (int)G, n, dw);
+    if (dy3) hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((int)std::min<long>((n3 + 15) / 16, 16384)), dim3(256), 0, st, ws3, (int)G, n3, dw3);
     return unetr_check_launch();
 }
 
@@ -460,11 +483,12 @@ extern "C" int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, floa
 }
 
 extern "C" int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                                 const float* dy3, long ldy3, float* dw3,
                                  int B, int D, int H, int W, int Cin, int Cout, int prec,
                                  float* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dy || !dw || B <= 0) return UNETR_ERR_ARG;
-    if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
-    if (prec == UNETR_PREC_F32) return wgrad_t<PrecF32>(x, ldx, dy, ldy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (!x || !dy || !dw || B <= 0 || ((dy3 != nullptr) != (dw3 != nullptr))) return UNETR_ERR_ARG;
+    if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_F32) return wgrad_t<PrecF32>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 

@@ -13,6 +13,7 @@
 // 128-byte rows (2 k-blocks) -> ds_read_b128 fragments -> MFMA.  Global loads of stage t+1 are issued
 // before the MFMAs of stage t (register prefetch), the LDS tile is single-buffered.
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/unetr_hip.h"
 
@@ -431,6 +432,10 @@ int launch_cfg(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, s
         if (splits > ksteps / 2) splits = ksteps / 2;
         if (splits < 1) splits = 1;
     }
+    { // tuning hooks (read once): UNETR_GEMM_SPLITS forces the split count
+        const int env_splits = getenv("UNETR_GEMM_SPLITS") ? atoi(getenv("UNETR_GEMM_SPLITS")) : 0;
+        if (env_splits > 0) splits = std::min(env_splits, std::max(1, ksteps));
+    }
     while (splits > 1 && (size_t)splits * batch * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits > 1 && ws == nullptr) splits = 1;
     int kper = cdiv(ksteps, splits) * SK;
@@ -457,7 +462,9 @@ int launch_gemm(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, 
     if (M <= 32 && N > 64) return launch_cfg<P, AL, BL, EP, 2, 4, 1, 4>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
     if (N <= 16) return launch_cfg<P, AL, BL, EP, 4, 1, 4, 1>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
     if (N <= 32) return launch_cfg<P, AL, BL, EP, 4, 2, 4, 1>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
-    if (M >= 2048 && N >= 128) return launch_cfg<P, AL, BL, EP, 4, 4, 2, 2>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hook
+    if (env_cfg == 128 || (env_cfg == 0 && M >= 2048 && N >= 128))
+        return launch_cfg<P, AL, BL, EP, 4, 4, 2, 2>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
     return launch_cfg<P, AL, BL, EP, 2, 2, 2, 2>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
 }
 

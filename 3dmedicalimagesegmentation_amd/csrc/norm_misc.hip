@@ -50,7 +50,7 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
     }
 }
 
-constexpr int LN_RPB = 16;  // rows per block in backward
+constexpr int LN_RPB = 4;   // rows per block in backward (one per wave): 108 workgroups at M = 432 instead of 27
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                      const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
@@ -118,15 +118,19 @@ layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, 
     }
 }
 
-// out[which*H + n] = sum_blocks part[(blk*2+which)*H + n]
-__global__ void ln_finalize_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * H) return;
-    int which = i / H, n = i - which * H;
+// out[which*H + n] = sum_blocks part[(blk*2+which)*H + n]; 64 columns x 4 partial-phases per workgroup
+__global__ void __launch_bounds__(256)
+ln_finalize_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    const int which = i / H, n = i - which * H;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[((long)b * 2 + which) * H + n];
-    (which ? dbeta : dgamma)[n] = s;
+    if (i < 2 * H)
+        for (int b = ph; b < nblk; b += 4) s += part[((long)b * 2 + which) * H + n];
+    sm[ph][tx] = s;
+    __syncthreads();
+    if (ph == 0 && i < 2 * H) (which ? dbeta : dgamma)[n] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
 
 // ------------------------------------------------------------------------------------------ colsum
@@ -528,7 +532,7 @@ extern "C" int unetr_layernorm_bwd(const float* dy, const float* x, const float*
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, x, gamma, mean, rstd, dx,
                        dres, ws, M, H);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 256)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
     return unetr_check_launch();
 }
 

@@ -276,14 +276,19 @@ def conv3(x, ldx, w, dims, prec, mode=0, out=None, ldo=None, accumulate=False):
     return out
 
 
-def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None):
+def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None):
+    """dw of the 3x3x3 conv; with dy3/out3 also the weight gradient of the 1x1x1 conv sharing the input x."""
     if _use_gemm_conv():
+        if dy3 is not None:
+            gemm(dy3, x, out3, cout, cin, dims[0] * dims[1] * dims[2] * dims[3], lda=cout, ldb=ldx, ldc=cin, prec=_capi.PREC_F32,
+                 a_trans=True, b_trans=True)
         return conv_wgrad(x, ldx, dy, lddy, dims, cin, cout, 3, prec, out=out)
     B, D, H, W = dims
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, 3, dtype=torch.float32, device=x.device)
     ws = workspace(x.device)
-    call("unetr_conv3_wgrad", x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), B, D, H, W, cin, cout, prec,
-         ws.data_ptr(), ws.numel() * 4, _stream())
+    call("unetr_conv3_wgrad", x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(),
+         dy3.data_ptr() if dy3 is not None else None, cout, out3.data_ptr() if out3 is not None else None,
+         B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
     return dw
 
 
@@ -490,12 +495,11 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     # conv3 (1x1x1)
     g3 = _gout(w3)
     dw3 = g3 if g3 is not None else torch.empty(cout, cin, 1, 1, 1, dtype=torch.float32, device=x.device)
-    gemm(dc3, x, dw3, cout, cin, B * V, lda=cout, ldb=ldx, ldc=cin, prec=_capi.PREC_F32, a_trans=True, b_trans=True)
     # conv2
     dw2 = conv3_wgrad(a1, cout, dc2, cout, dims, cout, cout, prec, out=_gout(w2))
     da1 = conv3(dc2, cout, w2, dims, prec, mode=1)
     dc1, _ = instnorm_bwd(da1, cout, c1, s1, B, V, cout, True)
-    dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=_gout(w1))
+    dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=_gout(w1), dy3=dc3, out3=dw3)
     dx = None
     if need_dx:
         dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=x.device)

@@ -111,7 +111,10 @@ size_t unetr_conv3_packed_bytes(int Cin, int Cout, int mode, int prec);
 int unetr_conv3_pack_weight(const float* w, void* wpack, int Cin, int Cout, int mode, int prec, void* stream);
 int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, float* y, long ldy, int accumulate,
                     int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream);
+/* dy3/dw3 (both or neither): also produce the weight gradient dw3[Cout,Cin] of the 1x1x1 conv that shares the
+ * input x (MONAI UnetResBlock.conv3 next to conv1) from its own output gradient dy3, inside the same pass. */
 int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                      const float* dy3, long ldy3, float* dw3,
                       int B, int D, int H, int W, int Cin, int Cout, int prec,
                       float* ws, size_t ws_bytes, void* stream);
 /* probe of the ds_read_b64_tr_b16 lane map used by the bf16 weight-gradient kernel (test hook) */
