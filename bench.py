@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-flat", action="store_true", help="per-tensor grads/AdamW instead of the flat arenas")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (two graphs + eager all-reduce slot) on one rank")
+    ap.add_argument("--fp32-comm", action="store_true", help="all-reduce gradients in fp32 even in bf16 mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -48,10 +50,13 @@ def log(msg):
 
 def main():
     args = parse()
+    # RCCL / HIP print banners on stdout; the contract is ONE JSON line there, so keep the real stdout aside
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist_on = world > 1
+    dist_on = world > 1 or (args.force_dist and "RANK" in os.environ)   # --force-dist under torchrun: 1-rank RCCL group
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
@@ -71,22 +76,55 @@ def main():
     x, y = synthetic_volume(args.batch, 1, 96, 4, seed=1234 + rank)
     x, y = x.to(dev), y.to(dev)
 
+    # ---- data parallel (N > 1): weak scaling, batch `--batch` per rank, gradients averaged over ranks ----------
+    # Arena mode: graph A = forward + loss + backward (+ one cast of the gradient arena into the communication
+    # buffer), ONE eager RCCL all-reduce over the whole buffer, graph B = copy back / average + AdamW.  No
+    # collective is captured inside a hipGraph, so the path does not depend on RCCL's capture support.
+    # --force-dist exercises exactly this path with a single rank (what the 1-GPU box can test).
+    ddp_on = dist_on or args.force_dist
+    comm_dtype = torch.bfloat16 if (args.precision == "bf16" and not args.fp32_comm) else torch.float32
     reducer = None
-    if dist_on:
-        reducer = pkg.ddp.GradAllReducer(model.parameters(), process_group=None, flat=flat)
+    comm_buf = None
+    if ddp_on and flat is None:
+        if not dist_on:
+            raise SystemExit("--force-dist needs the arena mode (drop --no-flat)")
+        reducer = pkg.ddp.GradAllReducer(model.parameters(), process_group=None)
+    if ddp_on and flat is not None:
+        comm_buf = torch.zeros(flat["total"], dtype=comm_dtype, device=dev)
+        if dist_on:
+            for p in model.parameters():
+                dist.broadcast(p.data, src=0)
 
-    def step():
+    def fwd_bwd():
         logit_map = model(x)
         loss = crit(logit_map, y)
         loss.backward()
-        if reducer is not None:
-            reducer.finish()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
+        if comm_buf is not None:
+            comm_buf.copy_(flat["grad"])        # fp32 -> communication dtype (bf16 in bf16 mode)
         return loss
 
-    use_graph = not args.no_graph and not dist_on
-    # eager warm-up (allocates workspaces / optimizer state; also what graph capture needs beforehand)
+    def comm():
+        if comm_buf is not None and dist_on:
+            dist.all_reduce(comm_buf, op=dist.ReduceOp.SUM)
+        elif reducer is not None:
+            reducer.finish()
+
+    def update():
+        if comm_buf is not None:
+            flat["grad"].copy_(comm_buf)
+            if world > 1:
+                flat["grad"].mul_(1.0 / world)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    def step():
+        loss = fwd_bwd()
+        comm()
+        update()
+        return loss
+
+    use_graph = not args.no_graph and reducer is None
+    # eager warm-up (allocates workspaces / optimizer state / RCCL communicators; needed before graph capture)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -95,23 +133,34 @@ def main():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     log(f"eager warm-up done, loss {float(loss.item()):.5f}")
-    graph = None
+    graph = graph_b = None
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = step()
+            if comm_buf is None:
+                with torch.cuda.graph(graph):
+                    loss = step()
+            else:
+                with torch.cuda.graph(graph):
+                    loss = fwd_bwd()
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b, pool=graph.pool()):
+                    update()
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
-            graph = None
+            graph = graph_b = None
             torch.cuda.synchronize()
 
     def run_step():
-        if graph is not None:
+        if graph is None:
+            step()
+        elif graph_b is None:
             graph.replay()
         else:
-            step()
+            graph.replay()
+            comm()
+            graph_b.replay()
 
     log("graph captured" if graph is not None else "eager mode")
     for _ in range(args.warmup):
@@ -142,7 +191,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "UNETR(img=96^3,patch=16,hidden=768,layers=12,heads=12,classes=4) fwd+DiceCE+bwd+AdamW, "
                                f"batch {args.batch}/GPU, configs[1]", "global_batch": world * args.batch,
-                   "launch": "hipGraph" if graph is not None else "eager", "final_loss": float(loss.item())},
+                   "launch": ("hipGraph" if graph_b is None else "hipGraph(fwd+bwd) + eager all-reduce + hipGraph(AdamW)") if graph is not None else "eager",
+                   "grad_comm_dtype": (str(comm_dtype).replace("torch.", "") if ddp_on else None), "final_loss": float(loss.item())},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -160,7 +210,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 def cpu_baseline(args):

@@ -73,3 +73,66 @@ def test_grad_allreducer_gloo_world2():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _flat_worker(rank, world, port, q):
+    """Arena mode of GradAllReducer on CPU tensors: buckets are slices of one flat gradient buffer, readiness comes
+    from functional._ret (immediate) and functional.flush_deferred (deferred weight gradients)."""
+    try:
+        sys.path.insert(0, ROOT)
+        import importlib
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
+        Fn, ddp = pkg.functional, pkg.ddp
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in [(6, 4), (10,), (3, 3, 3), (1, 1, 5), (40,)]]
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        fg = torch.zeros(n)
+        views = [(p, fg[o:o + p.numel()].view_as(p)) for p, o in zip(params, offs)]
+        Fn.register_grad_sinks(views)
+        flat = dict(param=torch.zeros(n), grad=fg, offsets=offs, params=params, total=n)
+        red = ddp.GradAllReducer(params, bucket_bytes=64, flat=flat)
+        assert len(red.buckets) >= 2 and red.buckets[0].params[-1] is params[-1]
+        # "backward": write gradients into the arena views in reverse order; #3 never gets one; #0 is deferred
+        for i in (4, 2, 1):
+            v = Fn._gout(params[i])
+            assert v is not None
+            v.fill_(float((rank + 1) * (i + 1)))
+            assert Fn._ret(params[i], v) is None and params[i].grad is v
+        v0 = Fn._gout(params[0])
+        assert Fn._ret(params[0], v0, deferred=True) is None
+        v0.fill_(float(rank + 1))              # the deferred kernel "runs" here
+        Fn._DEFER["armed"] = True
+        Fn.flush_deferred()
+        red.finish()
+        for i in (4, 2, 1, 0):
+            exp = (i + 1) * (1 + world) / 2.0
+            assert torch.allclose(params[i].grad, torch.full_like(params[i], exp)), (i, params[i].grad.flatten()[:2])
+        assert params[3].grad is None
+        red.remove()
+        Fn.clear_grad_sinks()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_grad_allreducer_flat_arena_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
