@@ -18,6 +18,7 @@
 // ds_read_b32 per element does the same.  Accumulators for (tap, ci-tile) pairs stay in registers while the
 // workgroup walks many voxel tiles; per-workgroup partial sums are reduced in a fixed order.
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/unetr_hip.h"
 
@@ -65,10 +66,10 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 // batches of SB chunks per thread with no dependent instruction in between, so a batch costs ONE memory
 // round trip instead of SB (the first version looped load -> convert -> ds_write per chunk and ran the
 // 96^3 convs at 1.1 TB/s).  vec: 16-byte loads (aligned, Cin % 4 == 0); otherwise predicated scalar loads.
-template <class P, int NCH>
+template <class P, int NCH, bool VEC>
 __device__ __forceinline__ void stage_halo(const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0, int D, int H, int W,
-                                           int c0, int Cin, int pitch, char* halo, int vec) {
-    constexpr int CH = P::CH, TOTAL = NHALO * NCH, ITERS = (TOTAL + 255) / 256, SB = 6, NQ = CH / 4;   // SB = ITERS (one batch) costs 40 more VGPRs and a wave of occupancy: slower
+                                           int c0, int Cin, int pitch, char* halo) {
+    constexpr int CH = P::CH, TOTAL = NHALO * NCH, ITERS = (TOTAL + 255) / 256, SB = 6, NQ = CH / 4;
     for (int it0 = 0; it0 < ITERS; it0 += SB) {
         f32x4 buf[SB][NQ];
 #pragma unroll
@@ -80,16 +81,23 @@ __device__ __forceinline__ void stage_halo(const float* __restrict__ x, long ldx
             const int c = c0 + ch * CH;
             const bool ok = (it0 + j < ITERS) && id < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
                             (unsigned)gx < (unsigned)W && c < Cin;
-            const float* q = x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + c;
-            if (vec) {
+            // branch-free: always load (from the tensor base when out of range), then select -- a predicated
+            // load compiles to a branch + s_waitcnt vmcnt(0) and serialises the whole batch
+            const float* q = ok ? x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + c : x;
 #pragma unroll
-                for (int c4 = 0; c4 < NQ; ++c4)
-                    buf[j][c4] = (ok && c + 4 * c4 + 4 <= Cin) ? *(const f32x4*)(q + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            } else {
+            for (int c4 = 0; c4 < NQ; ++c4) {
+                if constexpr (VEC) {
+                    const bool okc = ok && c + 4 * c4 + 4 <= Cin;
+                    f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : x);
+                    buf[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
 #pragma unroll
-                for (int c4 = 0; c4 < NQ; ++c4)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) buf[j][c4][e] = (ok && c + 4 * c4 + e < Cin) ? q[4 * c4 + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const bool oke = ok && c + 4 * c4 + e < Cin;
+                        float t = *(oke ? q + 4 * c4 + e : x);
+                        buf[j][c4][e] = oke ? t : 0.f;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -127,10 +135,10 @@ __device__ __forceinline__ void tile_coords(int id, int total, int ntx, int nty,
 
 constexpr int FPITCH = 80;  // 64 B of channels (one k-block) + 16 B pad per halo voxel
 
-template <class P, int NTB>
+template <class P, int NTB, bool VEC>
 __global__ void __launch_bounds__(256)
 conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
-                 int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int vec) {
+                 int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz) {
     constexpr int CH = P::CH, SL = 4 * CH;
     __shared__ __attribute__((aligned(16))) char halo[NHALO * FPITCH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -147,7 +155,7 @@ conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__
 
     for (int slab = 0; slab < nslab; ++slab) {
         __syncthreads();
-        stage_halo<P, 4>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, FPITCH, halo, vec);
+        stage_halo<P, 4, VEC>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, FPITCH, halo);
         __syncthreads();
         // B fragment of (tap, slab, n-tile j): 16 bytes at wp[((tap*nslab+slab)*Cout + n)*64 + g*16].
         // Fragments are prefetched one GROUP of GT taps ahead (L1/L2 latency ~ a few hundred cycles must hide
@@ -196,11 +204,218 @@ conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__
                 const int xo = x0 + 4 * g + rr;
                 if (xo >= W) continue;
                 float* yp = y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r;
+                if (accumulate) {
+                    float old[NTB];
 #pragma unroll
-                for (int j = 0; j < NTB; ++j) {
-                    float v = acc[i][j][rr];
-                    if (accumulate) v += yp[j * 16];
-                    yp[j * 16] = v;
+                    for (int j = 0; j < NTB; ++j) old[j] = yp[j * 16];
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr] + old[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr];
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------- forward, persistent + pipelined
+// The first kernel above is latency-bound per tile (PMC: waves wait 64 % of the time; each workgroup does
+// load -> wait -> convert -> MFMA -> store for ONE tile).  This version keeps workgroups resident and walks
+// tiles: while the 27 taps of tile t run out of LDS, the global loads of tile t+1's halo are already in
+// flight into registers (HaloRegs), and are converted + written to the single LDS window right after the
+// barrier that ends tile t.
+//
+// PAIR mode (bf16, <= 16 input channels -- the four largest convolutions of the network): one K=32 MFMA
+// contracts TWO taps x 16 channels (lane groups 0,1 -> tap 2p, groups 2,3 -> tap 2p+1) instead of one tap
+// zero-padded to 32 channels: 14 MFMAs + 14 ds_read_b128 per 16-voxel row instead of 27, a 31 KB halo
+// window (pitch 48 B) instead of 52 KB, and all 14 weight fragments live in registers for the whole launch.
+template <class P, int NCH>
+struct HaloRegs {
+    static constexpr int ITERS = (NHALO * NCH + 255) / 256;
+    f32x4 v[ITERS][P::CH / 4];
+};
+
+template <class P, int NCH, bool VEC>
+__device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0,
+                                          int D, int H, int W, int c0, int Cin) {
+    constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
+#pragma unroll
+    for (int j = 0; j < HaloRegs<P, NCH>::ITERS; ++j) {
+        const int id = threadIdx.x + j * 256;
+        const int hv = id / NCH, ch = id - hv * NCH;
+        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const int c = c0 + ch * CH;
+        const bool ok = id < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin;
+        const float* q = ok ? x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + c : x;   // branch-free (see stage_halo)
+#pragma unroll
+        for (int c4 = 0; c4 < NQ; ++c4) {
+            if constexpr (VEC) {
+                const bool okc = ok && c + 4 * c4 + 4 <= Cin;
+                f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : x);
+                R.v[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool oke = ok && c + 4 * c4 + e < Cin;
+                    float t = *(oke ? q + 4 * c4 + e : x);
+                    R.v[j][c4][e] = oke ? t : 0.f;
+                }
+            }
+        }
+    }
+}
+
+template <class P, int NCH>
+__device__ __forceinline__ void halo_store(const HaloRegs<P, NCH>& R, int pitch, char* halo) {
+    constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
+#pragma unroll
+    for (int j = 0; j < HaloRegs<P, NCH>::ITERS; ++j) {
+        const int id = threadIdx.x + j * 256;
+        if (id < TOTAL) {
+            const int hv = id / NCH, ch = id - hv * NCH;
+            float v[CH];
+#pragma unroll
+            for (int c4 = 0; c4 < NQ; ++c4) { v[4 * c4] = R.v[j][c4][0]; v[4 * c4 + 1] = R.v[j][c4][1]; v[4 * c4 + 2] = R.v[j][c4][2]; v[4 * c4 + 3] = R.v[j][c4][3]; }
+            *(u32x4*)(halo + hv * pitch + ch * 16) = P::pack(v);
+        }
+    }
+}
+
+// pair-mode weights: wp[pair][n][k], k = (tap - 2*pair)*16 + ci   (bf16; zero for tap 27 and ci >= K)
+__global__ void conv3_pack_pair_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Cin, int Cout, int mode) {
+    const int K = mode ? Cout : Cin, N = mode ? Cin : Cout;
+    const long total = 14L * N * 32;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int kk = (int)(i & 31); long t = i >> 5; int n = (int)(t % N); int tp = (int)(t / N);
+        int tap = 2 * tp + (kk >> 4), k = kk & 15;
+        float v = 0.f;
+        if (tap < 27 && k < K) v = mode ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
+        wp[i] = f2bf(v);
+    }
+}
+
+template <class P, int NTB, bool PAIR, bool VEC>
+__global__ void __launch_bounds__(256)
+conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
+                      int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
+    constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16 + 16;
+    __shared__ __attribute__((aligned(16))) char halo[NHALO * PITCH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int nt0 = blockIdx.y * NTB;
+    const int nslab = PAIR ? 1 : (Cin + SL - 1) / SL;
+
+    u32x4 wres[PAIR ? 14 : 1][NTB];
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int tp = 0; tp < 14; ++tp)
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) wres[tp][j] = *(const u32x4*)(wp + ((long)tp * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
+    }
+
+    HaloRegs<P, NCH> R;
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        int tx, ty, tz, b;
+        tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        halo_load<P, NCH, VEC>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, 0, Cin);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        int tx, ty, tz, b;
+        tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+        f32x4 acc[4][NTB];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int slab = 0; slab < nslab; ++slab) {
+            __syncthreads();                       // everyone is done reading the previous window
+            halo_store<P, NCH>(R, PITCH, halo);    // (waits for the prefetched loads)
+            __syncthreads();
+            {   // prefetch the next (tile, slab) window; it lands while the MFMAs below run
+                int ntile = tile, nslb = slab + 1;
+                if (nslb == nslab) { ntile = tile + gridDim.x; nslb = 0; }
+                if (ntile < ntiles) {
+                    int ax, ay, az, ab;
+                    tile_coords(ntile, ntiles, ntx, nty, ntz, ax, ay, az, ab);
+                    halo_load<P, NCH, VEC>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, nslb * SL, Cin);
+                }
+            }
+            if constexpr (PAIR) {
+                const char* hb0 = halo + ((wv * HY) * HX + r) * PITCH + (g & 1) * 16;
+#pragma unroll
+                for (int tp = 0; tp < 14; ++tp) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int tA = 2 * tp, tB = (2 * tp + 1 < 27) ? 2 * tp + 1 : 26;
+                    const int offA = (((tA / 9) * HY + (tA % 9) / 3) * HX + tA % 3) * PITCH;
+                    const int offB = (((tB / 9) * HY + (tB % 9) / 3) * HX + tB % 3) * PITCH;
+                    const char* hbase = hb0 + ((g >> 1) ? offB : offA);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, wres[tp][j]);
+                    }
+                }
+            } else {
+                constexpr int GT = NTB <= 2 ? 3 : 1, NG = 27 / GT;   // small groups: the halo prefetch registers are live here
+                const char* wbase = wp + ((long)slab * Cout + nt0 * 16 + r) * 64 + g * 16;
+                const long wtap = (long)nslab * Cout * 64;
+                u32x4 bcur[GT][NTB], bnxt[GT][NTB];
+#pragma unroll
+                for (int t = 0; t < GT; ++t)
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) bcur[t][j] = *(const u32x4*)(wbase + t * wtap + j * 16 * 64);
+                for (int tg = 0; tg < NG; ++tg) {
+                    if (tg + 1 < NG) {
+#pragma unroll
+                        for (int t = 0; t < GT; ++t)
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j) bnxt[t][j] = *(const u32x4*)(wbase + ((tg + 1) * GT + t) * wtap + j * 16 * 64);
+                    }
+#pragma unroll
+                    for (int t = 0; t < GT; ++t) {
+                        const int tap = tg * GT + t;
+                        const int dz = tap / 9, rem = tap - dz * 9, dy = rem / 3, dx = rem - dy * 3;
+                        const char* hbase = halo + ((((wv + dz) * HY + dy) * HX) + (r + dx)) * PITCH + g * 16;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, bcur[t][j]);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < GT; ++t)
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) bcur[t][j] = bnxt[t][j];
+                }
+            }
+        }
+        const int zo = z0 + wv;
+        if (zo < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yo = y0 + i;
+                if (yo >= H) continue;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int xo = x0 + 4 * g + rr;
+                    if (xo >= W) continue;
+                    float* yp = y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r;
+                    if (accumulate) {
+                        float old[NTB];
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) old[j] = yp[j * 16];
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr] + old[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr];
+                    }
                 }
             }
         }
@@ -209,31 +424,33 @@ conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__
 
 // -------------------------------------------------------------------------------------- weight grad
 // workgroup = (voxel-tile group, 32-channel ci slab, 16-channel co tile); 54 (tap, ci-tile) units over 4 waves
-template <class P> struct WgCfg {
+template <class P, bool HAS3 = false> struct WgCfg {
     typedef typename ElemOf<P>::type T;
     static constexpr int ES = sizeof(T);
-    static constexpr int PX = 32 * ES + 16;   // halo image pitch (32 channels)
-    static constexpr int PY = 16 * ES + 16;   // dy image pitch (16 channels)
+    // image pitches: 16 B of padding when it is free; with the second dy image (HAS3) in bf16 the padding is dropped
+    // so that two workgroups still fit a CU (measured: 76 KB per workgroup = one workgroup per CU, 1.35x slower)
+    static constexpr int PX = 32 * ES + ((HAS3 && ES == 2) ? 0 : 16);   // halo image pitch (32 channels)
+    static constexpr int PY = 16 * ES + ((HAS3 && ES == 2) ? 8 : 16);   // dy image pitch (16 channels)
     static constexpr int KV = 4 * P::CH;      // voxels per MFMA k-block (32 bf16 / 16 f32)
     static constexpr int NKB = NVOX / KV;
 };
 constexpr int WG_UNITS = 54, WG_UPW = 14;  // units per wave (ceil(54/4))
 
-template <class P>
+template <class P, bool VECX, bool VECY, bool HAS3>
 __global__ void __launch_bounds__(256)
 conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
                    const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
-                   int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles, int vecx, int vecy, int vecy3) {
-    using C = WgCfg<P>;
+                   int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
+    using C = WgCfg<P, HAS3>;
     typedef typename C::T T;
     constexpr int CH = P::CH;
     // dy3 != nullptr: also accumulate the 1x1x1 conv's weight gradient dw3[co][ci] = sum_v dy3[v,co] x[v,ci] of the
     // same residual block (MONAI UnetResBlock.conv3 shares its input with conv1): units 54/55 = centre tap fed by dy3.
-    __shared__ __attribute__((aligned(16))) char lds[NHALO * C::PX + 2 * NVOX * C::PY];
+    __shared__ __attribute__((aligned(16))) char lds[NHALO * C::PX + (HAS3 ? 2 : 1) * NVOX * C::PY];
     char* ximg = lds;
     char* yimg = lds + NHALO * C::PX;
     char* y3img = yimg + NVOX * C::PY;
-    const int nunits = dy3 ? WG_UNITS + 2 : WG_UNITS;
+    const int nunits = HAS3 ? WG_UNITS + 2 : WG_UNITS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 16;
     // per-unit LDS byte offsets of the shifted window (wave-uniform)
@@ -254,9 +471,9 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
         tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
-        stage_halo<P, 32 / CH>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg, vecx);
+        stage_halo<P, 32 / CH, VECX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
         // dy tile(s): 256 voxels x 16 channels, all loads of a thread in flight together
-        auto stage_dy = [&](const float* __restrict__ src, long ld, int vec, char* img) {
+        auto stage_dy = [&](const float* __restrict__ src, long ld, char* img) {
             constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
             f32x4 buf[YIT][NQ];
 #pragma unroll
@@ -266,16 +483,21 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
                 const int gz = z0 + (v >> 6), gy = y0 + ((v >> 4) & 3), gx = x0 + (v & 15);
                 const int cc = co0 + ch * CH;
                 const bool ok = gz < D && gy < H && gx < W && cc < Cout;
-                const float* q = src + ((((long)b * D + gz) * H + gy) * W + gx) * ld + cc;
-                if (vec) {
+                const float* q = ok ? src + ((((long)b * D + gz) * H + gy) * W + gx) * ld + cc : src;   // branch-free
 #pragma unroll
-                    for (int c4 = 0; c4 < NQ; ++c4)
-                        buf[j][c4] = (ok && cc + 4 * c4 + 4 <= Cout) ? *(const f32x4*)(q + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else {
+                for (int c4 = 0; c4 < NQ; ++c4) {
+                    if constexpr (VECY) {
+                        const bool okc = ok && cc + 4 * c4 + 4 <= Cout;
+                        f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : src);
+                        buf[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    } else {
 #pragma unroll
-                    for (int c4 = 0; c4 < NQ; ++c4)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) buf[j][c4][e] = (ok && cc + 4 * c4 + e < Cout) ? q[4 * c4 + e] : 0.f;
+                        for (int e = 0; e < 4; ++e) {
+                            const bool oke = ok && cc + 4 * c4 + e < Cout;
+                            float t = *(oke ? q + 4 * c4 + e : src);
+                            buf[j][c4][e] = oke ? t : 0.f;
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -288,8 +510,8 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
                 *(u32x4*)(img + v * C::PY + ch * 16) = P::pack(vals);
             }
         };
-        stage_dy(dy, lddy, vecy, yimg);
-        if (dy3) stage_dy(dy3, lddy3, vecy3, y3img);
+        stage_dy(dy, lddy, yimg);
+        if constexpr (HAS3) stage_dy(dy3, lddy3, y3img);
         __syncthreads();
 
         for (int kb = 0; kb < C::NKB; ++kb) {
@@ -305,7 +527,7 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
                 s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
                 const u32x4 afrag = __builtin_bit_cast(u32x4, a8);
                 u32x4 afrag3 = afrag;
-                if (dy3) {
+                if constexpr (HAS3) {
                     s16x4 clo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + v0 * C::PY + 8 * p));
                     s16x4 chi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + v1 * C::PY + 8 * p));
                     s16x8 c8 = {clo[0], clo[1], clo[2], clo[3], chi[0], chi[1], chi[2], chi[3]};
@@ -330,7 +552,7 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
                 for (int tt = 0; tt < 4; ++tt) {
                     int v = kb * 16 + 4 * g + tt;
                     av[tt] = *(const float*)(yimg + v * C::PY + c * 4);
-                    av3[tt] = dy3 ? *(const float*)(y3img + v * C::PY + c * 4) : 0.f;
+                    av3[tt] = HAS3 ? *(const float*)(y3img + v * C::PY + c * 4) : 0.f;
                     hb[tt] = (((v >> 6) * HY + ((v >> 4) & 3)) * HX + (v & 15)) * C::PX + c * 4;
                 }
 #pragma unroll
@@ -398,10 +620,23 @@ __global__ void tr16_probe_kernel(const uint16_t* __restrict__ in, uint16_t* __r
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)v[j];
 }
 
+// the pair layout is used for bf16 with <= 16 contraction channels (K = Cin forward, Cout for the data gradient)
+template <class P> inline bool use_pair(int K) { return P::CH == 8 && K <= 16; }
+inline int conv_pipe_enabled() {   // tuning hook: UNETR_CONV_PIPE=0 selects the one-tile-per-workgroup kernel
+    const char* e = getenv("UNETR_CONV_PIPE");
+    return e ? atoi(e) : 1;
+}
+
 template <class P>
 int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st) {
     typedef typename ElemOf<P>::type T;
     const int SL = 4 * P::CH, K = mode ? Cout : Cin, N = mode ? Cin : Cout;
+    if (use_pair<P>(K) && conv_pipe_enabled()) {
+        long total = 14L * N * 32;
+        hipLaunchKernelGGL(conv3_pack_pair_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, w,
+                           (uint16_t*)wp, Cin, Cout, mode);
+        return unetr_check_launch();
+    }
     long total = 27L * ((K + SL - 1) / SL) * N * SL;
     int blocks = (int)std::min<long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL((conv3_pack_kernel<T>), dim3(blocks), dim3(256), 0, st, w, (T*)wp, Cin, Cout, mode, SL);
@@ -420,9 +655,40 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
         while (ntb > 1 && spatial * (ntn / ntb) < 512) ntb >>= 1;
     }
     const int vec = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
+    if (conv_pipe_enabled() && ntb <= 4) {
+        // persistent, software-pipelined kernel: a few resident workgroups per CU walk the tiles
+        const bool pair = use_pair<P>(Cin);
+        if (pair && ntb > 2) ntb = 2;
+        const long cap = 512;   // 2 resident workgroups per CU (VGPR-limited); more would queue behind them
+        dim3 pgrid((unsigned)std::min<long>(spatial, cap), ntn / ntb);
+#define LAUNCH_PIPE(NTB_, PAIR_)                                                                                                  \
+    do {                                                                                                                          \
+        if (vec) hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, true>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, \
+                                    y, ldy, accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial);                            \
+        else hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, false>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp,   \
+                                y, ldy, accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial);                                \
+    } while (0)
+        if constexpr (P::CH == 8) {
+            if (pair) {
+                if (ntb == 1) LAUNCH_PIPE(1, true); else LAUNCH_PIPE(2, true);
+                return unetr_check_launch();
+            }
+        }
+        switch (ntb) {
+            case 1: LAUNCH_PIPE(1, false); break;
+            case 2: LAUNCH_PIPE(2, false); break;
+            default: LAUNCH_PIPE(4, false); break;
+        }
+        return unetr_check_launch();
+    }
     dim3 grid((unsigned)spatial, ntn / ntb);
-#define LAUNCH_FWD(NTB_) hipLaunchKernelGGL((conv3_fwd_kernel<P, NTB_>), grid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
-                                           accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, vec)
+#define LAUNCH_FWD(NTB_)                                                                                                          \
+    do {                                                                                                                          \
+        if (vec) hipLaunchKernelGGL((conv3_fwd_kernel<P, NTB_, true>), grid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy,     \
+                                    accumulate, D, H, W, Cin, Cout, ntx, nty, ntz);                                               \
+        else hipLaunchKernelGGL((conv3_fwd_kernel<P, NTB_, false>), grid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy,       \
+                                accumulate, D, H, W, Cin, Cout, ntx, nty, ntz);                                                   \
+    } while (0)
     switch (ntb) {
         case 1: LAUNCH_FWD(1); break;
         case 2: LAUNCH_FWD(2); break;
@@ -450,8 +716,18 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
     if (nci > 65535 || nco > 65535) return UNETR_ERR_ARG;
     const int vecx = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
     const int vecy = (((uintptr_t)dy & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((conv3_wgrad_kernel<P>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, ws, dy3, lddy3, ws3, D, H, W, Cin, Cout,
-                       ntx, nty, ntz, (int)ntiles, vecx, vecy, vecy3);
+    const bool vy = vecy && (!dy3 || vecy3);
+#define LAUNCH_WG(VX_, VY_)                                                                                                        \
+    do {                                                                                                                           \
+        if (dy3) hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, true>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, \
+                                    lddy, ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);                      \
+        else hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, false>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy,  \
+                                lddy, ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);                          \
+    } while (0)
+    if (vecx && vy) LAUNCH_WG(true, true);
+    else if (vecx) LAUNCH_WG(true, false);
+    else if (vy) LAUNCH_WG(false, true);
+    else LAUNCH_WG(false, false);
     int blocks = (int)std::min<long>((n + 15) / 16, 16384);
     hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, (int)G, n, dw);
     if (dy3) hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((int)std::min<long>((n3 + 15) / 16, 16384)), dim3(256), 0, st, ws3, (int)G, n3, dw3);

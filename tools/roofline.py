@@ -45,7 +45,7 @@ def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
         return ("conv3_fwd_kernel (3x3x3 LDS-halo implicit GEMM, " + ("dgrad" if mode else "fwd") + ")",
                 f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27, nbytes)
 
-    def fam_wgrad(xt, ldx, dy, lddy, dims, cin, cout, prec, out=None):
+    def fam_wgrad(xt, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None):
         B, D, H, W = dims
         v = B * D * H * W
         return ("conv3_wgrad_kernel (+reduce)", f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27,
