@@ -396,27 +396,41 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
             }
         }
         const int zo = z0 + wv;
-        if (zo < D) {
+        {
+            // 16 voxel rows x NTB channel tiles per lane; out-of-volume voxels are clamped to voxel 0 of the tile row
+            // for the (batched, unconditional) read of the accumulate path and skipped on store
+            float* yrow[4][4];
+            bool okv[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int yo = y0 + i;
-                if (yo >= H) continue;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int xo = x0 + 4 * g + rr;
-                    if (xo >= W) continue;
-                    float* yp = y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r;
-                    if (accumulate) {
-                        float old[NTB];
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j) old[j] = yp[j * 16];
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr] + old[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr];
-                    }
+                    const int yo = y0 + i, xo = x0 + 4 * g + rr;
+                    okv[i][rr] = zo < D && yo < H && xo < W;
+                    yrow[i][rr] = okv[i][rr] ? y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r : y + nt0 * 16 + r;
                 }
+            if (accumulate) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float old[4][NTB];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) old[rr][j] = yrow[i][rr][j * 16];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j)
+                            if (okv[i][rr]) yrow[i][rr][j * 16] = acc[i][j][rr] + old[rr][j];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j)
+                            if (okv[i][rr]) yrow[i][rr][j * 16] = acc[i][j][rr];
             }
         }
     }

@@ -201,6 +201,11 @@ def main():
             out["roofline"] = dominant_kernel_roofline(pkg, model, crit, x, y, args.precision)
         except Exception as e:  # noqa: BLE001
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            from tools.roofline import encoder_forward_rate
+            out["encoder_fwd"] = encoder_forward_rate(pkg, model, x, args.precision)
+        except Exception as e:  # noqa: BLE001
+            out["encoder_fwd"] = {"error": f"{type(e).__name__}: {e}"}
     log("roofline done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

@@ -1,23 +1,33 @@
+# PMC counters for the dominant conv kernel (run on the GPU box; separate --pmc passes as MI355X_MICROARCH.md prescribes).
+# usage: bash tools/pmc_conv3.sh <outdir> ; writes <outdir>/pmc_summary.json
 set -e
-cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/pmc1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=${1:-$R/gpurun_out/pmc}
 mkdir -p $O
-KB="python3 $R/tools/kernel_bench.py"
-$KB conv3_fwd --cin 16 --cout 16 --iters 10 > $O/times.log 2>&1
-$KB conv3_fwd --cin 32 --cout 16 --iters 10 >> $O/times.log 2>&1
-$KB conv3_dgrad --cin 32 --cout 16 --iters 10 >> $O/times.log 2>&1
-$KB conv3_wgrad --cin 32 --cout 16 --iters 10 >> $O/times.log 2>&1
-$KB conv3_fwd --cin 16 --cout 16 --prec fp32 --iters 5 >> $O/times.log 2>&1
-$KB gemm --m 432 --n 768 --k 3072 --iters 50 >> $O/times.log 2>&1
-$KB gemm --m 432 --n 3072 --k 768 --iters 50 >> $O/times.log 2>&1
-$KB gemm --m 13824 --n 3072 --k 768 --iters 10 >> $O/times.log 2>&1
-$KB gemm --m 13824 --n 768 --k 3072 --iters 10 >> $O/times.log 2>&1
-$KB encoder_fwd --batch 2 --iters 10 >> $O/times.log 2>&1
-$KB encoder_fwd --batch 32 --iters 3 >> $O/times.log 2>&1
-grep -E '^\{' $O/times.log | cut -c1-200
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+cd /tmp; export TMPDIR=/tmp
+ARGS="conv3_fwd --cin 16 --cout 16 --size 96 --batch 2 --prec bf16 --iters 3 --warmup 1"
+python3 $R/tools/kernel_bench.py conv3_fwd --cin 16 --cout 16 --size 96 --batch 2 --prec bf16 --iters 20 > $O/time.json 2>/dev/null
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   T=$(echo $C | cut -d' ' -f1)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$T -- python3 $R/tools/kernel_bench.py conv3_fwd --cin 16 --cout 16 --iters 3 --warmup 1 > $O/$T.log 2>&1 || echo "pmc $T failed"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$T -- python3 $R/tools/kernel_bench.py $ARGS > $O/$T.log 2>&1 || echo "pmc $T failed"
 done
-ls $O
+python3 - <<PY
+import csv, glob, json, collections
+out = {"command": "tools/kernel_bench.py $ARGS", "kernel_filter": "conv3_fwd"}
+out["time"] = json.load(open("$O/time.json"))
+for d in ["FETCH_SIZE", "WRITE_SIZE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU"]:
+    for f in glob.glob(f"$O/{d}/*/*_counter_collection.csv"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "conv3_fwd" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            out[k] = sum(v) / len(v)
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a 16 B/lane coalesced stream (guide, section HBM)
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    out["hbm_read_bytes_corrected"] = out["FETCH_SIZE"] * 1024 * 2
+    out["hbm_write_bytes"] = out["WRITE_SIZE"] * 1024
+    out["traffic_bytes_per_launch"] = out["hbm_read_bytes_corrected"] + out["hbm_write_bytes"]
+json.dump(out, open("$O/pmc_summary.json", "w"), indent=1)
+print(json.dumps(out)[:900])
+PY

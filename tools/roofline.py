@@ -76,7 +76,64 @@ def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
     else:
         bound, achieved, peak, unit = "hbm", nbytes / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
     return {"kernel": fam, "shape": label, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 5), "traffic": None, "avg_ms_per_launch": round(avg_ms, 4),
+            "frac": round(achieved / peak, 5), "traffic": _pmc_traffic(fam, label, precision), "avg_ms_per_launch": round(avg_ms, 4),
             "launches_per_step": len(rows) // reps, "algorithmic_bytes_per_launch": nbytes,
             "algorithmic_flops_per_launch": flops,
             "share_of_conv_time": round(tot[(fam, label)] / max(sum(tot.values()), 1e-9), 4)}
+
+
+def _pmc_traffic(fam, label, precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (tools/pmc_conv3.sh:
+    FETCH_SIZE x 2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE, separate passes), when it is the same
+    kernel / shape / precision; otherwise null."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_conv3_fwd_16to16_96cube.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    if "conv3_fwd" in fam and ", fwd)" in fam and label.startswith("16->16 ch @ 96x96x96, B=2") and precision == "bf16":
+        return d.get("traffic_bytes_per_launch")
+    return None
+
+
+def encoder_forward_rate(pkg, model, x_in, precision, iters=10):
+    """ViT-encoder forward (patch embedding + 12 transformer blocks + final LayerNorm) alone, hipGraph replay, as a
+    fraction of the dense MFMA peak of the compute dtype (BASELINE.json: 'encoder %MFMA-peak').  Algorithmic FLOPs:
+    39.771 GF per 96^3 volume."""
+    Fn = pkg.functional
+    prec = {"fp32": 0, "bf16": 1}[precision]
+    pe = model.vit.patch_embedding
+    B = x_in.shape[0]
+    L = pe.position_embeddings.shape[1]
+
+    def fwd():
+        with torch.no_grad():
+            z = Fn.PatchEmbedFn.apply(x_in, pe.patch_embeddings[1].weight, pe.patch_embeddings[1].bias, pe.position_embeddings,
+                                      model.patch_size[0], prec)
+            for blk in model.vit.blocks:
+                z = Fn.TransformerBlockFn.apply(
+                    z, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
+                    blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
+                    blk.mlp.linear2.bias, B, L, model.num_heads, prec)
+            return Fn.LayerNormFn.apply(z, model.vit.norm.weight, model.vit.norm.bias)
+    fwd()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fwd()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 39.771e9 * B
+    tf = flops / (ms * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS[precision]
+    return {"batch": B, "ms": round(ms, 4), "TFLOP/s": round(tf, 2), "peak_TFLOP/s": peak, "frac_of_mfma_peak": round(tf / peak, 5),
+            "algorithmic_flops": flops, "note": "batch 2 = 432 token rows per GEMM: launch/latency-bound, not MFMA-bound"}
