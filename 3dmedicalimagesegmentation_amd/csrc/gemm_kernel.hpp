@@ -32,18 +32,21 @@ struct LdRowT {  // element(row,k) = p[b*stride + row*ld + k]        (k contiguo
     __device__ __forceinline__ void load(int b, int row, int k, int kend, float* v) const {
         const bool ok = row < rows && k < kend;
         const float* q = p + (long)b * stride + (long)(ok ? row : 0) * ld + (ok ? k : 0);
+        // out-of-range data is masked by a MULTIPLY, not a select: hipcc turns `ok ? loaded : 0` back into a
+        // conditional load (one branch + s_waitcnt per chunk); the clamped address always holds real, finite data
+        const float okf = ok ? 1.f : 0.f;
         if constexpr (VEC) {
 #pragma unroll
             for (int c = 0; c < CH / 4; ++c) {
                 f32x4 t = *(const f32x4*)(q + 4 * c);
-                v[4 * c] = ok ? t[0] : 0.f; v[4 * c + 1] = ok ? t[1] : 0.f; v[4 * c + 2] = ok ? t[2] : 0.f; v[4 * c + 3] = ok ? t[3] : 0.f;
+                v[4 * c] = t[0] * okf; v[4 * c + 1] = t[1] * okf; v[4 * c + 2] = t[2] * okf; v[4 * c + 3] = t[3] * okf;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const bool okj = ok && (k + j < kend);
                 float t = q[okj ? j : 0];
-                v[j] = okj ? t : 0.f;
+                v[j] = t * (okj ? 1.f : 0.f);
             }
         }
     }
@@ -62,7 +65,7 @@ struct LdCol {  // element(row,k) = p[b*stride + k*ld + row]        (row contigu
         for (int j = 0; j < CH; ++j) {
             const bool ok = okr && (k + j < kend);
             float t = q[(long)(ok ? k + j : 0) * ld];
-            v[j] = ok ? t : 0.f;
+            v[j] = t * (ok ? 1.f : 0.f);       // mask by multiply (see LdRowT)
         }
     }
 };
@@ -256,6 +259,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int m0, int n0, int kbeg
                                           const AL& al, const BL& bl, const EP& ep, float* __restrict__ ws, char* lds) {
     constexpr int NT = 64 * WVM * WVN, BM = 16 * WM * WVM, BN = 16 * WN * WVN, CH = P::CH, SK = 8 * CH;
     constexpr int AIT = (BM * 8 + NT - 1) / NT, BIT = (BN * 8 + NT - 1) / NT;
+    constexpr bool AFULL = (BM * 8) % NT == 0, BFULL = (BN * 8) % NT == 0;   // no per-chunk guard (= no branch) when the tile divides evenly
     char* ldsA = lds;
     char* ldsB = lds + BM * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WVN, wn = wave % WVN;
@@ -272,7 +276,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int m0, int n0, int kbeg
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             int id = tid + i * NT;
-            if (id < BM * 8) {
+            if (AFULL || id < BM * 8) {
                 int row = AL::KCONTIG ? (id >> 3) : (id % BM), c = AL::KCONTIG ? (id & 7) : (id / BM);
                 al.template load<CH>(batch, m0 + row, k0 + c * CH, kend, raw[slot][i]);
             }
@@ -280,7 +284,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int m0, int n0, int kbeg
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
             int id = tid + i * NT;
-            if (id < BN * 8) {
+            if (BFULL || id < BN * 8) {
                 int row = BL::KCONTIG ? (id >> 3) : (id % BN), c = BL::KCONTIG ? (id & 7) : (id / BN);
                 bl.template load<CH>(batch, n0 + row, k0 + c * CH, kend, raw[slot][AIT + i]);
             }
@@ -290,7 +294,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int m0, int n0, int kbeg
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             int id = tid + i * NT;
-            if (id < BM * 8) {
+            if (AFULL || id < BM * 8) {
                 int row = AL::KCONTIG ? (id >> 3) : (id % BM), c = AL::KCONTIG ? (id & 7) : (id / BM);
                 *(u32x4*)(ldsA + lds_tile_off(row, c)) = P::pack(raw[slot][i]);
             }
@@ -298,7 +302,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int m0, int n0, int kbeg
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
             int id = tid + i * NT;
-            if (id < BN * 8) {
+            if (BFULL || id < BN * 8) {
                 int row = BL::KCONTIG ? (id >> 3) : (id % BN), c = BL::KCONTIG ? (id & 7) : (id / BN);
                 *(u32x4*)(ldsB + lds_tile_off(row, c)) = P::pack(raw[slot][AIT + i]);
             }
@@ -311,33 +315,33 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int m0, int n0, int kbeg
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Branch-free pipeline body: stages past the end of the K range are loaded as zeros by the loaders (k >= kend)
+    // and multiplied harmlessly, so there is no control flow between the loads of stage kt+PF and the MFMAs of
+    // stage kt -- with per-stage `if (kt < nk)` guards every pair of loads sat in its own basic block and was
+    // followed by s_waitcnt vmcnt(0).  The host picks split-K so that the stage count is a multiple of PF.
 #pragma unroll
-    for (int s = 0; s < PF; ++s)
-        if (s < nk) gload(s, s);
+    for (int s = 0; s < PF; ++s) gload(s, s);
     for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
-            const int kt = kt0 + s;
-            if (kt < nk) {
-                lstore(s);
-                __syncthreads();
-                if (kt + PF < nk) gload(kt + PF, s);
+            lstore(s);
+            __syncthreads();
+            gload(kt0 + s + PF, s);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    u32x4 a[WM], b[WN];
+            for (int kb = 0; kb < 2; ++kb) {
+                u32x4 a[WM], b[WN];
 #pragma unroll
-                    for (int i = 0; i < WM; ++i)
-                        a[i] = *(const u32x4*)(ldsA + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+                for (int i = 0; i < WM; ++i)
+                    a[i] = *(const u32x4*)(ldsA + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
 #pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        b[j] = *(const u32x4*)(ldsB + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+                for (int j = 0; j < WN; ++j)
+                    b[j] = *(const u32x4*)(ldsB + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
 #pragma unroll
-                    for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                        for (int j = 0; j < WN; ++j) P::mma(acc[i][j], a[i], b[j]);
-                }
-                __syncthreads();
+                    for (int j = 0; j < WN; ++j) P::mma(acc[i][j], a[i], b[j]);
             }
+            __syncthreads();
         }
     }
 
@@ -427,9 +431,11 @@ int launch_cfg(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, s
     int ksteps = cdiv(K, SK);
     long tiles = (long)mt * nt * batch;
     int splits = 1;
-    if (tiles < 512 && ksteps >= 4) {
-        splits = (int)((768 + tiles - 1) / tiles);
-        if (splits > ksteps / 2) splits = ksteps / 2;
+    // split-K only when the tile grid leaves most CUs idle (measured at M = 432: N >= 2304 is fastest unsplit, N = 768
+    // wants ~6 slabs at K = 3072 and 2-4 at K = 768); each slab gets whole prefetch rings (3 stages)
+    if (tiles < 192 && ksteps >= 6) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        if (splits > ksteps / 3) splits = ksteps / 3;
         if (splits < 1) splits = 1;
     }
     { // tuning hooks (read once): UNETR_GEMM_SPLITS forces the split count
@@ -438,7 +444,9 @@ int launch_cfg(int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, s
     }
     while (splits > 1 && (size_t)splits * batch * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits > 1 && ws == nullptr) splits = 1;
-    int kper = cdiv(ksteps, splits) * SK;
+    int steps_per = cdiv(ksteps, splits);
+    if (splits > 1 && steps_per > 3) steps_per = (steps_per + 2) / 3 * 3;   // whole prefetch rings (PF = 3)
+    int kper = steps_per * SK;
     splits = cdiv(K, kper);
     if (nt > 65535 || (long)batch * splits > 65535) return UNETR_ERR_ARG;
     dim3 grid(mt, nt, batch * splits);
