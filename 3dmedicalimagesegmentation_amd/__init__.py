@@ -5,8 +5,8 @@ The directory name starts with a digit, so import it with
 ``sys.path`` and keep the reference scripts' own ``from unetr import UNETR`` line unchanged.
 """
 from .unetr import UNETR, UNETRLogits, default_precision  # noqa: F401
-from .losses import DiceCELoss  # noqa: F401
+from .losses import DiceCELoss, ranking_loss  # noqa: F401
 from .optim import AdamW  # noqa: F401
 from . import _capi, ddp, functional  # noqa: F401
 
-__all__ = ["UNETR", "UNETRLogits", "DiceCELoss", "AdamW", "default_precision"]
+__all__ = ["UNETR", "UNETRLogits", "DiceCELoss", "ranking_loss", "AdamW", "default_precision"]

@@ -70,10 +70,12 @@ _SIGNATURES = {
     "unetr_outconv_bwd": [P, P, c_long, P, P, c_long, P, P, c_int, c_long, c_int, c_int, P, c_size_t, P],
     "unetr_dicece_fwd": [P, P, c_int, c_int, c_long, c_float, c_float, P, P, P, c_size_t, P],
     "unetr_dicece_bwd": [P, P, P, P, P, c_int, c_int, c_long, P],
+    "unetr_ranking_loss_fwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, c_size_t, P],
+    "unetr_ranking_loss_bwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P],
 }
 
-EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes",)
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_ranking_workspace_floats")
 
 _lib = None
 
@@ -94,6 +96,8 @@ def load():
         fn.restype = c_int
     lib.unetr_conv3_packed_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.unetr_conv3_packed_bytes.restype = c_size_t
+    lib.unetr_ranking_workspace_floats.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.unetr_ranking_workspace_floats.restype = c_size_t
     _lib = lib
     return lib
 

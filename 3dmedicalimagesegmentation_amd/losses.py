@@ -37,3 +37,49 @@ class DiceCELoss(nn.Module):
 
     def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         return self.terms(input, target)[0]
+
+
+class _RankingLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, slice_dimension, init_idx, temperature, kind):
+        Fn._require_gpu(feat)
+        feat = feat.contiguous()
+        if feat.dim() != 5 or feat.shape[0] != 4:
+            raise ValueError("ranking losses need a [4, C, S1, S2, S3] batch (2 volumes x 2 transforms), as "
+                             "unetr_ranking_pretraining_3d.py:251-253 requires")
+        _, C, S1, S2, S3 = feat.shape
+        lib = Fn._capi.load()
+        need = lib.unetr_ranking_workspace_floats(C, S1, S2, S3, slice_dimension)
+        ws = Fn.workspace(feat.device)
+        if need > ws.numel():
+            raise RuntimeError("ranking loss workspace too small")
+        loss = torch.empty(1, dtype=torch.float32, device=feat.device)
+        W = torch.empty(C, 16, 16, dtype=torch.float32, device=feat.device)
+        Fn.call("unetr_ranking_loss_fwd", feat.data_ptr(), C, S1, S2, S3, slice_dimension, init_idx, float(temperature), kind,
+                loss.data_ptr(), W.data_ptr(), ws.data_ptr(), ws.numel(), Fn._stream())
+        ctx.save_for_backward(feat, W)
+        ctx.meta = (C, S1, S2, S3, slice_dimension, init_idx)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        feat, W = ctx.saved_tensors
+        C, S1, S2, S3, sd, init_idx = ctx.meta
+        dfeat = torch.zeros_like(feat)
+        dl = dloss.reshape(1).contiguous()
+        Fn.call("unetr_ranking_loss_bwd", feat.data_ptr(), C, S1, S2, S3, sd, init_idx, W.data_ptr(), dl.data_ptr(), dfeat.data_ptr(),
+                Fn._stream())
+        return dfeat, None, None, None, None
+
+
+def ranking_loss(features, slice_dimension, init_idx, temperature, kind="ranking"):
+    """Fused self-supervised pre-training loss of unetr_ranking_pretraining_3d.py.
+
+    Equivalent to ``extract_triplets_more_partitions(f1, f2, slice_dimension)`` (lines 59-133, with the random
+    ``init_idx`` passed in) followed by ``BTLoss`` (kind="ranking", lines 202-212) or ``ContrastiveLoss``
+    (kind="contrastive", lines 219-231) on ``f1, f2 = torch.split(features, [2, 2])`` -- the loss value only; calling
+    ``backward()`` / ``optimizer.step()`` stays with the caller as everywhere else in this package."""
+    kinds = {"ranking": 0, "contrastive": 1}
+    if kind not in kinds:
+        raise KeyError(f"loss kind {kind!r} is not supported")
+    return _RankingLossFn.apply(features, int(slice_dimension), int(init_idx), float(temperature), kinds[kind])

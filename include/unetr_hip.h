@@ -156,6 +156,17 @@ int unetr_dicece_fwd(const float* logits, const float* label, int B, int C, long
 int unetr_dicece_bwd(const float* logits, const float* label, const float* coef, const float* dloss,
                      float* dlogits, int B, int C, long V, void* stream);
 
+/* ---- ranking pre-training losses (unetr_ranking_pretraining_3d.py:59-133 triplet construction, :202-217 BTLoss,
+ * :219-236 ContrastiveLoss), fused: feat is the NCDHW feature map [4, C, S1, S2, S3] (2 volumes x 2 transforms: enc4 in
+ * the "feat" stage, logits in the "recon" stage), slice_dim in {2,3,4} as in the reference, init_idx the random slice
+ * offset the reference draws with np.random.choice (injected for determinism).  kind 0 = Bradley-Terry, 1 = contrastive.
+ * W [C,16,16] keeps dL/d<v_i,v_j> for backward; dfeat must be zero-filled by the caller (only the 16 slices are written). */
+size_t unetr_ranking_workspace_floats(int C, int S1, int S2, int S3, int slice_dim);
+int unetr_ranking_loss_fwd(const float* feat, int C, int S1, int S2, int S3, int slice_dim, int init_idx,
+                           float temperature, int kind, float* loss, float* W, float* ws, size_t ws_floats, void* stream);
+int unetr_ranking_loss_bwd(const float* feat, int C, int S1, int S2, int S3, int slice_dim, int init_idx,
+                           const float* W, const float* dloss, float* dfeat, void* stream);
+
 /* ---- fused AdamW over one flat fp32 buffer (torch.optim.AdamW semantics; unetr_segmentation_3d.py:522) */
 int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, const float* step_dev, void* stream);
