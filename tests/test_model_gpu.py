@@ -185,3 +185,77 @@ def test_flat_buffers_match_per_tensor_path(pkg, dev):
             assert relerr(p, ref[k]) < 1e-5, (it, k)
     assert torch.equal(pb["vit.patch_embedding.cls_token"], torch.zeros_like(pb["vit.patch_embedding.cls_token"]))
     pkg.functional.clear_grad_sinks()
+
+
+C2 = dict(in_channels=1, out_channels=4, img_size=(96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072,
+          num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True)
+
+
+def test_c2_full_size_fp32_parity(pkg, dev):
+    """BASELINE config[1] geometry (96^3, hidden 768, 12 heads, 4 classes) at batch 1, fp32 mode, against the fp32 CPU
+    oracle: logits / enc4 / Dice / CE within north_star's 1e-3; gradients by cosine (the fp32 oracle is itself noisy)."""
+    from oracle.unetr_oracle import oracle_dice_ce_terms, synthetic_volume
+    ref, hip = _pair(pkg, dev, C2, ref_dtype=torch.float32)
+    hip.precision = "fp32"
+    x, y = synthetic_volume(1, 1, 96, 4, seed=11)
+    enc4_r, logits_r = ref(x)
+    d_r, c_r = oracle_dice_ce_terms(logits_r, y)
+    (d_r + c_r).backward()
+    enc4, logits = hip(x.to(dev))
+    t = pkg.DiceCELoss(to_onehot_y=True, softmax=True).terms(logits, y.to(dev))
+    t[0].backward()
+    assert relerr(logits, logits_r) < 1e-3 and relerr(enc4, enc4_r) < 1e-3
+    assert relerr(t[1], d_r) < 1e-3 and relerr(t[2], c_r) < 1e-3
+    gr, gh = dict(ref.named_parameters()), dict(hip.named_parameters())
+    for k in ["vit.blocks.0.attn.qkv.weight", "vit.blocks.11.mlp.linear1.weight", "encoder1.layer.conv2.conv.weight",
+              "decoder5.conv_block.conv1.conv.weight", "decoder2.conv_block.conv1.conv.weight", "decoder2.transp_conv.conv.weight",
+              "out.conv.conv.weight"]:
+        assert cosine(gh[k].grad, gr[k].grad) > 0.9999, k
+
+
+def test_c4_160_forward_parity(pkg, dev):
+    """BASELINE config[3] geometry: 160^3 input, 1000 tokens (attention tiles with a masked tail, 10^3 token grid)."""
+    from oracle.unetr_oracle import synthetic_volume
+    cfg = dict(C2, img_size=(160, 160, 160), hidden_size=192, mlp_dim=384, num_heads=3, out_channels=3)
+    ref, hip = _pair(pkg, dev, cfg, ref_dtype=torch.float32)
+    hip.precision = "fp32"
+    x, _ = synthetic_volume(1, 1, 160, 3, seed=5)
+    with torch.no_grad():
+        enc4_r, logits_r = ref(x)
+        enc4, logits = hip(x.to(dev))
+    assert logits.shape == (1, 3, 160, 160, 160) and enc4.shape == (1, 128, 20, 20, 20)
+    assert relerr(logits, logits_r) < 1e-3 and relerr(enc4, enc4_r) < 1e-3
+
+
+def test_c5_pretraining_steps(pkg, dev):
+    """BASELINE config[4]: the two stages of unetr_ranking_pretraining_3d.py:238-296 on a [4, ...] batch -- 'feat'
+    (loss on enc4, everything trains) and 'recon' (loss on the logits with freeze_encoder=True) -- vs the oracle."""
+    from oracle.unetr_oracle import oracle_bt_loss, oracle_extract_triplets, synthetic_volume
+    ref, hip = _pair(pkg, dev, C1, seed=2)
+    hip.precision = "fp32"
+    x, _ = synthetic_volume(4, 1, 32, 2, seed=9)
+    rd = next(ref.parameters()).dtype
+    for stage, dim, T in (("feat", 2, 0.1), ("recon", 4, 0.1)):
+        ref.zero_grad()
+        hip.zero_grad()
+        if stage == "feat":
+            inp_r, _ = ref(x.to(rd))
+            inp_h, _ = hip(x.to(dev))
+            init_idx = 0                      # enc4 is 4^3 here: partition size 1
+        else:
+            _, inp_r = ref(x.to(rd), freeze_encoder=True)
+            _, inp_h = hip(x.to(dev), freeze_encoder=True)
+            init_idx = 3                      # logits are 32^3: partition size 8
+        f1, f2 = torch.split(inp_r, [2, 2], dim=0)
+        l_r = oracle_bt_loss(*oracle_extract_triplets(f1, f2, dim, init_idx), T)
+        l_r.backward()
+        l_h = pkg.ranking_loss(inp_h, dim, init_idx, T, kind="ranking")
+        l_h.backward()
+        assert relerr(l_h, l_r) < 1e-3, stage
+        gr, gh = dict(ref.named_parameters()), dict(hip.named_parameters())
+        for k, p in gr.items():
+            assert (p.grad is None) == (gh[k].grad is None), (stage, k)
+        keys = ["decoder2.conv_block.conv1.conv.weight", "out.conv.conv.weight"] if stage == "recon" else \
+            ["encoder4.transp_conv_init.conv.weight", "vit.blocks.9.mlp.linear1.weight", "vit.patch_embedding.patch_embeddings.1.weight"]
+        for k in keys:
+            assert cosine(gh[k].grad, gr[k].grad) > 0.999, (stage, k)
