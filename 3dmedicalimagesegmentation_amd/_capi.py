@@ -30,6 +30,16 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class GemmBf16Desc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int), ("N", c_int), ("K", c_int), ("b_kn", c_int),
+        ("lda", c_long), ("ldb", c_long), ("ldc", c_long), ("ldcb", c_long),
+        ("bias", c_void_p), ("res", c_void_p), ("ldr", c_long), ("res_mod", c_int),
+        ("pre", c_void_p), ("aux", c_void_p), ("ldaux", c_long),
+        ("act", c_int), ("accumulate", c_int), ("alpha", c_float),
+    ]
+
+
 class GroupedProblem(ctypes.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int)]
 
@@ -42,16 +52,18 @@ P = c_void_p
 _SIGNATURES = {
     "unetr_abi_version": [],
     "unetr_gemm": [ctypes.POINTER(GemmDesc), P, P, P, P, c_size_t, P],
+    "unetr_gemm_bf16": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_size_t, P],
+    "unetr_cast_bf16": [P, P, c_long, P],
     "unetr_gemm_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, c_int, P],
     "unetr_colsum_grouped": [ctypes.POINTER(ColsumProblem), c_int, P],
     "unetr_tconv_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_colsum": [P, c_long, c_int, c_int, P, c_int, P, c_size_t, P],
-    "unetr_layernorm_fwd": [P, P, P, P, P, P, c_int, c_int, c_float, P],
-    "unetr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P],
-    "unetr_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P],
-    "unetr_attention_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P],
+    "unetr_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
+    "unetr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P],
+    "unetr_attention_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P],
+    "unetr_attention_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P],
     "unetr_conv_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv_gemm_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv_gemm_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
@@ -72,7 +84,7 @@ _SIGNATURES = {
     "unetr_dicece_bwd": [P, P, P, P, P, c_int, c_int, c_long, P],
     "unetr_ranking_loss_fwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, c_size_t, P],
     "unetr_ranking_loss_bwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
-    "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P],
+    "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_ranking_workspace_floats")

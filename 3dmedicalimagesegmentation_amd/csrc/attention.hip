@@ -146,7 +146,8 @@ constexpr float NEG_BIG = -1.0e30f;
 // ------------------------------------------------------------------------------------------ forward
 template <class P, int DH>
 __global__ void __launch_bounds__(256)
-attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse, int L, int heads, float scale) {
+attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, uint16_t* __restrict__ outb, float* __restrict__ lse,
+                int L, int heads, float scale) {
     using C = AttnCfg<P, DH>;
     __shared__ __attribute__((aligned(16))) char lds[C::IMG_C + (C::BF ? C::IMG_T : C::IMG_C)];
     char* kimg = lds;
@@ -200,6 +201,11 @@ attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* _
         float* op = out + ((long)b * L + q) * Hd + head * DH + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) *(f32x4*)(op + dt * 16) = o[dt] * inv;
+        if (outb) {
+            uint16_t* ob = outb + ((long)b * L + q) * Hd + head * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) *(bf16x4*)(ob + dt * 16) = __builtin_convertvector(o[dt] * inv, bf16x4);
+        }
         if (g == 0) lse[((long)b * heads + head) * L + q] = m + logf(l);
     }
 }
@@ -225,7 +231,7 @@ __global__ void attn_delta_kernel(const float* __restrict__ out, const float* __
 template <class P, int DH>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
-                   const float* __restrict__ delta, float* __restrict__ dqkv, int L, int heads, float scale) {
+                   const float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb, int L, int heads, float scale) {
     using C = AttnCfg<P, DH>;
     __shared__ __attribute__((aligned(16))) char lds[2 * C::IMG_C + C::IMG_T];
     char* kimg = lds;
@@ -268,6 +274,11 @@ attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout
         float* op = dqkv + ((long)b * L + q) * rs + head * DH + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) *(f32x4*)(op + dt * 16) = dq[dt] * scale;
+        if (dqkvb) {
+            uint16_t* ob = dqkvb + ((long)b * L + q) * rs + head * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) *(bf16x4*)(ob + dt * 16) = __builtin_convertvector(dq[dt] * scale, bf16x4);
+        }
     }
 }
 
@@ -275,7 +286,7 @@ attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout
 template <class P, int DH>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
-                    const float* __restrict__ delta, float* __restrict__ dqkv, int L, int heads, float scale) {
+                    const float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb, int L, int heads, float scale) {
     using C = AttnCfg<P, DH>;
     __shared__ __attribute__((aligned(16))) char lds[2 * C::IMG_C + 2 * C::IMG_T + 256];
     char* qimg = lds;
@@ -332,20 +343,28 @@ attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dou
             *(f32x4*)(kp + dt * 16) = dk[dt] * scale;
             *(f32x4*)(vp + dt * 16) = dv[dt];
         }
+        if (dqkvb) {
+            uint16_t* kb = dqkvb + ((long)b * L + key) * rs + Hd + head * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                *(bf16x4*)(kb + dt * 16) = __builtin_convertvector(dk[dt] * scale, bf16x4);
+                *(bf16x4*)(kb + Hd + dt * 16) = __builtin_convertvector(dv[dt], bf16x4);
+            }
+        }
     }
 }
 
 template <class P, int DH>
-int launch_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, float scale, hipStream_t st) {
-    hipLaunchKernelGGL((attn_fwd_kernel<P, DH>), dim3(cdiv(L, 64), heads, B), dim3(256), 0, st, qkv, out, lse, L, heads, scale);
+int launch_fwd(const float* qkv, float* out, uint16_t* outb, float* lse, int B, int L, int heads, float scale, hipStream_t st) {
+    hipLaunchKernelGGL((attn_fwd_kernel<P, DH>), dim3(cdiv(L, 64), heads, B), dim3(256), 0, st, qkv, out, outb, lse, L, heads, scale);
     return unetr_check_launch();
 }
 template <class P, int DH>
-int launch_bwd(const float* qkv, const float* dout, const float* lse, const float* delta, float* dqkv, int B, int L, int heads,
-               float scale, hipStream_t st) {
+int launch_bwd(const float* qkv, const float* dout, const float* lse, const float* delta, float* dqkv, uint16_t* dqkvb, int B, int L,
+               int heads, float scale, hipStream_t st) {
     dim3 grid(cdiv(L, 64), heads, B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, L, heads, scale);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, L, heads, scale);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
     return unetr_check_launch();
 }
 
@@ -363,23 +382,23 @@ int launch_bwd(const float* qkv, const float* dout, const float* lse, const floa
     }                                                                                         \
     return UNETR_ERR_UNSUPPORTED;
 
-extern "C" int unetr_attention_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, int dh,
+extern "C" int unetr_attention_fwd(const float* qkv, float* out, void* out_bf16, float* lse, int B, int L, int heads, int dh,
                                    float scale, int prec, void* stream) {
     if (!qkv || !out || !lse || B <= 0 || L <= 0 || heads <= 0 || B > 65535 || heads > 65535) return UNETR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-#define CALL_FWD(PP, DD) launch_fwd<PP, DD>(qkv, out, lse, B, L, heads, scale, st)
+#define CALL_FWD(PP, DD) launch_fwd<PP, DD>(qkv, out, (uint16_t*)out_bf16, lse, B, L, heads, scale, st)
     ATTN_DISPATCH(CALL_FWD)
 }
 
 extern "C" int unetr_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
-                                   float* dqkv, float* delta, int B, int L, int heads, int dh, float scale, int prec,
-                                   void* stream) {
+                                   float* dqkv, void* dqkv_bf16, float* delta, int B, int L, int heads, int dh, float scale,
+                                   int prec, void* stream) {
     if (!qkv || !out || !dout || !lse || !dqkv || !delta || B <= 0 || L <= 0 || heads <= 0 || B > 65535 || heads > 65535)
         return UNETR_ERR_ARG;
     if (dh & 3) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     long total = (long)B * heads * L;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, out, dout, delta, B, L, heads, dh);
-#define CALL_BWD(PP, DD) launch_bwd<PP, DD>(qkv, dout, lse, delta, dqkv, B, L, heads, scale, st)
+#define CALL_BWD(PP, DD) launch_bwd<PP, DD>(qkv, dout, lse, delta, dqkv, (uint16_t*)dqkv_bf16, B, L, heads, scale, st)
     ATTN_DISPATCH(CALL_BWD)
 }

@@ -1,0 +1,265 @@
+// unetr_gemm_bf16: the ViT encoder's Linear layers with bf16-STORED operands (reference: monai SABlock / MLPBlock
+// nn.Linear calls reached from /root/reference/unetr.py:78-90,190).  The fp32-storage GEMM family (gemm_kernel.hpp)
+// converts fp32 -> bf16 on the way into LDS: twice the operand bytes through L2 and a VALU pass per chunk, which caps
+// it near 12 % of the MFMA peak on large shapes.  Here the producers (LayerNorm, attention, GELU epilogue, the
+// optimizer's weight shadow) already emit bf16, so a tile travels HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4,
+// no VGPR round trip, no ds_write) into a double-buffered 128-byte-row image, and the waves only read fragments and
+// issue MFMAs.
+//
+//   C[M,N] (+)= alpha * A[M,K] . B^T + epilogue      A: bf16 [M,K] (k contiguous)
+//       b_kn = 0: B is bf16 [N,K] (k contiguous; forward  y = x W^T with W as stored by nn.Linear)
+//       b_kn = 1: B is bf16 [K,N] (n contiguous; data gradient dx = dy W with the same W) -- fragments come out of
+//                 LDS through ds_read_b64_tr_b16, the transposing read, so no transposed weight copy is kept
+//
+// LDS image (both operands, b_kn = 0): row r of the tile is 128 bytes = 8 chunks of 8 bf16; chunk c of row r sits
+// in slot c ^ ((r >> 1) & 7).  An LDS-DMA writes wave-uniform base + lane * 16, i.e. lane-linear, so the swizzle
+// is applied to the per-lane SOURCE address: lane (row r, slot s) fetches global chunk s ^ ((r >> 1) & 7).  The 16
+// lanes of one ds_read_b128 group (rows r..r+15, same logical chunk) then hit 16 different 16-byte slots of the
+// 256-byte bank row.
+//
+// Pipeline: one barrier per 64-deep K step.  __syncthreads() drains stage kt's DMA (hipcc emits vmcnt(0) before the
+// barrier while an LDS-DMA is in flight) and orders it for every reader; stage kt+1 is issued right after it into
+// the other buffer, whose last readers finished before they reached this barrier; then fragments + MFMAs of stage kt.
+#include "gemm_kernel.hpp"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define LDS_AS_ __attribute__((address_space(3)))
+
+struct EpBf {
+    float* C; long ldc;
+    uint16_t* Cb; long ldcb;
+    const float* bias;
+    const float* res; long ldr; int res_mod;
+    float* pre;
+    const float* aux; long ldaux;
+    int act, accumulate; float alpha;
+    __device__ __forceinline__ void store(int, int m, int n, float v) const {
+        v *= alpha;
+        if (bias) v += bias[n];
+        if (pre) pre[(long)m * ldc + n] = v;
+        if (act == 1) v = gelu_exact(v);
+        else if (act == 2) v *= gelu_grad(aux[(long)m * ldaux + n]);
+        if (res) v += res[(long)(m % res_mod) * ldr + n];
+        if (C) {
+            if (accumulate) v += C[(long)m * ldc + n];
+            C[(long)m * ldc + n] = v;
+        }
+        if (Cb) {
+            __bf16 h = (__bf16)v;
+            Cb[(long)m * ldcb + n] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+};
+
+// b_kn image swizzle: XOR applied to the 16-byte chunk index of reduction row r (chunk PAIRS move, a transposing read
+// touches 8 bytes).  The 16 (g, q) rows one ds_read_b64_tr_b16 wave-instruction touches (r = 8g + q) are spread over
+// the 8 pair positions of the 256-byte bank row: 16 chunks/row -> bits (q, g&1); 8 chunks/row (two rows per bank
+// row, r&1 picks the half) -> bits (q>>1, g&1).
+template <int CPR> __device__ __forceinline__ int bkn_x(int r) {
+    if constexpr (CPR >= 16) return ((r & 3) | (((r >> 3) & 1) << 2)) << 1;
+    else return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1;
+}
+
+// tile -> (tm, tn): workgroup L runs on XCD L % 8; give every XCD a contiguous run of tiles, m fastest, so the
+// column tiles (weights) an XCD touches are few and stay in its own L2 while A is shared through MALL
+__device__ __forceinline__ bool tile_of(int L, int mt, int nt, int& tm, int& tn) {
+    const int T = mt * nt, per = (T + 7) >> 3;
+    const int t = (L & 7) * per + (L >> 3);
+    if ((L >> 3) >= per || t >= T) return false;
+    tm = t % mt; tn = t / mt;
+    return true;
+}
+
+template <int WM, int WN, int WVM, int WVN, bool BKN>
+__global__ void __launch_bounds__(64 * WVM * WVN)
+gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
+                 const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep,
+                 float* __restrict__ ws) {
+    constexpr int NT = 64 * WVM * WVN, BM = 16 * WM * WVM, BN = 16 * WN * WVN, BK = 64;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BKN ? BK * BN * 2 : BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int AIT = A_BYTES / 16 / NT, BIT = B_BYTES / 16 / NT;
+    static_assert(A_BYTES % (16 * NT) == 0 && B_BYTES % (16 * NT) == 0, "tile must divide into whole wave DMAs");
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+    int tm, tn;
+    if (!tile_of(blockIdx.x, mt, nt, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y, kbeg = split * kper, kend = min(K, kbeg + kper);
+    const int nk = (kend - kbeg) / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WVN, wn = wave % WVN;
+
+    // per-thread source pointers of the DMA pieces at k = kbeg (advanced by BK elements / BK rows per stage)
+    const uint16_t* asrc[AIT];
+    const uint16_t* bsrc[BIT];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        const int id = tid + i * NT, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
+        asrc[i] = A + (long)min(m0 + r, M - 1) * lda + kbeg + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+        const int id = tid + i * NT;
+        if constexpr (!BKN) {
+            const int r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
+            bsrc[i] = B + (long)min(n0 + r, N - 1) * ldb + kbeg + c * 8;
+        } else {
+            // image: BK rows (reduction index) of BN bf16, CPR 16-byte chunks per row, swizzled by bkn_x
+            constexpr int CPR = BN / 8;
+            const int r = id / CPR, s = id % CPR;
+            const int c = s ^ bkn_x<CPR>(r);
+            bsrc[i] = B + (long)(kbeg + r) * ldb + min(n0 + c * 8, N - 8);
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+        char* la = lds + buf * STAGE;
+        char* lb = la + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < AIT; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + (long)kt * BK), (lds_void_t*)(la + (wave * 64 + i * NT) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const uint16_t* g = BKN ? bsrc[i] + (long)kt * BK * ldb : bsrc[i] + (long)kt * BK;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(lb + (wave * 64 + i * NT) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* la = lds + (kt & 1) * STAGE;
+        const char* lb = la + A_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                a[i] = *(const u32x4*)(la + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (!BKN) {
+                    b[j] = *(const u32x4*)(lb + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+                } else {
+                    constexpr int CPR = BN / 8;
+                    const int cc = lane & 15, g = lane >> 4, q = cc >> 2, p = cc & 3;
+                    const int r0 = kb * 32 + 8 * g + q, r1 = r0 + 4;
+                    const int ch = (wn * WN + j) * 2 + (p >> 1);               // logical 16-byte chunk of the 4 columns
+                    const int s0 = ch ^ bkn_x<CPR>(r0);
+                    const int s1 = ch ^ bkn_x<CPR>(r1);
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(lb + r0 * (BN * 2) + s0 * 16 + (p & 1) * 8));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(lb + r1 * (BN * 2) + s1 * 16 + (p & 1) * 8));
+                    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    b[j] = __builtin_bit_cast(u32x4, v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], a[i], b[j]);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * WM + i) * 16 + 4 * (lane >> 4) + r;
+                const int n = n0 + (wn * WN + j) * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    if (splits > 1) ws[((long)split * M + m) * N + n] = acc[i][j][r];
+                    else ep.store(0, m, n, acc[i][j][r]);
+                }
+            }
+}
+
+template <int WM, int WN, int WVM, int WVN, bool BKN>
+int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep,
+                float* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN;
+    const int mt = cdiv(M, BM), nt = cdiv(N, BN), ksteps = K / 64;
+    const long tiles = (long)mt * nt;
+    int splits = 1;
+    if (tiles < 192 && ksteps >= 4) {           // few tiles (batch-2 token counts): cut K so that >= ~256 workgroups run
+        splits = (int)((320 + tiles - 1) / tiles);
+        if (splits > ksteps / 2) splits = ksteps / 2;
+    }
+    if (const char* e = getenv("UNETR_GEMM_SPLITS")) { int v = atoi(e); if (v > 0) splits = std::min(v, ksteps); }
+    while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
+    if (splits < 1 || ws == nullptr) splits = 1;
+    const int kper = cdiv(ksteps, splits) * 64;
+    splits = cdiv(K, kper);
+    const int per = cdiv(tiles, 8);
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WVM, WVN, BKN>), dim3(per * 8, splits), dim3(64 * WVM * WVN), 0, st,
+                       M, N, K, mt, nt, splits, kper, A, lda, B, ldb, ep, ws);
+    if (splits > 1)
+        hipLaunchKernelGGL((splitk_reduce_kernel<EpBf, false>), dim3(cdiv(N, 64), cdiv(M, 4), 1), dim3(256), 0, st, M, N, splits, ws, ep);
+    return unetr_check_launch();
+}
+
+__global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n8) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const f32x4 a = ((const f32x4*)src)[2 * i], b = ((const f32x4*)src)[2 * i + 1];
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        ((u32x4*)dst)[i] = PrecBF16::pack(v);
+    }
+}
+
+__global__ void __launch_bounds__(256) cast_bf16_tail_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long beg, long n) {
+    const long i = beg + blockIdx.x * 256L + threadIdx.x;
+    if (i < n) { __bf16 h = (__bf16)src[i]; dst[i] = __builtin_bit_cast(uint16_t, h); }
+}
+
+}  // namespace
+
+extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
+                               float* ws, size_t ws_bytes, void* stream) {
+    if (!d || !A || !B || (!C && !Cb)) return UNETR_ERR_ARG;
+    const int M = d->M, N = d->N, K = d->K;
+    if (M <= 0 || N <= 0 || K <= 0) return UNETR_ERR_ARG;
+    // whole 64-deep K stages, 16-byte aligned rows; the transposed-B form also needs whole 8-column chunks
+    if (K % 64 || d->lda % 8 || d->ldb % 8 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return UNETR_ERR_UNSUPPORTED;
+    if (d->b_kn && (N % 8 || N < 8)) return UNETR_ERR_UNSUPPORTED;
+    if (d->act == 2 && !d->aux) return UNETR_ERR_ARG;
+    if ((d->pre || d->accumulate) && !C) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    EpBf ep{C, d->ldc, (uint16_t*)Cb, d->ldcb, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : M,
+            d->pre, d->aux, d->ldaux, d->act, d->accumulate, d->alpha};
+    const uint16_t* a = (const uint16_t*)A;
+    const uint16_t* b = (const uint16_t*)B;
+    const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hook
+    const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
+    if (!d->b_kn) {
+        if (big) return launch_bf16<4, 4, 2, 2, false>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
+        return launch_bf16<2, 2, 2, 2, false>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
+    }
+    if (big) return launch_bf16<4, 4, 2, 2, true>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
+    return launch_bf16<2, 2, 2, 2, true>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
+}
+
+// fp32 -> bf16 (round to nearest even), the weight shadow / activation cast
+extern "C" int unetr_cast_bf16(const float* src, void* dst, long n, void* stream) {
+    if (!src || !dst || n < 0) return UNETR_ERR_ARG;
+    if (n == 0) return UNETR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)src & 15) | ((uintptr_t)dst & 15)) == 0;
+    const long n8 = al ? n / 8 : 0;
+    if (n8) hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(n8, 256), 4096)), dim3(256), 0, st, src, (uint16_t*)dst, n8);
+    if (n8 * 8 < n) hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3(cdiv(n - n8 * 8, 256)), dim3(256), 0, st, src, (uint16_t*)dst, n8 * 8, n);
+    return unetr_check_launch();
+}

@@ -12,7 +12,8 @@ constexpr int LN_MAXV = 8;  // float4 per lane -> H <= 2048
 // --------------------------------------------------------------------------------------- LayerNorm
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int H, float eps) {
+                     float* __restrict__ y, uint16_t* __restrict__ yb, float* __restrict__ mean, float* __restrict__ rstd,
+                     int M, int H, float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nv = H >> 2;
@@ -46,6 +47,7 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
             yr[i] = o;
+            if (yb) ((bf16x4*)(yb + (long)row * H))[i] = __builtin_convertvector(o, bf16x4);
         }
     }
 }
@@ -54,7 +56,7 @@ constexpr int LN_RPB = 4;   // rows per block in backward (one per wave): 108 wo
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                      const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-                     const float* __restrict__ dres, float* __restrict__ part, int M, int H) {
+                     uint16_t* __restrict__ dxb, const float* __restrict__ dres, float* __restrict__ part, int M, int H) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][H]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = H >> 2;
@@ -97,6 +99,7 @@ layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, 
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
                 if (dres) { f32x4 p = ((const f32x4*)(dres + (long)row * H))[i]; o += p; }
                 dxr[i] = o;
+                if (dxb) ((bf16x4*)(dxb + (long)row * H))[i] = __builtin_convertvector(o, bf16x4);
             }
         }
     }
@@ -478,7 +481,8 @@ outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, fl
 // -------------------------------------------------------------------------------------------- AdamW
 __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4,
-             long n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ step_dev) {
+             long n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ step_dev,
+             uint16_t* __restrict__ shadow) {
     const float step = *step_dev;
     const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
@@ -494,6 +498,7 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
             mv[e] = me; vv[e] = ve;
         }
         ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+        if (shadow) ((bf16x4*)shadow)[i] = __builtin_convertvector(pv, bf16x4);
     }
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
@@ -503,6 +508,7 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
         float ve = b2 * v[i] + (1.f - b2) * g[i] * g[i];
         p[i] = pe - step_size * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
         m[i] = me; v[i] = ve;
+        if (shadow) { __bf16 h = (__bf16)p[i]; shadow[i] = __builtin_bit_cast(uint16_t, h); }
     }
 }
 
@@ -514,24 +520,25 @@ inline int grid_for(long total, int per_block = 256, int cap = 8192) {
 }  // namespace
 
 // ============================================================================================ C ABI
-extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16,
                                    float* mean, float* rstd, int M, int H, float eps, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0) return UNETR_ERR_ARG;
     if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, M, H, eps);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       (uint16_t*)y_bf16, mean, rstd, M, H, eps);
     return unetr_check_launch();
 }
 
 extern "C" int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, float* dx, const float* dres, float* dgamma, float* dbeta,
-                                   int M, int H, float* ws, size_t ws_bytes, void* stream) {
+                                   const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
+                                   float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0) return UNETR_ERR_ARG;
     if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
     int nblk = cdiv(M, LN_RPB);
     if ((size_t)nblk * 2 * H * sizeof(float) > ws_bytes || !ws) return UNETR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, x, gamma, mean, rstd, dx,
-                       dres, ws, M, H);
+                       (uint16_t*)dx_bf16, dres, ws, M, H);
     hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
     return unetr_check_launch();
 }
@@ -682,12 +689,13 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx,
 }
 
 extern "C" int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                           float eps, float weight_decay, const float* step_dev, void* stream) {
-    if (!p || !g || !m || !v || !step_dev || n <= 0) return UNETR_ERR_ARG;
+                           float eps, float weight_decay, const float* step_dev, void* shadow_bf16, void* stream) {
+    if (!p || !g || !m || !v || !step_dev || n <= 0 || (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)) return UNETR_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
         return UNETR_ERR_ARG;
     long n4 = n >> 2;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(std::max<long>(n4, 1), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, step_dev);
+                       p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, step_dev,
+                       (uint16_t*)shadow_bf16);
     return unetr_check_launch();
 }

@@ -107,6 +107,8 @@ class GradAllReducer:
     def broadcast_parameters(self, params: Iterable[torch.nn.Parameter]):
         for p in params:
             dist.broadcast(p.data, src=0, group=self.group)
+        from . import functional as Fn
+        Fn.invalidate_weight_shadows()      # p.data was rewritten behind the version counter
 
     def _on_grad(self, p):
         b = self._where[p]

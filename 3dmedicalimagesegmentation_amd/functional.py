@@ -7,11 +7,13 @@ these functions must live on a ROCm device -- there is no CPU or eager-PyTorch f
 Layouts: token matrices [B*L, H]; feature maps channels-last [B, D, H, W, C] (possibly row-pitched views).
 """
 import ctypes
+import os
+import weakref
 
 import torch
 
 from . import _capi
-from ._capi import GemmDesc, call
+from ._capi import GemmDesc, GemmBf16Desc, call
 
 LN_EPS = 1e-5
 IN_EPS = 1e-5
@@ -21,13 +23,27 @@ _WS_BYTES = 256 << 20
 
 
 def workspace(device):
-    """Per-device scratch for split-K slabs and reduction partials (stream-ordered, reused by every call)."""
-    key = (device.type, device.index)
+    """Scratch for split-K slabs and reduction partials: one buffer per (device, stream), because the encoder1 branch
+    runs on a side stream concurrently with the ViT (stream-ordered reuse inside a stream is safe)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
+
+
+_SIDE = {}
+
+
+def side_stream(device):
+    """The second HIP stream used to overlap independent branches of the network (one per device)."""
+    key = (device.type, device.index)
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[key] = st
+    return st
 
 
 def _stream():
@@ -179,6 +195,100 @@ def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, prec, a_trans=False, b_trans=False,
     call("unetr_gemm", ctypes.byref(d), A.data_ptr(), B.data_ptr(), C.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
 
 
+def cast_bf16(src, out=None):
+    """fp32 -> bf16 (RNE) copy through the HIP cast kernel"""
+    src = src.contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    call("unetr_cast_bf16", src.data_ptr(), out.data_ptr(), src.numel(), _stream())
+    return out
+
+
+def gemm_bf16(A, B, M, N, K, *, b_kn=False, C=None, Cb=None, lda=None, ldb=None, bias=None, res=None, ldr=0, res_mod=0,
+              pre=None, aux=None, ldaux=0, act=0, accumulate=False, alpha=1.0):
+    """C / Cb [M,N] = epilogue(A[M,K] @ (B[N,K]^T | B[K,N])) with bf16-stored operands (csrc/gemm_bf16.hip)"""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
+    d = GemmBf16Desc()
+    d.M, d.N, d.K, d.b_kn = M, N, K, int(b_kn)
+    d.lda = lda if lda is not None else K
+    d.ldb = ldb if ldb is not None else (N if b_kn else K)
+    d.ldc = d.ldcb = N
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.ldr, d.res_mod = ldr, res_mod
+    d.pre = pre.data_ptr() if pre is not None else None
+    d.aux = aux.data_ptr() if aux is not None else None
+    d.ldaux = ldaux
+    d.act, d.accumulate, d.alpha = act, int(accumulate), alpha
+    ws = workspace(A.device)
+    call("unetr_gemm_bf16", ctypes.byref(d), A.data_ptr(), B.data_ptr(), C.data_ptr() if C is not None else None,
+         Cb.data_ptr() if Cb is not None else None, ws.data_ptr(), ws.numel() * 4, _stream())
+
+
+# ---- bf16 operand storage (bf16 precision mode) ---------------------------------------------------------------
+# The encoder's Linear layers read bf16-STORED operands through unetr_gemm_bf16: activations are emitted as bf16 by
+# the producing kernels (LayerNorm, attention, GELU epilogue), weights come from a bf16 shadow.  A shadow is fresh when
+# (a) the flat-arena AdamW maintains it (the optimizer kernel writes the bf16 copy next to the fp32 master) and torch
+# has not modified the parameter since (version counter), or (b) it was cast in this "weight epoch" -- every code path
+# of this package that changes weights behind torch's back (per-parameter AdamW, DDP broadcast) bumps the epoch.
+# Under hipGraph capture a non-maintained shadow is always re-cast, so the cast is part of the captured step.
+_SHADOW = {}
+_WEIGHT_EPOCH = [0]
+
+
+def bf16_storage_enabled():
+    return os.environ.get("UNETR_AMD_BF16_STORAGE", "1") != "0"
+
+
+def invalidate_weight_shadows():
+    _WEIGHT_EPOCH[0] += 1
+    for ent in _SHADOW.values():
+        ent[1] = -1
+
+
+def register_weight_shadow(w, shadow):
+    """flat-arena mode: `shadow` is the bf16 view the optimizer kernel keeps in step with `w`"""
+    _SHADOW[id(w)] = [shadow, w._version, _WEIGHT_EPOCH[0], True, weakref.ref(w)]   # caller has just cast it
+
+
+def weight_bf16(w):
+    ent = _SHADOW.get(id(w))
+    if ent is None or ent[4]() is not w or ent[0].shape != w.shape or ent[0].device != w.device:
+        ent = [torch.empty(w.shape, dtype=torch.bfloat16, device=w.device), -1, -1, False, weakref.ref(w)]
+        _SHADOW[id(w)] = ent
+    fresh = ent[1] == w._version and (ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
+    if not fresh:
+        cast_bf16(w.detach(), out=ent[0])
+        ent[1], ent[2] = w._version, _WEIGHT_EPOCH[0]
+    return ent[0]
+
+
+def shadow_ptr_for_update(w):
+    """optimizer side: where the bf16 copy of `w` lives, if the GEMMs have asked for one; the caller's kernel rewrites
+    it together with the fp32 master, which makes the shadow optimizer-maintained from here on"""
+    ent = _SHADOW.get(id(w))
+    if ent is None or ent[4]() is not w or ent[1] != w._version:
+        return None
+    ent[3] = True
+    return ent[0].data_ptr()
+
+
+def _bf16_path(prec, *kdims):
+    return prec == _capi.PREC_BF16 and bf16_storage_enabled() and all(k % 64 == 0 for k in kdims)
+
+
+def _twin(t):
+    """bf16 copy of an fp32 activation / gradient: the twin its producer attached, else a cast"""
+    tw = getattr(t, "_unetr_bf16", None)
+    if tw is not None and tw[0].shape == t.shape and tw[1] == t._version:   # autograd may accumulate into t in place
+        return tw[0]
+    return cast_bf16(t)
+
+
+def _attach_twin(t, tb):
+    t._unetr_bf16 = (tb, t._version)
+
+
 def linear_fwd(x, w, bias, prec, res=None, res_mod=0, act=0, pre=None):
     """y[M,N] = act(x[M,K] @ w[N,K]^T + bias) + res"""
     M, K = x.shape
@@ -214,38 +324,47 @@ def colsum(x, M, N, ld, out=None):
     return out
 
 
-def layernorm_fwd(x, w, b):
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def bf16_like(t):
+    return torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+
+
+def layernorm_fwd(x, w, b, bf16_out=None):
     M, H = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-    call("unetr_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-         M, H, LN_EPS, _stream())
+    call("unetr_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), _p(bf16_out), mean.data_ptr(),
+         rstd.data_ptr(), M, H, LN_EPS, _stream())
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dres=None, out_w=None, out_b=None):
+def layernorm_bwd(dy, x, w, mean, rstd, dres=None, out_w=None, out_b=None, dx_bf16=None):
     M, H = x.shape
     dx = torch.empty_like(x)
     dw = out_w if out_w is not None else torch.empty(H, dtype=torch.float32, device=x.device)
     db = out_b if out_b is not None else torch.empty(H, dtype=torch.float32, device=x.device)
     ws = workspace(x.device)
     call("unetr_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-         dres.data_ptr() if dres is not None else None, dw.data_ptr(), db.data_ptr(), M, H, ws.data_ptr(), ws.numel() * 4, _stream())
+         _p(dx_bf16), dres.data_ptr() if dres is not None else None, dw.data_ptr(), db.data_ptr(), M, H, ws.data_ptr(), ws.numel() * 4, _stream())
     return dx, dw, db
 
 
-def attention_fwd(qkv, B, L, heads, dh, prec):
+def attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=None):
     out = torch.empty(B * L, heads * dh, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, L, dtype=torch.float32, device=qkv.device)
-    call("unetr_attention_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, L, heads, dh, float(dh) ** -0.5, prec, _stream())
+    call("unetr_attention_fwd", qkv.data_ptr(), out.data_ptr(), _p(out_bf16), lse.data_ptr(), B, L, heads, dh, float(dh) ** -0.5, prec, _stream())
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, B, L, heads, dh, prec):
+def attention_bwd(qkv, out, dout, lse, B, L, heads, dh, prec, dqkv_bf16=None):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    call("unetr_attention_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+    call("unetr_attention_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), _p(dqkv_bf16),
+         delta.data_ptr(),
          B, L, heads, dh, float(dh) ** -0.5, prec, _stream())
     return dqkv
 
@@ -388,7 +507,11 @@ class PatchEmbedFn(torch.autograd.Function):
         hid = w.shape[0]
         patches = torch.empty(B * L, pd, dtype=torch.float32, device=x_in.device)
         call("unetr_patch_gather", x_in.data_ptr(), patches.data_ptr(), B, C, D, H, W, patch, _stream())
-        z = linear_fwd(patches, w, b, prec, res=pos, res_mod=L)
+        if _bf16_path(prec, pd):
+            z = torch.empty(B * L, hid, dtype=torch.float32, device=x_in.device)
+            gemm_bf16(cast_bf16(patches), weight_bf16(w), B * L, hid, pd, C=z, bias=b, res=pos, ldr=hid, res_mod=L)
+        else:
+            z = linear_fwd(patches, w, b, prec, res=pos, res_mod=L)
         ctx.save_for_backward(patches, w, b, pos)
         ctx.meta = (B, L, hid, prec)
         return z
@@ -413,14 +536,35 @@ class TransformerBlockFn(torch.autograd.Function):
         x = x.contiguous()
         hid = x.shape[1]
         dh = hid // heads
-        y1, m1, r1 = layernorm_fwd(x, n1w, n1b)
-        qkv = linear_fwd(y1, wqkv, None, prec)
-        att, lse = attention_fwd(qkv, B, L, heads, dh, prec)
-        x1 = linear_fwd(att, wp, bp, prec, res=x)
-        y2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
-        u = torch.empty(x.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
-        a = linear_fwd(y2, w1, b1, prec, act=1, pre=u)
-        x2 = linear_fwd(a, w2, b2, prec, res=x1)
+        M, mlp = x.shape[0], w1.shape[0]
+        if _bf16_path(prec, hid, mlp):
+            # bf16-stored operands: every GEMM input below is written as bf16 by its producer (fp32 copies stay for
+            # the weight-gradient GEMMs and the LayerNorm / attention backward kernels)
+            f32 = dict(dtype=torch.float32, device=x.device)
+            y1b = bf16_like(x)
+            y1, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b)
+            qkv = torch.empty(M, 3 * hid, **f32)
+            gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=qkv)
+            attb = bf16_like(x)
+            att, lse = attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=attb)
+            x1 = torch.empty(M, hid, **f32)
+            gemm_bf16(attb, weight_bf16(wp), M, hid, hid, C=x1, bias=bp, res=x, ldr=hid)
+            y2b = bf16_like(x)
+            y2, m2, r2 = layernorm_fwd(x1, n2w, n2b, bf16_out=y2b)
+            u, a = torch.empty(M, mlp, **f32), torch.empty(M, mlp, **f32)
+            ab = bf16_like(a)
+            gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, C=a, Cb=ab, bias=b1, act=1, pre=u)
+            x2 = torch.empty(M, hid, **f32)
+            gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
+        else:
+            y1, m1, r1 = layernorm_fwd(x, n1w, n1b)
+            qkv = linear_fwd(y1, wqkv, None, prec)
+            att, lse = attention_fwd(qkv, B, L, heads, dh, prec)
+            x1 = linear_fwd(att, wp, bp, prec, res=x)
+            y2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
+            u = torch.empty(M, mlp, dtype=torch.float32, device=x.device)
+            a = linear_fwd(y2, w1, b1, prec, act=1, pre=u)
+            x2 = linear_fwd(a, w2, b2, prec, res=x1)
         ctx.save_for_backward(x, n1w, wqkv, wp, n2w, w1, w2, y1, m1, r1, qkv, att, lse, x1, y2, m2, r2, u, a,
                               n1b, bp, n2b, b1, b2)
         ctx.meta = (B, L, heads, dh, prec)
@@ -433,40 +577,71 @@ class TransformerBlockFn(torch.autograd.Function):
         B, L, heads, dh, prec = ctx.meta
         M, hid = x.shape
         dx2 = dx2.contiguous()
+        mlp = w1.shape[0]
+        fast = _bf16_path(prec, hid, mlp)
+        f32 = dict(dtype=torch.float32, device=x.device)
         # MLP
-        du = linear_dgrad(dx2, w2, prec, aux=u)
+        if fast:
+            # data gradients dX = dY . W read W [out, in] as the [K_reduce, N_out] operand (b_kn) -- no transposed copy
+            du, dub = torch.empty(M, mlp, **f32), torch.empty(M, mlp, dtype=torch.bfloat16, device=x.device)
+            gemm_bf16(_twin(dx2), weight_bf16(w2), M, mlp, hid, b_kn=True, C=du, Cb=dub, act=2, aux=u, ldaux=mlp)
+        else:
+            du = linear_dgrad(dx2, w2, prec, aux=u)
         dw2 = wgrad_or_defer(dx2, a, prec, w2)
         db2 = colsum_or_defer(dx2, M, hid, hid, b2)
         dw1 = wgrad_or_defer(du, y2, prec, w1)
         db1 = colsum_or_defer(du, M, du.shape[1], du.shape[1], b1)
-        dy2 = linear_dgrad(du, w1, prec)
-        dx1, dn2w, dn2b = layernorm_bwd(dy2, x1, n2w, m2, r2, dres=dx2, out_w=_gout(n2w), out_b=_gout(n2b))
+        if fast:
+            dy2 = torch.empty(M, hid, **f32)
+            gemm_bf16(dub, weight_bf16(w1), M, hid, mlp, b_kn=True, C=dy2)
+            dx1b = bf16_like(x)
+        else:
+            dy2 = linear_dgrad(du, w1, prec)
+            dx1b = None
+        dx1, dn2w, dn2b = layernorm_bwd(dy2, x1, n2w, m2, r2, dres=dx2, out_w=_gout(n2w), out_b=_gout(n2b), dx_bf16=dx1b)
         # attention
-        datt = linear_dgrad(dx1, wp, prec)
+        if fast:
+            datt = torch.empty(M, hid, **f32)
+            gemm_bf16(dx1b, weight_bf16(wp), M, hid, hid, b_kn=True, C=datt)
+        else:
+            datt = linear_dgrad(dx1, wp, prec)
         dwp = wgrad_or_defer(dx1, att, prec, wp)
         dbp = colsum_or_defer(dx1, M, hid, hid, bp)
-        dqkv = attention_bwd(qkv, att, datt, lse, B, L, heads, dh, prec)
+        dqkvb = torch.empty(M, 3 * hid, dtype=torch.bfloat16, device=x.device) if fast else None
+        dqkv = attention_bwd(qkv, att, datt, lse, B, L, heads, dh, prec, dqkv_bf16=dqkvb)
         dwqkv = wgrad_or_defer(dqkv, y1, prec, wqkv)
-        dy1 = linear_dgrad(dqkv, wqkv, prec)
-        dx, dn1w, dn1b = layernorm_bwd(dy1, x, n1w, m1, r1, dres=dx1, out_w=_gout(n1w), out_b=_gout(n1b))
+        if fast:
+            dy1 = torch.empty(M, hid, **f32)
+            gemm_bf16(dqkvb, weight_bf16(wqkv), M, hid, 3 * hid, b_kn=True, C=dy1)
+            dxb = bf16_like(x)
+        else:
+            dy1 = linear_dgrad(dqkv, wqkv, prec)
+            dxb = None
+        dx, dn1w, dn1b = layernorm_bwd(dy1, x, n1w, m1, r1, dres=dx1, out_w=_gout(n1w), out_b=_gout(n1b), dx_bf16=dxb)
+        if fast:
+            _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
         return (dx, _ret(n1w, dn1w), _ret(n1b, dn1b), dwqkv, dwp, dbp, _ret(n2w, dn2w),
                 _ret(n2b, dn2b), dw1, db1, dw2, db2, None, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, twin=False):
         _require_gpu(x)
         x = x.contiguous()
         y, mean, rstd = layernorm_fwd(x, w, b)
         ctx.save_for_backward(x, w, mean, rstd, b)
+        ctx.twin = bool(twin)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd, b = ctx.saved_tensors
-        dx, dw, db = layernorm_bwd(dy.contiguous(), x, w, mean, rstd, out_w=_gout(w), out_b=_gout(b))
-        return dx, _ret(w, dw), _ret(b, db)
+        dxb = bf16_like(x) if ctx.twin else None    # bf16 operand for the last transformer block's backward GEMMs
+        dx, dw, db = layernorm_bwd(dy.contiguous(), x, w, mean, rstd, out_w=_gout(w), out_b=_gout(b), dx_bf16=dxb)
+        if dxb is not None:
+            _attach_twin(dx, dxb)
+        return dx, _ret(w, dw), _ret(b, db), None
 
 
 # ------------------------------------------------------------------------------ conv-side building blocks

@@ -10,6 +10,7 @@ launch covers every contiguous run of parameters that received a gradient (2 lau
 MONAI's unused ``cls_token`` splits the arena), instead of one launch per tensor."""
 import torch
 
+from . import functional as Fn
 from ._capi import call
 
 
@@ -71,7 +72,8 @@ class AdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 call("unetr_adamw", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                     group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i, stream)
+                     group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i,
+                     Fn.shadow_ptr_for_update(p), stream)
         return loss
 
     def _flat_step(self, group, params, pattern, dev, stream):
@@ -85,6 +87,8 @@ class AdamW(torch.optim.Optimizer):
         if self._flat_state is None:
             self._flat_state = (torch.zeros_like(fp), torch.zeros_like(fp))
         m, v = self._flat_state
+        shadow = flat.get("shadow")            # bf16 copy of the arena read by the bf16-storage GEMMs, refreshed in the same kernel
+        sbase = shadow.data_ptr() if shadow is not None else None
         steps = self._advance_steps(0, params, pattern, dev)
         b1, b2 = group["betas"]
         i, n = 0, len(params)
@@ -98,7 +102,8 @@ class AdamW(torch.optim.Optimizer):
             lo = offs[i]
             hi = offs[j] + (params[j].numel() + 3) // 4 * 4
             call("unetr_adamw", fp.data_ptr() + lo * esz, gbase + lo * esz, m.data_ptr() + lo * esz, v.data_ptr() + lo * esz, hi - lo,
-                 group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i, stream)
+                 group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i,
+                 sbase + lo * 2 if sbase is not None else None, stream)
             for k in range(i, j + 1):
                 self._host_steps[k] += 1
             i = j + 1

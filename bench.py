@@ -94,6 +94,7 @@ def main():
         if dist_on:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0)
+            pkg.functional.invalidate_weight_shadows()
 
     def fwd_bwd():
         logit_map = model(x)

@@ -51,6 +51,32 @@ typedef struct {
 int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float* B, float* C,
                float* ws, size_t ws_bytes, void* stream);
 
+/* ---- bf16-STORED operand GEMM (LDS-DMA staged): the same nn.Linear forward / data-gradient calls as unetr_gemm
+ * (MONAI ViT Linear layers built at unetr.py:78-89) for the bf16 precision mode, where LayerNorm / attention / GELU
+ * epilogues and the optimizer's weight shadow already hold the operands as bf16.
+ *   C[M,N] = epilogue(A[M,K] * Bop):  A bf16 [M,K] (k contiguous, pitch lda);
+ *   b_kn = 0: B bf16 [N,K] (pitch ldb; forward y = x W^T);  b_kn = 1: B bf16 [K,N] (pitch ldb; dgrad dx = dy W).
+ * K must be a multiple of 64; pitches multiples of 8 elements.  Outputs: fp32 C (pitch ldc; may be NULL) and/or
+ * bf16 Cb (pitch ldcb; may be NULL); `pre`/`accumulate` need C.  Epilogue fields as in unetr_gemm_desc. */
+typedef struct {
+    int M, N, K, b_kn;
+    long lda, ldb, ldc, ldcb;
+    const float* bias;
+    const float* res;
+    long ldr;
+    int res_mod;
+    float* pre;
+    const float* aux;
+    long ldaux;
+    int act;
+    int accumulate;
+    float alpha;
+} unetr_gemm_bf16_desc;
+int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
+                    float* ws, size_t ws_bytes, void* stream);
+/* fp32 -> bf16 round-to-nearest-even copy (weight shadows; torch .to(torch.bfloat16) semantics) */
+int unetr_cast_bf16(const float* src, void* dst, long n, void* stream);
+
 /* Grouped launches for the work that is OFF the critical path of backward at batch 2: the weight gradients
  * dW_i[N_i,K_i] = dY_i[M_i,N_i]^T * X_i[M_i,K_i] of all transformer blocks (torch.nn.Linear backward, MONAI
  * ViT built at unetr.py:78-89) and the bias / position-embedding gradient column sums.  One launch covers up to
@@ -78,19 +104,21 @@ int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumula
 
 /* ---- LayerNorm (nn.LayerNorm(H), eps 1e-5, affine; MONAI TransformerBlock.norm1/2, ViT.norm) -------- */
 int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                        void* y_bf16 /* optional bf16 copy of y for unetr_gemm_bf16, or NULL */,
                         float* mean, float* rstd, int M, int H, float eps, void* stream);
 int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                        const float* rstd, float* dx, const float* dres /* optional, added to dx */, float* dgamma, float* dbeta,
+                        const float* rstd, float* dx, void* dx_bf16 /* optional bf16 copy of dx, or NULL */,
+                        const float* dres /* optional, added to dx */, float* dgamma, float* dbeta,
                         int M, int H, float* ws, size_t ws_bytes, void* stream);
 
 /* ---- multi-head self-attention core (MONAI SABlock.forward between qkv and out_proj) ----------------
  * qkv: [B*L, 3*Hd] with feature = which*Hd + head*dh + j;  out: [B*L, Hd] ("b h l d -> b l (h d)");
  * lse: [B, heads, L] log-sum-exp of the scaled scores (saved for backward). */
-int unetr_attention_fwd(const float* qkv, float* out, float* lse, int B, int L, int heads, int dh,
-                        float scale, int prec, void* stream);
+int unetr_attention_fwd(const float* qkv, float* out, void* out_bf16 /* optional bf16 copy, or NULL */, float* lse,
+                        int B, int L, int heads, int dh, float scale, int prec, void* stream);
 int unetr_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
-                        float* dqkv, float* delta, int B, int L, int heads, int dh, float scale, int prec,
-                        void* stream);
+                        float* dqkv, void* dqkv_bf16 /* optional bf16 copy, or NULL */, float* delta,
+                        int B, int L, int heads, int dh, float scale, int prec, void* stream);
 
 /* ---- 3x3x3 (pad 1) and 1x1x1 conv, stride 1, no bias (nn.Conv3d in MONAI UnetResBlock.conv1/2/3) ------
  * General-shape path: implicit GEMM through the MFMA GEMM family (im2col operand loaders, no im2col
@@ -169,7 +197,8 @@ int unetr_ranking_loss_bwd(const float* feat, int C, int S1, int S2, int S3, int
 
 /* ---- fused AdamW over one flat fp32 buffer (torch.optim.AdamW semantics; unetr_segmentation_3d.py:522) */
 int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                float eps, float weight_decay, const float* step_dev, void* stream);
+                float eps, float weight_decay, const float* step_dev,
+                void* shadow_bf16 /* optional: bf16 copy of the updated p (GEMM weight shadow), or NULL */, void* stream);
 
 #ifdef __cplusplus
 }

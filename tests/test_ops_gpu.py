@@ -30,6 +30,56 @@ def test_gemm_nt_nn_tn(pkg, dev, prec, M, N, K):
     assert relerr(Fn.linear_wgrad(dy.to(dev), x.to(dev), prec), dy.t() @ x) < TOL[prec]
 
 
+@pytest.mark.parametrize("M,N,K", [(432, 768, 768), (432, 2304, 768), (432, 768, 3072), (37, 56, 64), (2000, 384, 128),
+                                   (1500, 3072, 768), (8, 128, 4096), (130, 200, 192)])
+def test_gemm_bf16_storage(pkg, dev, M, N, K):
+    """LDS-DMA GEMM on bf16-stored operands: both B layouts, fp32 and bf16 outputs, exact against the same bf16 inputs
+    multiplied in fp64 (only the fp32 accumulation order differs)."""
+    Fn = pkg.functional
+    x, w, dy = g(M, K, seed=1).bfloat16(), g(N, K, seed=2).bfloat16(), g(M, N, seed=3).bfloat16()
+    ref = (x.double() @ w.double().t()).float()
+    xd, wd, dyd = x.to(dev), w.to(dev), dy.to(dev)
+    y = torch.empty(M, N, device=dev)
+    yb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, Cb=yb)
+    assert relerr(y, ref) < 2e-5
+    assert torch.equal(yb.cpu(), y.cpu().bfloat16())
+    if N % 64 == 0 and K % 8 == 0:   # data gradient: dx[M,K] = dy[M,N] @ w[N,K], reduction over N, B read as [N,K] = [K_red, N_out]
+        dx = torch.empty(M, K, device=dev)
+        Fn.gemm_bf16(dyd, wd, M, K, N, b_kn=True, C=dx)
+        assert relerr(dx, (dy.double() @ w.double()).float()) < 2e-5
+
+
+def test_gemm_bf16_epilogues(pkg, dev):
+    Fn = pkg.functional
+    M, N, K, L = 432, 512, 256, 216
+    x, w = g(M, K, seed=1).bfloat16(), g(N, K, seed=2, scale=0.1).bfloat16()
+    b, res, pos, aux = g(N, seed=3), g(M, N, seed=4), g(L, N, seed=5), g(M, N, seed=6)
+    xd, wd = x.to(dev), w.to(dev)
+    lin = (x.double() @ w.double().t()).float()
+    y = torch.empty(M, N, device=dev)
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, bias=b.to(dev), res=res.to(dev), ldr=N)
+    assert relerr(y, lin + b + res) < 2e-5
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, bias=b.to(dev), res=pos.to(dev), ldr=N, res_mod=L)
+    assert relerr(y, lin + b + pos.repeat(2, 1)) < 2e-5
+    pre = torch.empty(M, N, device=dev)
+    yb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, Cb=yb, bias=b.to(dev), act=1, pre=pre)
+    assert relerr(pre, lin + b) < 2e-5 and relerr(y, F.gelu(lin + b)) < 2e-5
+    assert relerr(yb.float(), F.gelu(lin + b)) < 5e-3
+    auxr = aux.clone().requires_grad_(True)
+    F.gelu(auxr).sum().backward()
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, act=2, aux=aux.to(dev), ldaux=N)
+    assert relerr(y, lin * auxr.grad) < 2e-5
+    y0 = g(M, N, seed=7)
+    y = y0.to(dev)
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, accumulate=True, alpha=0.5)
+    assert relerr(y, y0 + 0.5 * lin) < 2e-5
+    assert torch.equal(Fn.cast_bf16(res.to(dev)).cpu(), res.bfloat16())
+    odd = g(1003, seed=8)
+    assert torch.equal(Fn.cast_bf16(odd.to(dev)).cpu(), odd.bfloat16())
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_gemm_epilogues(pkg, dev, prec):
     Fn = pkg.functional
@@ -275,6 +325,7 @@ def test_adamw(pkg, dev):
     pd = torch.zeros(n + 1, device=dev)[:n]  # 16B-aligned base
     pd.copy_(p)
     m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    shadow = torch.zeros(n, device=dev, dtype=torch.bfloat16)
     step = torch.zeros(1, device=dev)
     for it in range(3):
         pr.grad = gr * (it + 1)
@@ -282,8 +333,9 @@ def test_adamw(pkg, dev):
         step += 1
         gd = (gr * (it + 1)).to(dev)
         pkg._capi.call("unetr_adamw", pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2,
-                       step.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                       step.data_ptr(), shadow.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert relerr(pd, pr) < 1e-5
+    assert torch.equal(shadow.cpu(), pd.cpu().bfloat16())      # bf16 weight shadow written by the same kernel
 
 
 @pytest.mark.parametrize("kind", ["ranking", "contrastive"])

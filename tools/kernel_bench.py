@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "gemm", "gemm_dgrad", "gemm_wgrad", "instnorm", "encoder_fwd"])
+    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd"])
     ap.add_argument("--cin", type=int, default=16)
     ap.add_argument("--cout", type=int, default=16)
     ap.add_argument("--size", type=int, default=96)
@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--prec", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="time one hipGraph holding `iters` launches (hides host launch cost)")
     a = ap.parse_args()
     pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
     Fn = pkg.functional
@@ -59,7 +60,11 @@ def main():
         dy = torch.randn(M, N, generator=g).to(dev)
         flops = 2.0 * M * N * K
         nbytes = 4.0 * (M * K + N * K + M * N)
-        fn = {"gemm": lambda: Fn.linear_fwd(x, w, None, prec), "gemm_dgrad": lambda: Fn.linear_dgrad(dy, w, prec),
+        xb, wb, dyb = x.bfloat16(), w.bfloat16(), dy.bfloat16()
+        yo, dxo = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev)
+        fn = {"gemm_bf16": lambda: Fn.gemm_bf16(xb, wb, M, N, K, C=yo),
+              "gemm_bf16_dgrad": lambda: Fn.gemm_bf16(dyb, wb, M, K, N, b_kn=True, C=dxo),
+              "gemm": lambda: Fn.linear_fwd(x, w, None, prec), "gemm_dgrad": lambda: Fn.linear_dgrad(dy, w, prec),
               "gemm_wgrad": lambda: Fn.linear_wgrad(dy, x, prec)}[a.kernel]
         label = f"{a.kernel} M={M} N={N} K={K} {a.prec}"
     elif a.kernel == "instnorm":
@@ -91,12 +96,26 @@ def main():
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / a.iters
+    if a.graph:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(a.iters):
+                fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters / 5
+    else:
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
     print(json.dumps({"kernel": label, "ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "TFLOP/s": round(flops / ms / 1e9, 2),
                       "algorithmic_bytes": nbytes, "algorithmic_flops": flops}))
 
