@@ -75,7 +75,7 @@ __device__ __forceinline__ bool tile_of(int L, int mt, int nt, int& tm, int& tn)
     return true;
 }
 
-template <int WM, int WN, int WVM, int WVN, bool BKN>
+template <int WM, int WN, int WVM, int WVN, bool BKN, int NS>
 __global__ void __launch_bounds__(64 * WVM * WVN)
 gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
                  const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep,
@@ -86,7 +86,9 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int AIT = A_BYTES / 16 / NT, BIT = B_BYTES / 16 / NT;
     static_assert(A_BYTES % (16 * NT) == 0 && B_BYTES % (16 * NT) == 0, "tile must divide into whole wave DMAs");
-    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    constexpr int G = AIT + BIT;                 // LDS-DMA instructions per thread per stage
+    static_assert(NS >= 2 && (NS - 2) * G <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
 
     int tm, tn;
     if (!tile_of(blockIdx.x, mt, nt, tm, tn)) return;
@@ -137,11 +139,18 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue(0, 0);
+    // NS-stage ring, NS-1 stages in flight.  At the top of step kt: wait until this wave's pieces of stage kt have landed
+    // (a counted vmcnt leaves the NS-2 younger stages in flight; the tail drains), and until its own fragment reads of
+    // step kt-1 are done; the raw barrier then publishes stage kt to every wave and frees the buffer of step kt-1, which
+    // the DMA of stage kt+NS-1 overwrites.  (__syncthreads() would drain vmcnt(0) and serialise the ring.)
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* la = lds + (kt & 1) * STAGE;
+        if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NS - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+        const char* la = lds + (kt % NS) * STAGE;
         const char* lb = la + A_BYTES;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -188,24 +197,23 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
             }
 }
 
-template <int WM, int WN, int WVM, int WVN, bool BKN>
+template <int WM, int WN, int WVM, int WVN, bool BKN, int NS>
 int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep,
                 float* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN;
     const int mt = cdiv(M, BM), nt = cdiv(N, BN), ksteps = K / 64;
     const long tiles = (long)mt * nt;
     int splits = 1;
-    if (tiles < 192 && ksteps >= 4) {           // few tiles (batch-2 token counts): cut K so that >= ~256 workgroups run
-        splits = (int)((320 + tiles - 1) / tiles);
-        if (splits > ksteps / 2) splits = ksteps / 2;
-    }
+    // few tiles (batch-2 token counts): the kernel is latency-bound, one workgroup's time is ~ its K steps, so long K
+    // ranges are cut into slabs of >= 12 steps (shorter slabs cost more in the reduce launch than they save)
+    if (tiles < 192 && ksteps >= 24) splits = std::min(ksteps / 12, (int)((512 + tiles - 1) / tiles));
     if (const char* e = getenv("UNETR_GEMM_SPLITS")) { int v = atoi(e); if (v > 0) splits = std::min(v, ksteps); }
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits < 1 || ws == nullptr) splits = 1;
     const int kper = cdiv(ksteps, splits) * 64;
     splits = cdiv(K, kper);
     const int per = cdiv(tiles, 8);
-    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WVM, WVN, BKN>), dim3(per * 8, splits), dim3(64 * WVM * WVN), 0, st,
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WVM, WVN, BKN, NS>), dim3(per * 8, splits), dim3(64 * WVM * WVN), 0, st,
                        M, N, K, mt, nt, splits, kper, A, lda, B, ldb, ep, ws);
     if (splits > 1)
         hipLaunchKernelGGL((splitk_reduce_kernel<EpBf, false>), dim3(cdiv(N, 64), cdiv(M, 4), 1), dim3(256), 0, st, M, N, splits, ws, ep);
@@ -242,14 +250,21 @@ extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, con
             d->pre, d->aux, d->ldaux, d->act, d->accumulate, d->alpha};
     const uint16_t* a = (const uint16_t*)A;
     const uint16_t* b = (const uint16_t*)B;
-    const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hook
+    const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hooks
+    const int env_ns = getenv("UNETR_GEMM_STAGES") ? atoi(getenv("UNETR_GEMM_STAGES")) : 0;
     const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
+#define BF16_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st)
     if (!d->b_kn) {
-        if (big) return launch_bf16<4, 4, 2, 2, false>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
-        return launch_bf16<2, 2, 2, 2, false>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
+        if (big) { if (env_ns == 3) BF16_GO(4, 4, false, 3); if (env_ns == 4) BF16_GO(4, 4, false, 4); BF16_GO(4, 4, false, 2); }
+        if (env_ns == 2) BF16_GO(2, 2, false, 2);
+        if (env_ns == 6) BF16_GO(2, 2, false, 6);
+        BF16_GO(2, 2, false, 4);
     }
-    if (big) return launch_bf16<4, 4, 2, 2, true>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
-    return launch_bf16<2, 2, 2, 2, true>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st);
+    if (big) { if (env_ns == 3) BF16_GO(4, 4, true, 3); if (env_ns == 4) BF16_GO(4, 4, true, 4); BF16_GO(4, 4, true, 2); }
+    if (env_ns == 2) BF16_GO(2, 2, true, 2);
+    if (env_ns == 6) BF16_GO(2, 2, true, 6);
+    BF16_GO(2, 2, true, 4);
+#undef BF16_GO
 }
 
 // fp32 -> bf16 (round to nearest even), the weight shadow / activation cast

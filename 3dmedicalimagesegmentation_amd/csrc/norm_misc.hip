@@ -532,14 +532,15 @@ extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const flo
 extern "C" int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                    const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
                                    float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0) return UNETR_ERR_ARG;
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || ((dgamma == nullptr) != (dbeta == nullptr)) || M <= 0) return UNETR_ERR_ARG;
     if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
     int nblk = cdiv(M, LN_RPB);
     if ((size_t)nblk * 2 * H * sizeof(float) > ws_bytes || !ws) return UNETR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, x, gamma, mean, rstd, dx,
                        (uint16_t*)dx_bf16, dres, ws, M, H);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
+    // dgamma == dbeta == NULL: the caller reduces the [nblk][2][H] partials left in ws itself (grouped, off the critical path)
+    if (dgamma) hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
     return unetr_check_launch();
 }
 

@@ -353,6 +353,26 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres=None, out_w=None, out_b=None, dx_bf
     return dx, dw, db
 
 
+def layernorm_bwd_params(dy, x, w, b, mean, rstd, dres=None, dx_bf16=None):
+    """LayerNorm backward returning (dx, grad_w, grad_b) as autograd wants them.  In arena mode the dgamma/dbeta
+    reduction over row blocks is not needed inside backward: the kernel leaves its partials in a private buffer and the
+    two column sums join the grouped launch at the end of the pass (one launch for all 25 LayerNorms)."""
+    ow, ob = _gout(w), _gout(b)
+    if ow is None or ob is None:
+        dx, dw, db = layernorm_bwd(dy, x, w, mean, rstd, dres=dres, out_w=ow, out_b=ob, dx_bf16=dx_bf16)
+        return dx, _ret(w, dw), _ret(b, db)
+    M, H = x.shape
+    nblk = (M + 3) // 4
+    part = torch.empty(nblk * 2 * H, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    call("unetr_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+         _p(dx_bf16), _p(dres), None, None, M, H, part.data_ptr(), part.numel() * 4, _stream())
+    _DEFER["colsum"].append((part, ow, nblk, H, 2 * H))
+    _DEFER["colsum"].append((part[H:], ob, nblk, H, 2 * H))
+    _arm_flush()
+    return dx, _ret(w, ow, deferred=True), _ret(b, ob, deferred=True)
+
+
 def attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=None):
     out = torch.empty(B * L, heads * dh, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, L, dtype=torch.float32, device=qkv.device)
@@ -598,7 +618,7 @@ class TransformerBlockFn(torch.autograd.Function):
         else:
             dy2 = linear_dgrad(du, w1, prec)
             dx1b = None
-        dx1, dn2w, dn2b = layernorm_bwd(dy2, x1, n2w, m2, r2, dres=dx2, out_w=_gout(n2w), out_b=_gout(n2b), dx_bf16=dx1b)
+        dx1, dn2w, dn2b = layernorm_bwd_params(dy2, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
         # attention
         if fast:
             datt = torch.empty(M, hid, **f32)
@@ -617,11 +637,10 @@ class TransformerBlockFn(torch.autograd.Function):
         else:
             dy1 = linear_dgrad(dqkv, wqkv, prec)
             dxb = None
-        dx, dn1w, dn1b = layernorm_bwd(dy1, x, n1w, m1, r1, dres=dx1, out_w=_gout(n1w), out_b=_gout(n1b), dx_bf16=dxb)
+        dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         if fast:
             _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
-        return (dx, _ret(n1w, dn1w), _ret(n1b, dn1b), dwqkv, dwp, dbp, _ret(n2w, dn2w),
-                _ret(n2b, dn2b), dw1, db1, dw2, db2, None, None, None, None)
+        return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -638,10 +657,10 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, mean, rstd, b = ctx.saved_tensors
         dxb = bf16_like(x) if ctx.twin else None    # bf16 operand for the last transformer block's backward GEMMs
-        dx, dw, db = layernorm_bwd(dy.contiguous(), x, w, mean, rstd, out_w=_gout(w), out_b=_gout(b), dx_bf16=dxb)
+        dx, dw, db = layernorm_bwd_params(dy.contiguous(), x, w, b, mean, rstd, dx_bf16=dxb)
         if dxb is not None:
             _attach_twin(dx, dxb)
-        return dx, _ret(w, dw), _ret(b, db), None
+        return dx, dw, db, None
 
 
 # ------------------------------------------------------------------------------ conv-side building blocks

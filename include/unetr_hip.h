@@ -106,6 +106,8 @@ int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumula
 int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                         void* y_bf16 /* optional bf16 copy of y for unetr_gemm_bf16, or NULL */,
                         float* mean, float* rstd, int M, int H, float eps, void* stream);
+/* dgamma == dbeta == NULL: only dx is produced and ws keeps the per-row-block partial sums, laid out
+ * [ceil(M/4)][2][H] (dgamma row, dbeta row), for a later unetr_colsum_grouped over all LayerNorms of the step. */
 int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                         const float* rstd, float* dx, void* dx_bf16 /* optional bf16 copy of dx, or NULL */,
                         const float* dres /* optional, added to dx */, float* dgamma, float* dbeta,
