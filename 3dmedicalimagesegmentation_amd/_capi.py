@@ -85,6 +85,7 @@ _SIGNATURES = {
     "unetr_ranking_loss_fwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, c_size_t, P],
     "unetr_ranking_loss_bwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],
+    "unetr_adamw_reduced": [P, P, c_int, c_float, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_ranking_workspace_floats")

@@ -479,15 +479,23 @@ outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, fl
 }
 
 // -------------------------------------------------------------------------------------------- AdamW
+// GB16: gradients come as bf16 (the data-parallel communication buffer after the all-reduce); gscale = 1 / world size
+template <bool GB16>
 __global__ void __launch_bounds__(256)
-adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4,
-             long n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ step_dev,
+adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale, float* __restrict__ m, float* __restrict__ v,
+             long n4, long n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ step_dev,
              uint16_t* __restrict__ shadow) {
     const float step = *step_dev;
     const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    auto grad1 = [&](long i) -> float {
+        if (GB16) { uint32_t u = (uint32_t)((const uint16_t*)gsrc)[i] << 16; return __builtin_bit_cast(float, u) * gscale; }
+        return ((const float*)gsrc)[i] * gscale;
+    };
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i], gv;
+        if (GB16) gv = __builtin_convertvector(((const bf16x4*)gsrc)[i], f32x4) * gscale;
+        else gv = ((const f32x4*)gsrc)[i] * gscale;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float pe = pv[e] * (1.f - lr * wd);
@@ -503,9 +511,10 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
         long i = n4 * 4 + threadIdx.x;
+        const float g = grad1(i);
         float pe = p[i] * (1.f - lr * wd);
-        float me = b1 * m[i] + (1.f - b1) * g[i];
-        float ve = b2 * v[i] + (1.f - b2) * g[i] * g[i];
+        float me = b1 * m[i] + (1.f - b1) * g;
+        float ve = b2 * v[i] + (1.f - b2) * g * g;
         p[i] = pe - step_size * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
         m[i] = me; v[i] = ve;
         if (shadow) { __bf16 h = (__bf16)p[i]; shadow[i] = __builtin_bit_cast(uint16_t, h); }
@@ -689,14 +698,31 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx,
     return UNETR_OK;
 }
 
+static int adamw_launch(float* p, const void* g, int g_bf16, float gscale, float* m, float* v, long n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, const float* step_dev, void* shadow_bf16, void* stream) {
+    if (!p || !g || !m || !v || !step_dev || n <= 0 || (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)) return UNETR_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) return UNETR_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(g) & (g_bf16 ? 7 : 15)) return UNETR_ERR_ARG;
+    long n4 = n >> 2;
+    dim3 grid(grid_for(std::max<long>(n4, 1), 256, 4096));
+    if (g_bf16)
+        hipLaunchKernelGGL(adamw_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g, gscale, m, v, n4, n, lr, beta1, beta2, eps,
+                           weight_decay, step_dev, (uint16_t*)shadow_bf16);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p, g, gscale, m, v, n4, n, lr, beta1, beta2, eps,
+                           weight_decay, step_dev, (uint16_t*)shadow_bf16);
+    return unetr_check_launch();
+}
+
 extern "C" int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, const float* step_dev, void* shadow_bf16, void* stream) {
-    if (!p || !g || !m || !v || !step_dev || n <= 0 || (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)) return UNETR_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
-        return UNETR_ERR_ARG;
-    long n4 = n >> 2;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(std::max<long>(n4, 1), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, step_dev,
-                       (uint16_t*)shadow_bf16);
-    return unetr_check_launch();
+    return adamw_launch(p, g, 0, 1.0f, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_bf16, stream);
+}
+
+// the data-parallel form: gradients are read from the all-reduced communication buffer (fp32 or bf16) and averaged
+// (gscale = 1 / world size) inside the update, so no copy back into the gradient arena is needed
+extern "C" int unetr_adamw_reduced(float* p, const void* g, int g_is_bf16, float gscale, float* m, float* v, long n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
+                                   void* shadow_bf16, void* stream) {
+    return adamw_launch(p, g, g_is_bf16, gscale, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_bf16, stream);
 }

@@ -76,35 +76,76 @@ class AdamW(torch.optim.Optimizer):
                      Fn.shadow_ptr_for_update(p), stream)
         return loss
 
-    def _flat_step(self, group, params, pattern, dev, stream):
-        """One launch per contiguous run of parameters with arena gradients and equal step counts."""
-        flat = self._flat
-        fg, fp, offs = flat["grad"], flat["param"], flat["offsets"]
-        gbase, esz = fg.data_ptr(), 4
-        for p, o, has in zip(params, offs, pattern):
-            if has and p.grad.data_ptr() != gbase + o * esz:
-                return False          # some gradient is not in the arena (e.g. accumulated): per-tensor path
-        if self._flat_state is None:
-            self._flat_state = (torch.zeros_like(fp), torch.zeros_like(fp))
-        m, v = self._flat_state
-        shadow = flat.get("shadow")            # bf16 copy of the arena read by the bf16-storage GEMMs, refreshed in the same kernel
-        sbase = shadow.data_ptr() if shadow is not None else None
-        steps = self._advance_steps(0, params, pattern, dev)
-        b1, b2 = group["betas"]
-        i, n = 0, len(params)
+    def _flat_runs(self, params, pattern, max_elems=None):
+        """Contiguous arena ranges (i, j, lo, hi) of parameters that step together: consecutive parameters with a
+        gradient and equal step counts, optionally cut at parameter boundaries into pieces of <= max_elems."""
+        offs = self._flat["offsets"]
+        runs, i, n = [], 0, len(params)
         while i < n:
             if not pattern[i]:
                 i += 1
                 continue
             j = i
-            while j + 1 < n and pattern[j + 1] and self._host_steps[j + 1] == self._host_steps[i]:
+            while (j + 1 < n and pattern[j + 1] and self._host_steps[j + 1] == self._host_steps[i]
+                   and (max_elems is None or offs[j + 1] + params[j + 1].numel() - offs[i] <= max_elems)):
                 j += 1
-            lo = offs[i]
-            hi = offs[j] + (params[j].numel() + 3) // 4 * 4
-            call("unetr_adamw", fp.data_ptr() + lo * esz, gbase + lo * esz, m.data_ptr() + lo * esz, v.data_ptr() + lo * esz, hi - lo,
-                 group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i,
-                 sbase + lo * 2 if sbase is not None else None, stream)
-            for k in range(i, j + 1):
-                self._host_steps[k] += 1
+            runs.append((i, j, offs[i], offs[j] + (params[j].numel() + 3) // 4 * 4))
             i = j + 1
+        return runs
+
+    def _launch_run(self, group, run, steps, gptr, g_bf16, gscale, stream):
+        flat = self._flat
+        i, j, lo, hi = run
+        m, v = self._flat_state
+        b1, b2 = group["betas"]
+        shadow = flat.get("shadow")            # bf16 copy of the arena read by the bf16-storage GEMMs, refreshed in the same kernel
+        sptr = shadow.data_ptr() + lo * 2 if shadow is not None else None
+        call("unetr_adamw_reduced", flat["param"].data_ptr() + lo * 4, gptr + lo * (2 if g_bf16 else 4), int(g_bf16), gscale,
+             m.data_ptr() + lo * 4, v.data_ptr() + lo * 4, hi - lo, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+             steps.data_ptr() + 4 * i, sptr, stream)
+        for k in range(i, j + 1):
+            self._host_steps[k] += 1
+
+    def _flat_step(self, group, params, pattern, dev, stream):
+        """One launch per contiguous run of parameters with arena gradients and equal step counts."""
+        flat = self._flat
+        gbase = flat["grad"].data_ptr()
+        for p, o, has in zip(params, flat["offsets"], pattern):
+            if has and p.grad.data_ptr() != gbase + o * 4:
+                return False          # some gradient is not in the arena (e.g. accumulated): per-tensor path
+        if self._flat_state is None:
+            self._flat_state = (torch.zeros_like(flat["param"]), torch.zeros_like(flat["param"]))
+        steps = self._advance_steps(0, params, pattern, dev)
+        for run in self._flat_runs(params, pattern):
+            self._launch_run(group, run, steps, gbase, False, 1.0, stream)
         return True
+
+    # ---- data-parallel arena update: all-reduce pieces overlap the optimizer kernels of the pieces before them ----
+    def plan_reduced(self, max_elems):
+        """Freeze the current gradient pattern (which parameters have .grad) into arena ranges of <= max_elems.  The
+        plan is reused every step by ``step_reduced`` -- under hipGraph replay ``.grad`` attributes do not change."""
+        if self._flat is None or len(self.param_groups) != 1:
+            raise RuntimeError("plan_reduced needs AdamW(..., flat=model.use_flat_buffers())")
+        params = self.param_groups[0]["params"]
+        pattern = tuple(p.grad is not None for p in params)
+        return dict(pattern=pattern, runs=self._flat_runs(params, pattern, max_elems))
+
+    @torch.no_grad()
+    def step_reduced(self, plan, gsrc, gscale, before_run=None):
+        """AdamW over the planned ranges with gradients read from ``gsrc`` (a flat fp32 or bf16 tensor laid out like
+        the arena: the all-reduced communication buffer) times ``gscale``.  ``before_run(k, lo, hi)`` runs before range
+        k's kernel is launched -- the caller makes the current stream wait for that range's all-reduce there."""
+        group = self.param_groups[0]
+        params = group["params"]
+        dev = self._flat["param"].device
+        stream = torch.cuda.current_stream().cuda_stream
+        if self._flat_state is None:
+            self._flat_state = (torch.zeros_like(self._flat["param"]), torch.zeros_like(self._flat["param"]))
+        steps = self._advance_steps(0, params, plan["pattern"], dev)
+        g_bf16 = gsrc.dtype == torch.bfloat16
+        if not g_bf16 and gsrc.dtype != torch.float32:
+            raise RuntimeError("gradient source must be fp32 or bf16")
+        for k, run in enumerate(plan["runs"]):
+            if before_run is not None:
+                before_run(k, run[2], run[3])
+            self._launch_run(group, run, steps, gsrc.data_ptr(), g_bf16, gscale, stream)

@@ -77,9 +77,10 @@ def main():
     x, y = x.to(dev), y.to(dev)
 
     # ---- data parallel (N > 1): weak scaling, batch `--batch` per rank, gradients averaged over ranks ----------
-    # Arena mode: graph A = forward + loss + backward (+ one cast of the gradient arena into the communication
-    # buffer), ONE eager RCCL all-reduce over the whole buffer, graph B = copy back / average + AdamW.  No
-    # collective is captured inside a hipGraph, so the path does not depend on RCCL's capture support.
+    # Arena mode: hipGraph = forward + loss + backward (+ one cast of the gradient arena into the bf16 communication
+    # buffer); then the buffer is all-reduced in <= 6 pieces on a side stream (eager RCCL calls) while AdamW runs on each
+    # piece as soon as it is reduced, reading the summed gradients straight from the buffer.  No collective is captured
+    # inside a hipGraph, so the path does not depend on RCCL's capture support.
     # --force-dist exercises exactly this path with a single rank (what the 1-GPU box can test).
     ddp_on = dist_on or args.force_dist
     comm_dtype = torch.bfloat16 if (args.precision == "bf16" and not args.fp32_comm) else torch.float32
@@ -96,34 +97,59 @@ def main():
                 dist.broadcast(p.data, src=0)
             pkg.functional.invalidate_weight_shadows()
 
+    comm_stream = torch.cuda.Stream() if ddp_on else None
+    plan = {"p": None}
+    in_place = comm_buf is not None and comm_dtype == torch.float32     # fp32 comm: all-reduce the gradient arena itself
+
     def fwd_bwd():
         logit_map = model(x)
         loss = crit(logit_map, y)
         loss.backward()
-        if comm_buf is not None:
-            comm_buf.copy_(flat["grad"])        # fp32 -> communication dtype (bf16 in bf16 mode)
+        if comm_buf is not None and not in_place:
+            comm_buf.copy_(flat["grad"])        # fp32 -> bf16 communication buffer
         return loss
 
+    def comm_update():
+        """Arena data-parallel step: the gradient buffer is all-reduced in <= 6 pieces on a side stream while the main
+        stream runs AdamW on each piece as soon as its all-reduce has finished (the optimizer kernel reads the summed
+        gradients from the communication buffer and averages on the fly: no copy back, no separate scaling pass)."""
+        buf = flat["grad"] if in_place else comm_buf
+        if plan["p"] is None:
+            plan["p"] = opt.plan_reduced(max_elems=(flat["total"] + 5) // 6)
+        runs = plan["p"]["runs"]
+        main = torch.cuda.current_stream()
+        comm_stream.wait_stream(main)
+        events = []
+        with torch.cuda.stream(comm_stream):
+            for (_, _, lo, hi) in runs:
+                if dist_on:
+                    dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM)
+                ev = torch.cuda.Event()
+                ev.record(comm_stream)
+                events.append(ev)
+        opt.step_reduced(plan["p"], buf, 1.0 / world, before_run=lambda k, lo, hi: main.wait_event(events[k]))
+
     def comm():
-        if comm_buf is not None and dist_on:
-            dist.all_reduce(comm_buf, op=dist.ReduceOp.SUM)
-        elif reducer is not None:
+        if reducer is not None:
             reducer.finish()
 
     def update():
-        if comm_buf is not None:
-            flat["grad"].copy_(comm_buf)
-            if world > 1:
-                flat["grad"].mul_(1.0 / world)
         opt.step()
         opt.zero_grad(set_to_none=True)
 
     def step():
         loss = fwd_bwd()
-        comm()
-        update()
+        if comm_buf is not None:
+            comm_update()
+            if graph is None:                     # eager mode re-plans every step from fresh .grad attributes
+                plan["p"] = None
+                opt.zero_grad(set_to_none=True)
+        else:
+            comm()
+            update()
         return loss
 
+    graph = None
     use_graph = not args.no_graph and reducer is None
     # eager warm-up (allocates workspaces / optimizer state / RCCL communicators; needed before graph capture)
     side = torch.cuda.Stream()
@@ -134,7 +160,6 @@ def main():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     log(f"eager warm-up done, loss {float(loss.item()):.5f}")
-    graph = graph_b = None
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
@@ -144,24 +169,21 @@ def main():
             else:
                 with torch.cuda.graph(graph):
                     loss = fwd_bwd()
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, pool=graph.pool()):
-                    update()
+                plan["p"] = None                  # planned from the .grad attributes the captured backward just set
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
-            graph = graph_b = None
+            graph = None
             torch.cuda.synchronize()
 
     def run_step():
         if graph is None:
             step()
-        elif graph_b is None:
+        elif comm_buf is None:
             graph.replay()
         else:
             graph.replay()
-            comm()
-            graph_b.replay()
+            comm_update()
 
     log("graph captured" if graph is not None else "eager mode")
     for _ in range(args.warmup):
@@ -192,7 +214,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "UNETR(img=96^3,patch=16,hidden=768,layers=12,heads=12,classes=4) fwd+DiceCE+bwd+AdamW, "
                                f"batch {args.batch}/GPU, configs[1]", "global_batch": world * args.batch,
-                   "launch": ("hipGraph" if graph_b is None else "hipGraph(fwd+bwd) + eager all-reduce + hipGraph(AdamW)") if graph is not None else "eager",
+                   "launch": ("hipGraph" if comm_buf is None else "hipGraph(fwd+bwd) + chunked all-reduce overlapped with AdamW") if graph is not None else "eager",
                    "grad_comm_dtype": (str(comm_dtype).replace("torch.", "") if ddp_on else None), "final_loss": float(loss.item())},
     }
 

@@ -202,6 +202,13 @@ int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, 
                 float eps, float weight_decay, const float* step_dev,
                 void* shadow_bf16 /* optional: bf16 copy of the updated p (GEMM weight shadow), or NULL */, void* stream);
 
+/* data-parallel form of the same update (replaces the DistributedDataParallel gradient averaging that the reference's
+ * single-GPU script does not need, BASELINE.json configs[2]): g is the all-reduced SUM in the communication buffer
+ * (fp32, or bf16 when g_is_bf16), gscale = 1 / world size is applied on the fly. */
+int unetr_adamw_reduced(float* p, const void* g, int g_is_bf16, float gscale, float* m, float* v, long n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
+                        void* shadow_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,6 +187,46 @@ def test_flat_buffers_match_per_tensor_path(pkg, dev):
     pkg.functional.clear_grad_sinks()
 
 
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_data_parallel_arena_update(pkg, dev, comm_dtype):
+    """The N>1 update of bench.py on one device: AdamW.step_reduced reads the 'all-reduced' gradient SUM of a simulated
+    2-rank job (both ranks hold the same gradient) from the communication buffer in <= 3 planned pieces and averages on
+    the fly.  It must match AdamW.step() fed the (communication-dtype rounded) gradients bit for bit, keep the unused
+    cls_token untouched, and keep the bf16 weight shadow in step with the fp32 master."""
+    from oracle.unetr_oracle import synthetic_volume
+    Fn = pkg.functional
+    torch.manual_seed(4)
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    x, y = synthetic_volume(1, 1, 32, 2, seed=6)
+    x, y = x.to(dev), y.to(dev)
+    results = []
+    for mode in ("plain", "reduced"):
+        torch.manual_seed(4)
+        m = pkg.UNETRLogits(**C1).to(dev)
+        flat = m.use_flat_buffers()
+        opt = pkg.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-2, flat=flat)
+        for it in range(2):
+            crit(m(x), y).backward()
+            g = flat["grad"]
+            if mode == "plain":
+                g.copy_(g.to(comm_dtype).float())               # what the other path sees after the cast
+                opt.step()
+            else:
+                buf = (g.to(comm_dtype) * 2)                    # sum over two identical ranks (exact in both dtypes)
+                plan = opt.plan_reduced(max_elems=(flat["total"] + 2) // 3)
+                assert len(plan["runs"]) >= 3
+                seen = []
+                opt.step_reduced(plan, buf, 0.5, before_run=lambda k, lo, hi: seen.append((k, lo, hi)))
+                assert [k for k, _, _ in seen] == list(range(len(plan["runs"])))
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        results.append((flat["param"].clone(), flat["shadow"].clone()))
+        assert torch.equal(flat["shadow"].float(), flat["param"].bfloat16().float())
+        Fn.clear_grad_sinks()
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
+
+
 C2 = dict(in_channels=1, out_channels=4, img_size=(96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072,
           num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True)
 
