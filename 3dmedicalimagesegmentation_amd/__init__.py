@@ -7,6 +7,8 @@ The directory name starts with a digit, so import it with
 from .unetr import UNETR, UNETRLogits, default_precision  # noqa: F401
 from .losses import DiceCELoss, ranking_loss  # noqa: F401
 from .optim import AdamW  # noqa: F401
-from . import _capi, ddp, functional  # noqa: F401
+from .inference import DiceMetric, sliding_window_inference  # noqa: F401
+from . import _capi, ddp, functional, inference  # noqa: F401
 
-__all__ = ["UNETR", "UNETRLogits", "DiceCELoss", "ranking_loss", "AdamW", "default_precision"]
+__all__ = ["UNETR", "UNETRLogits", "DiceCELoss", "ranking_loss", "AdamW", "default_precision", "sliding_window_inference",
+           "DiceMetric"]

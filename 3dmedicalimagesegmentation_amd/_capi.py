@@ -80,8 +80,11 @@ _SIGNATURES = {
     "unetr_copy_rows": [P, c_long, P, c_long, c_long, c_int, c_int, P],
     "unetr_outconv_fwd": [P, c_long, P, P, P, c_int, c_long, c_int, c_int, P],
     "unetr_outconv_bwd": [P, P, c_long, P, P, c_long, P, P, c_int, c_long, c_int, c_int, P, c_size_t, P],
-    "unetr_dicece_fwd": [P, P, c_int, c_int, c_long, c_float, c_float, P, P, P, c_size_t, P],
-    "unetr_dicece_bwd": [P, P, P, P, P, c_int, c_int, c_long, P],
+    "unetr_dicece_fwd": [P, P, c_int, c_int, c_long, c_int, c_float, c_float, P, P, P, c_size_t, P],
+    "unetr_dicece_bwd": [P, P, P, P, P, c_int, c_int, c_long, c_int, P],
+    "unetr_sw_accumulate": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_sw_finalize": [P, P, c_int, c_int, c_long, P],
+    "unetr_dice_counts": [P, P, c_int, c_int, c_long, c_int, P, P, c_size_t, P],
     "unetr_ranking_loss_fwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, c_size_t, P],
     "unetr_ranking_loss_bwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],

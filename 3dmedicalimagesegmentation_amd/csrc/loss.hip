@@ -6,6 +6,11 @@
 //   per (b,c): I = sum p*y, G = sum y, Pp = sum p over the volume
 //   dice = mean_{b,c} [1 - (2I + nr) / (G + Pp + dr)];  ce = mean_{b,v} -log p[b, label, v];  loss = dice + ce
 //
+// SIG mode = DiceCELoss(to_onehot_y=False, sigmoid=True) on a multi-label float target [B,C,*spatial]
+// (unetr_segmentation_3d.py:477-482, the 4-channel MR task): the Dice term uses p = sigmoid(logits) against the target
+// as given; the CE term is MONAI 0.6.0's DiceCELoss.ce with equal channel counts -- softmax cross entropy of the raw
+// logits against argmax_c(target) (first maximal channel, torch.argmax's rule).
+//
 // HBM-bound: one pass over logits+label for the forward (fixed-order partial buffers -> reproducible), one
 // pass for the backward that recomputes the softmax and writes dlogits.
 #include <algorithm>
@@ -17,7 +22,7 @@ namespace {
 constexpr int MAXC = 16;
 constexpr int LVPB = 4096;  // voxels per block
 
-template <int C>
+template <int C, bool SIG>
 __global__ void __launch_bounds__(256)
 dicece_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ label, long V, float* __restrict__ part) {
     // part: [B][nchunk][3*C + 1]  (I[c], Pp[c], G[c], ce_sum)
@@ -35,12 +40,29 @@ dicece_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ la
 #pragma unroll
         for (int c = 0; c < C; ++c) { z[c] = expf(z[c] - mx); se += z[c]; }
         const float inv = 1.f / se;
-        const int lab = (int)label[(long)b * V + v];
+        if constexpr (SIG) {
+            float t[C], tmax = -3.0e38f;
+            int lab = 0;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            float p = z[c] * inv;
-            accP[c] += p;
-            if (c == lab) { accI[c] += p; accG[c] += 1.f; ce -= logf(p); }
+            for (int c = 0; c < C; ++c) {
+                t[c] = label[((long)b * C + c) * V + v];
+                if (t[c] > tmax) { tmax = t[c]; lab = c; }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float x = logits[((long)b * C + c) * V + v];
+                const float sg = 1.f / (1.f + expf(-x));
+                accP[c] += sg; accI[c] += sg * t[c]; accG[c] += t[c];
+                if (c == lab) ce -= logf(z[c] * inv);
+            }
+        } else {
+            const int lab = (int)label[(long)b * V + v];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float p = z[c] * inv;
+                accP[c] += p;
+                if (c == lab) { accI[c] += p; accG[c] += 1.f; ce -= logf(p); }
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -90,7 +112,7 @@ __global__ void dicece_final_kernel(const float* __restrict__ part, int B, int C
     }
 }
 
-template <int C>
+template <int C, bool SIG>
 __global__ void __launch_bounds__(256)
 dicece_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ label, const float* __restrict__ coef,
                   const float* __restrict__ dloss, float* __restrict__ dlogits, int B, long V) {
@@ -106,6 +128,24 @@ dicece_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ la
 #pragma unroll
         for (int c = 0; c < C; ++c) { z[c] = expf(z[c] - mx); se += z[c]; }
         const float inv = 1.f / se;
+        if constexpr (SIG) {
+            float t[C], tmax = -3.0e38f;
+            int lab = 0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                t[c] = label[((long)b * C + c) * V + v];
+                if (t[c] > tmax) { tmax = t[c]; lab = c; }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float x = logits[((long)b * C + c) * V + v];
+                const float sg = 1.f / (1.f + expf(-x));
+                const float* cf = coef + ((long)b * C + c) * 2;
+                const float dz = (cf[0] * t[c] + cf[1]) * sg * (1.f - sg) + (z[c] * inv - (c == lab ? 1.f : 0.f)) * ce_scale;
+                dlogits[((long)b * C + c) * V + v] = up * dz;
+            }
+            continue;
+        }
         const int lab = (int)label[(long)b * V + v];
         float gp[C], dot = 0.f;
 #pragma unroll
@@ -134,27 +174,30 @@ dicece_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ la
         default: return UNETR_ERR_UNSUPPORTED;                                                                \
     }
 
-extern "C" int unetr_dicece_fwd(const float* logits, const float* label, int B, int C, long V, float smooth_nr,
-                                float smooth_dr, float* out, float* coef, float* ws, size_t ws_bytes, void* stream) {
+extern "C" int unetr_dicece_fwd(const float* logits, const float* label, int B, int C, long V, int sigmoid_multilabel,
+                                float smooth_nr, float smooth_dr, float* out, float* coef, float* ws, size_t ws_bytes,
+                                void* stream) {
     if (!logits || !label || !out || !coef || B <= 0 || V <= 0 || B > 65535) return UNETR_ERR_ARG;
     if (C < 1 || C > MAXC) return UNETR_ERR_UNSUPPORTED;
     int nchunk = cdiv(V, LVPB);
     if (!ws || (size_t)B * nchunk * (3 * C + 1) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-#define CALL_F(CC) hipLaunchKernelGGL((dicece_fwd_kernel<CC>), dim3(nchunk, B), dim3(256), 0, st, logits, label, V, ws)
-    DICE_DISPATCH(C, CALL_F)
+#define CALL_F(CC) hipLaunchKernelGGL((dicece_fwd_kernel<CC, false>), dim3(nchunk, B), dim3(256), 0, st, logits, label, V, ws)
+#define CALL_FS(CC) hipLaunchKernelGGL((dicece_fwd_kernel<CC, true>), dim3(nchunk, B), dim3(256), 0, st, logits, label, V, ws)
+    if (sigmoid_multilabel) { DICE_DISPATCH(C, CALL_FS) } else { DICE_DISPATCH(C, CALL_F) }
     hipLaunchKernelGGL(dicece_final_kernel, dim3(1), dim3(256), 0, st, ws, B, C, nchunk, V, smooth_nr, smooth_dr, out, coef);
     return unetr_check_launch();
 }
 
 extern "C" int unetr_dicece_bwd(const float* logits, const float* label, const float* coef, const float* dloss,
-                                float* dlogits, int B, int C, long V, void* stream) {
+                                float* dlogits, int B, int C, long V, int sigmoid_multilabel, void* stream) {
     if (!logits || !label || !coef || !dlogits || B <= 0 || V <= 0) return UNETR_ERR_ARG;
     if (C < 1 || C > MAXC) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     long total = (long)B * V;
     int blocks = (int)std::max<long>(1, std::min<long>((total + 255) / 256, 8192));
-#define CALL_B(CC) hipLaunchKernelGGL((dicece_bwd_kernel<CC>), dim3(blocks), dim3(256), 0, st, logits, label, coef, dloss, dlogits, B, V)
-    DICE_DISPATCH(C, CALL_B)
+#define CALL_B(CC) hipLaunchKernelGGL((dicece_bwd_kernel<CC, false>), dim3(blocks), dim3(256), 0, st, logits, label, coef, dloss, dlogits, B, V)
+#define CALL_BS(CC) hipLaunchKernelGGL((dicece_bwd_kernel<CC, true>), dim3(blocks), dim3(256), 0, st, logits, label, coef, dloss, dlogits, B, V)
+    if (sigmoid_multilabel) { DICE_DISPATCH(C, CALL_BS) } else { DICE_DISPATCH(C, CALL_B) }
     return unetr_check_launch();
 }

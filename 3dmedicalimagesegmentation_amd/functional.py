@@ -846,32 +846,36 @@ def to_channels_last(x_in):
 
 
 class DiceCEFn(torch.autograd.Function):
-    """DiceCELoss(to_onehot_y=True, softmax=True) -> (loss, dice, ce) as a 3-vector (unetr_segmentation_3d.py:404)."""
+    """DiceCELoss -> (loss, dice, ce) as a 3-vector.  multilabel=False: DiceCELoss(to_onehot_y=True, softmax=True)
+    (unetr_segmentation_3d.py:404); multilabel=True: DiceCELoss(to_onehot_y=False, sigmoid=True) (:477-482)."""
 
     @staticmethod
-    def forward(ctx, logits, label, smooth_nr, smooth_dr):
+    def forward(ctx, logits, label, smooth_nr, smooth_dr, multilabel=False):
         _require_gpu(logits)
         logits = logits.contiguous()
         label = label.contiguous().to(torch.float32)
         B, C = logits.shape[0], logits.shape[1]
         V = logits.numel() // (B * C)
-        if label.numel() != B * V:
+        if multilabel and label.numel() != B * C * V:
+            raise ValueError(f"multi-label target must be [B,C,*spatial] like the logits, got {tuple(label.shape)}")
+        if not multilabel and label.numel() != B * V:
             raise ValueError(f"label must be [B,1,*spatial] class indices, got {tuple(label.shape)}")
         out = torch.empty(3, dtype=torch.float32, device=logits.device)
         coef = torch.empty(B * C * 2, dtype=torch.float32, device=logits.device)
         ws = workspace(logits.device)
-        call("unetr_dicece_fwd", logits.data_ptr(), label.data_ptr(), B, C, V, smooth_nr, smooth_dr, out.data_ptr(), coef.data_ptr(),
-             ws.data_ptr(), ws.numel() * 4, _stream())
+        call("unetr_dicece_fwd", logits.data_ptr(), label.data_ptr(), B, C, V, int(multilabel), smooth_nr, smooth_dr, out.data_ptr(),
+             coef.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
         ctx.save_for_backward(logits, label, coef)
-        ctx.meta = (B, C, V)
+        ctx.meta = (B, C, V, int(multilabel))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         logits, label, coef = ctx.saved_tensors
-        B, C, V = ctx.meta
+        B, C, V, ml = ctx.meta
         # only out[0] (= dice + ce) is differentiable; out[1], out[2] are reporting copies
         dloss = dout[0:1].contiguous()
         dlogits = torch.empty_like(logits)
-        call("unetr_dicece_bwd", logits.data_ptr(), label.data_ptr(), coef.data_ptr(), dloss.data_ptr(), dlogits.data_ptr(), B, C, V, _stream())
-        return dlogits, None, None, None
+        call("unetr_dicece_bwd", logits.data_ptr(), label.data_ptr(), coef.data_ptr(), dloss.data_ptr(), dlogits.data_ptr(), B, C, V,
+             ml, _stream())
+        return dlogits, None, None, None, None

@@ -1,6 +1,7 @@
-"""DiceCELoss behind MONAI's interface for the configuration the reference uses on the hot path
-(unetr_segmentation_3d.py:404: ``DiceCELoss(to_onehot_y=True, softmax=True)``), computed by the HIP kernels
-in csrc/loss.hip (one streaming pass forward, one backward).  No CPU fallback."""
+"""DiceCELoss behind MONAI's interface for the two configurations the reference instantiates
+(unetr_segmentation_3d.py:404 ``DiceCELoss(to_onehot_y=True, softmax=True)`` for the single-channel CT tasks and
+:477-482 ``DiceCELoss(to_onehot_y=False, sigmoid=True)`` for the 4-channel multi-label MR task), computed by the HIP
+kernels in csrc/loss.hip (one streaming pass forward, one backward).  No CPU fallback."""
 import torch
 import torch.nn as nn
 
@@ -15,25 +16,28 @@ class DiceCELoss(nn.Module):
         super().__init__()
         bad = []
         if not include_background: bad.append("include_background=False")
-        if not to_onehot_y: bad.append("to_onehot_y=False")
-        if sigmoid: bad.append("sigmoid=True")
-        if not softmax: bad.append("softmax=False")
+        if (to_onehot_y, softmax, sigmoid) not in ((True, True, False), (False, False, True)):
+            bad.append(f"to_onehot_y={to_onehot_y}, softmax={softmax}, sigmoid={sigmoid}")
         if squared_pred: bad.append("squared_pred=True")
         if jaccard: bad.append("jaccard=True")
         if reduction != "mean": bad.append(f"reduction={reduction!r}")
         if batch: bad.append("batch=True")
         if lambda_dice != 1.0 or lambda_ce != 1.0: bad.append("lambda_dice/lambda_ce != 1")
         if bad:
-            raise NotImplementedError("HIP DiceCELoss implements DiceCELoss(to_onehot_y=True, softmax=True) with MONAI "
-                                      "defaults; got " + ", ".join(bad))
+            raise NotImplementedError("HIP DiceCELoss implements DiceCELoss(to_onehot_y=True, softmax=True) and "
+                                      "DiceCELoss(to_onehot_y=False, sigmoid=True) with MONAI defaults; got " + ", ".join(bad))
+        self.multilabel = bool(sigmoid)
         self.smooth_nr = float(smooth_nr)
         self.smooth_dr = float(smooth_dr)
 
     def terms(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """3-vector (loss, dice term, ce term); only element 0 carries gradient."""
-        if target.shape[1] != 1:
+        if self.multilabel:
+            if target.shape != input.shape:
+                raise ValueError("sigmoid=True needs a multi-label target shaped like the logits [B,C,*spatial]")
+        elif target.shape[1] != 1:
             raise ValueError("target must be [B,1,*spatial] class indices (to_onehot_y=True)")
-        return Fn.DiceCEFn.apply(input, target, self.smooth_nr, self.smooth_dr)
+        return Fn.DiceCEFn.apply(input, target, self.smooth_nr, self.smooth_dr, self.multilabel)
 
     def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         return self.terms(input, target)[0]

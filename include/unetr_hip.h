@@ -178,13 +178,30 @@ int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx, const floa
                       float* dw, float* dbias, int B, long V, int Cin, int Cout,
                       float* ws, size_t ws_bytes, void* stream);
 
-/* ---- DiceCELoss(to_onehot_y=True, softmax=True) (unetr_segmentation_3d.py:404) ----------------------
- * logits [B,C,V] NCDHW, label [B,V] float-valued class ids.  out[0]=loss, out[1]=dice term, out[2]=ce term.
+/* ---- DiceCELoss (unetr_segmentation_3d.py:404 and :477-482) -------------------------------------------
+ * sigmoid_multilabel = 0: DiceCELoss(to_onehot_y=True, softmax=True); label [B,V] float-valued class ids.
+ * sigmoid_multilabel = 1: DiceCELoss(to_onehot_y=False, sigmoid=True); label [B,C,V] float multi-label mask; the
+ *   CE term is softmax cross entropy against argmax_c(label) (MONAI 0.6.0 DiceCELoss.ce with equal channel counts).
+ * logits [B,C,V] NCDHW.  out[0]=loss, out[1]=dice term, out[2]=ce term.
  * coef: [B*C*2] per-(b,c) Dice gradient coefficients kept for backward. */
-int unetr_dicece_fwd(const float* logits, const float* label, int B, int C, long V, float smooth_nr,
-                     float smooth_dr, float* out, float* coef, float* ws, size_t ws_bytes, void* stream);
+int unetr_dicece_fwd(const float* logits, const float* label, int B, int C, long V, int sigmoid_multilabel,
+                     float smooth_nr, float smooth_dr, float* out, float* coef, float* ws, size_t ws_bytes, void* stream);
 int unetr_dicece_bwd(const float* logits, const float* label, const float* coef, const float* dloss,
-                     float* dlogits, int B, int C, long V, void* stream);
+                     float* dlogits, int B, int C, long V, int sigmoid_multilabel, void* stream);
+
+/* ---- validation side (unetr_segmentation_3d.py:103-132) -------------------------------------------------
+ * unetr_sw_accumulate / unetr_sw_finalize: the blending step of monai.inferers.sliding_window_inference (MONAI 0.6.0,
+ * called at :110): out[c, z0+z, y0+y, x0+x] += w * seg[c,z,y,x], count[...] += w for ONE window of ONE volume
+ * (out / count point at that volume: [C,D,H,W] and [D,H,W]; importance = NULL means w = 1, mode="constant"), then
+ * out[b,c,v] /= count[b,v].  One launch per window, in MONAI's window order.
+ * unetr_dice_counts: the sums behind monai.metrics.DiceMetric (:485-486): counts[b][c] = (sum pred*y, sum pred, sum y).
+ * from_logits = 1: pred = one_hot(argmax_c logits[B,C,V]) and y = class ids [B,V] (AsDiscrete(argmax, to_onehot) at
+ * :405-406 fused in); from_logits = 0: pred and y are [B,C,V] (already discrete) tensors. */
+int unetr_sw_accumulate(const float* seg, const float* importance, float* out, float* count, int C,
+                        int rz, int ry, int rx, int D, int H, int W, int z0, int y0, int x0, void* stream);
+int unetr_sw_finalize(float* out, const float* count, int B, int C, long V, void* stream);
+int unetr_dice_counts(const float* pred, const float* y, int B, int C, long V, int from_logits, double* counts,
+                      float* ws, size_t ws_bytes, void* stream);
 
 /* ---- ranking pre-training losses (unetr_ranking_pretraining_3d.py:59-133 triplet construction, :202-217 BTLoss,
  * :219-236 ContrastiveLoss), fused: feat is the NCDHW feature map [4, C, S1, S2, S3] (2 volumes x 2 transforms: enc4 in

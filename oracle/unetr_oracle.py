@@ -474,6 +474,111 @@ def oracle_contrastive_loss(reference, similar, dissimilar, temperature):
 # ----------------------------------------------------------------------------------------------
 # synthetic CT-like data shared by tests and bench so both sides see identical inputs
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------------------
+# Validation side (unetr_segmentation_3d.py:103-132).  MONAI 0.6.0 is not installed: these restate
+# monai.inferers.sliding_window_inference (mode="constant", the reference's default), monai.data.utils.dense_patch_slices,
+# AsDiscrete(argmax/to_onehot) and monai.metrics.DiceMetric + do_metric_reduction from the published 0.6.0 sources.
+# PARITY UNPINNED (no MONAI here to check against); the reference's call sites fix the arguments.
+def oracle_sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.25):
+    import math
+    num_spatial_dims = inputs.dim() - 2
+    batch_size = inputs.shape[0]
+    image_size_ = list(inputs.shape[2:])
+    roi_size = tuple(roi_size)
+    image_size = tuple(max(image_size_[i], roi_size[i]) for i in range(num_spatial_dims))
+    pad_size = []
+    for k in range(inputs.dim() - 1, 1, -1):
+        diff = max(roi_size[k - 2] - inputs.shape[k], 0)
+        half = diff // 2
+        pad_size.extend([half, diff - half])
+    inputs = F.pad(inputs, pad=pad_size, mode="constant", value=0.0)
+    scan_interval = []
+    for i in range(num_spatial_dims):
+        if roi_size[i] == image_size[i]:
+            scan_interval.append(int(roi_size[i]))
+        else:
+            interval = int(roi_size[i] * (1 - overlap))
+            scan_interval.append(interval if interval > 0 else 1)
+    # dense_patch_slices
+    scan_num = []
+    for i in range(num_spatial_dims):
+        num = int(math.ceil(float(image_size[i]) / scan_interval[i]))
+        scan_dim = next((d for d in range(num) if d * scan_interval[i] + roi_size[i] >= image_size[i]), None)
+        scan_num.append(scan_dim + 1 if scan_dim is not None else 1)
+    starts = []
+    for dim in range(num_spatial_dims):
+        dim_starts = []
+        for idx in range(scan_num[dim]):
+            start_idx = idx * scan_interval[dim]
+            start_idx -= max(start_idx + roi_size[dim] - image_size[dim], 0)
+            dim_starts.append(start_idx)
+        starts.append(dim_starts)
+    grid = torch.stack(torch.meshgrid(*[torch.tensor(s) for s in starts], indexing="ij"), -1).reshape(-1, num_spatial_dims)
+    slices = [tuple(slice(int(s), int(s) + roi_size[d]) for d, s in enumerate(x)) for x in grid]
+    num_win = len(slices)
+    total_slices = num_win * batch_size
+    importance_map = torch.ones(roi_size, dtype=inputs.dtype)
+    output_image = count_map = None
+    for slice_g in range(0, total_slices, sw_batch_size):
+        slice_range = range(slice_g, min(slice_g + sw_batch_size, total_slices))
+        unravel_slice = [[slice(int(idx / num_win), int(idx / num_win) + 1), slice(None)] + list(slices[idx % num_win])
+                         for idx in slice_range]
+        window_data = torch.cat([inputs[tuple(win_slice)] for win_slice in unravel_slice])
+        seg_prob = predictor(window_data)
+        if output_image is None:
+            output_shape = [batch_size, seg_prob.shape[1]] + list(image_size)
+            output_image = torch.zeros(output_shape, dtype=seg_prob.dtype)
+            count_map = torch.zeros(output_shape, dtype=seg_prob.dtype)
+        for idx, original_idx in zip(slice_range, unravel_slice):
+            output_image[tuple(original_idx)] += importance_map * seg_prob[idx - slice_g]
+            count_map[tuple(original_idx)] += importance_map
+    output_image = output_image / count_map
+    final_slicing = []
+    for sp in range(num_spatial_dims):
+        slice_dim = slice(pad_size[sp * 2], image_size_[num_spatial_dims - sp - 1] + pad_size[sp * 2])
+        final_slicing.insert(0, slice_dim)
+    while len(final_slicing) < output_image.dim():
+        final_slicing.insert(0, slice(None))
+    return output_image[tuple(final_slicing)]
+
+
+def oracle_post_pred(logits, n_classes):
+    """AsDiscrete(argmax=True, to_onehot=True, n_classes) on a batched [B,C,...] tensor (unetr_segmentation_3d.py:406)"""
+    return F.one_hot(torch.argmax(logits, dim=1), n_classes).movedim(-1, 1).float()
+
+
+def oracle_post_label(label, n_classes):
+    """AsDiscrete(to_onehot=True, n_classes) (unetr_segmentation_3d.py:405)"""
+    return F.one_hot(label.squeeze(1).long(), n_classes).movedim(-1, 1).float()
+
+
+def oracle_dice_metric(y_pred, y, reduction="mean"):
+    """monai.metrics.compute_meandice (include_background=True) + do_metric_reduction for "mean" / "mean_batch";
+    returns (per-item per-class dice with NaN where the class is absent from y, reduced value)"""
+    axes = list(range(2, y_pred.dim()))
+    inter = torch.sum(y * y_pred, dim=axes)
+    y_o = torch.sum(y, dim=axes)
+    denom = y_o + torch.sum(y_pred, dim=axes)
+    f = torch.where(y_o > 0, (2.0 * inter) / denom, torch.tensor(float("nan")))
+    raw = f.clone()
+    nans = torch.isnan(f)
+    not_nans = (~nans).float()
+    f = f.clone()
+    f[nans] = 0
+    zero = torch.zeros(1)
+    if reduction == "mean":
+        nn_c = not_nans.sum(dim=1)
+        f = torch.where(nn_c > 0, f.sum(dim=1) / nn_c, zero)
+        nn_b = (nn_c > 0).float().sum(dim=0)
+        f = torch.where(nn_b > 0, f.sum(dim=0) / nn_b, zero)
+    elif reduction == "mean_batch":
+        nn_b = not_nans.sum(dim=0)
+        f = torch.where(nn_b > 0, f.sum(dim=0) / nn_b, zero)
+    else:
+        raise ValueError(reduction)
+    return raw, f
+
+
 def synthetic_volume(batch, in_channels, size, n_classes, seed):
     g = torch.Generator().manual_seed(seed)
     ax = torch.linspace(-1, 1, size)

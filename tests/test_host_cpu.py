@@ -82,9 +82,12 @@ def test_state_dict_interop_with_oracle(pkg):
 
 
 def test_dicece_rejects_unsupported(pkg):
-    with pytest.raises(NotImplementedError):
-        pkg.DiceCELoss(to_onehot_y=False, sigmoid=True)
-    pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    for kw in (dict(to_onehot_y=False, softmax=True), dict(to_onehot_y=True, sigmoid=True), dict(to_onehot_y=True, softmax=True, jaccard=True),
+               dict(to_onehot_y=True, softmax=True, include_background=False), dict()):
+        with pytest.raises(NotImplementedError):
+            pkg.DiceCELoss(**kw)
+    pkg.DiceCELoss(to_onehot_y=True, softmax=True)       # unetr_segmentation_3d.py:404
+    pkg.DiceCELoss(to_onehot_y=False, sigmoid=True)      # unetr_segmentation_3d.py:477-482 (4-channel MR task)
 
 
 def test_reference_import_line_works():

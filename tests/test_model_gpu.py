@@ -267,6 +267,42 @@ def test_c4_160_forward_parity(pkg, dev):
     assert relerr(logits, logits_r) < 1e-3 and relerr(enc4, enc4_r) < 1e-3
 
 
+def test_task01_multilabel_4channel(pkg, dev):
+    """SURVEY 8(f) rank 3 -- the 4-channel MR task (unetr_segmentation_3d.py:310-312, 477-482): in_channels = 4 and
+    DiceCELoss(to_onehot_y=False, sigmoid=True) on a multi-label target.  Train-step parity on a small geometry against
+    the fp64 oracle, then the 128^3 geometry (patch_dim 16 384, 512 tokens) forward against the fp32 oracle."""
+    from oracle.unetr_oracle import oracle_dice_ce_terms, synthetic_volume
+    cfg = dict(C1, in_channels=4, out_channels=4)
+    ref, hip = _pair(pkg, dev, cfg, seed=3)
+    hip.precision = "fp32"
+    x, _ = synthetic_volume(2, 4, 32, 4, seed=11)
+    target = (torch.rand(2, 4, 32, 32, 32, generator=torch.Generator().manual_seed(12)) < 0.3).float()
+    rd = next(ref.parameters()).dtype
+    _, logits_r = ref(x.to(rd))
+    d_r, c_r = oracle_dice_ce_terms(logits_r, target.to(rd), to_onehot_y=False, softmax=False, sigmoid=True)
+    (d_r + c_r).backward()
+    _, logits = hip(x.to(dev))
+    t = pkg.DiceCELoss(to_onehot_y=False, sigmoid=True).terms(logits, target.to(dev))
+    t[0].backward()
+    assert relerr(logits, logits_r) < 1e-3 and relerr(t[1], d_r) < 1e-3 and relerr(t[2], c_r) < 1e-3
+    gr, gh = dict(ref.named_parameters()), dict(hip.named_parameters())
+    for k, p in gr.items():
+        if p.grad is None:
+            assert gh[k].grad is None, k
+        else:
+            assert relerr(gh[k].grad, p.grad) < 1e-2, k
+    del ref, hip
+    big = dict(C2, in_channels=4, out_channels=4, img_size=(128, 128, 128), hidden_size=192, mlp_dim=384, num_heads=3)
+    ref, hip = _pair(pkg, dev, big, ref_dtype=torch.float32)
+    hip.precision = "fp32"
+    x, _ = synthetic_volume(1, 4, 128, 4, seed=13)
+    with torch.no_grad():
+        enc4_r, logits_r = ref(x)
+        enc4, logits = hip(x.to(dev))
+    assert logits.shape == (1, 4, 128, 128, 128) and enc4.shape == (1, 128, 16, 16, 16)
+    assert relerr(logits, logits_r) < 1e-3 and relerr(enc4, enc4_r) < 1e-3
+
+
 def test_c5_pretraining_steps(pkg, dev):
     """BASELINE config[4]: the two stages of unetr_ranking_pretraining_3d.py:238-296 on a [4, ...] batch -- 'feat'
     (loss on enc4, everything trains) and 'recon' (loss on the logits with freeze_encoder=True) -- vs the oracle."""
@@ -299,3 +335,45 @@ def test_c5_pretraining_steps(pkg, dev):
             ["encoder4.transp_conv_init.conv.weight", "vit.blocks.9.mlp.linear1.weight", "vit.patch_embedding.patch_embeddings.1.weight"]
         for k in keys:
             assert cosine(gh[k].grad, gr[k].grad) > 0.999, (stage, k)
+
+
+def test_sliding_window_inference_and_dice_metric(pkg, dev):
+    """SURVEY 8(f) rank 2 -- the validation step (unetr_segmentation_3d.py:103-132): sliding-window inference with the
+    reference's arguments (roi = crop^3, sw_batch_size 4, default overlap 0.25) over volumes larger than, equal to and
+    smaller than the window, then argmax/one-hot post-processing and DiceMetric "mean" / "mean_batch" -- against the CPU
+    oracle running the oracle model."""
+    from oracle.unetr_oracle import (oracle_dice_metric, oracle_post_label, oracle_post_pred,
+                                     oracle_sliding_window_inference, synthetic_volume)
+    ref, hip = _pair(pkg, dev, C1, seed=4, ref_dtype=torch.float32)
+    hip.precision = "fp32"
+    ref_pred = lambda w: ref(w)[1]
+    for size, overlap in ((48, 0.25), (40, 0.5), (32, 0.25), (24, 0.25)):
+        x, y = synthetic_volume(2, 1, size, 2, seed=20 + size)
+        with torch.no_grad():
+            out_r = oracle_sliding_window_inference(x, (32, 32, 32), 4, ref_pred, overlap=overlap)
+        out_h = pkg.sliding_window_inference(x.to(dev), (32, 32, 32), 4, hip, overlap=overlap)
+        assert out_h.shape == out_r.shape == (2, 2, size, size, size)
+        assert relerr(out_h, out_r) < 1e-3, size
+        # metric on the oracle's own predictions (so argmax ties / near-ties cannot differ), both call conventions
+        pr, lr = oracle_post_pred(out_r, 2), oracle_post_label(y, 2)
+        for red in ("mean", "mean_batch"):
+            raw_r, val_r = oracle_dice_metric(pr, lr, red)
+            m = pkg.DiceMetric(include_background=True, reduction=red, get_not_nans=False)
+            raw_h = m(y_pred=[t for t in pr.to(dev)], y=[t for t in lr.to(dev)])
+            assert torch.allclose(raw_h.cpu(), raw_r, atol=1e-6, equal_nan=True)
+            assert torch.allclose(m.aggregate().cpu(), val_r, atol=1e-6)
+            m.reset()
+            m(out_r.to(dev), y.to(dev), from_logits=True)           # fused argmax + one-hot
+            assert torch.allclose(m.aggregate().cpu(), val_r, atol=1e-6)
+        # north_star: Dice of the HIP prediction within 1e-3 of the reference's
+        m = pkg.DiceMetric()
+        m(out_h, y.to(dev), from_logits=True)
+        assert abs(m.aggregate().item() - oracle_dice_metric(pr, lr)[1].item()) < 1e-3
+    # an absent class gives NaN for that item/class and drops out of the averages
+    y0 = torch.zeros(2, 1, 24, 24, 24)
+    pr, lr = oracle_post_pred(out_r, 2), oracle_post_label(y0, 2)
+    raw_r, val_r = oracle_dice_metric(pr, lr, "mean")
+    m = pkg.DiceMetric()
+    raw_h = m(pr.to(dev), lr.to(dev))
+    assert torch.isnan(raw_h[:, 1]).all() and torch.allclose(raw_h.cpu(), raw_r, atol=1e-6, equal_nan=True)
+    assert torch.allclose(m.aggregate().cpu(), val_r, atol=1e-6)

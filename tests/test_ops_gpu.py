@@ -317,6 +317,27 @@ def test_dicece(pkg, dev, B, C, S):
     assert relerr(ld.grad, lr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("B,C,S", [(2, 3, 24), (1, 4, 17), (2, 2, 32)])
+def test_dicece_sigmoid_multilabel(pkg, dev, B, C, S):
+    """DiceCELoss(to_onehot_y=False, sigmoid=True) on an overlapping multi-label mask (unetr_segmentation_3d.py:477-482):
+    Dice on sigmoid probabilities, CE against argmax_c(target) -- including all-zero voxels (argmax -> channel 0)."""
+    from oracle.unetr_oracle import oracle_dice_ce_terms
+    logits = g(B, C, S, S, S, seed=1) * 2
+    gen = torch.Generator().manual_seed(2)
+    target = (torch.rand(B, C, S, S, S, generator=gen) < 0.35).float()      # channels overlap, many voxels are all-zero
+    lr = logits.clone().requires_grad_(True)
+    d, c = oracle_dice_ce_terms(lr, target, to_onehot_y=False, softmax=False, sigmoid=True)
+    (d + c).backward()
+    ld = logits.to(dev).requires_grad_(True)
+    crit = pkg.DiceCELoss(to_onehot_y=False, sigmoid=True)
+    t = crit.terms(ld, target.to(dev))
+    assert relerr(t[1], d) < 1e-5 and relerr(t[2], c) < 1e-5 and relerr(t[0], d + c) < 1e-5
+    (t[0] * 1.0).backward()
+    assert relerr(ld.grad, lr.grad) < 1e-4
+    with pytest.raises(ValueError):
+        crit(ld, target[:, :1].to(dev))
+
+
 def test_adamw(pkg, dev):
     n = 100003
     p, gr = g(n, seed=1), g(n, seed=2)

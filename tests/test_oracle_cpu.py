@@ -121,3 +121,47 @@ def test_ranking_losses_triplet_structure():
     assert torch.isfinite(bt) and bt.item() > 0
     ct = oracle_contrastive_loss(r[:24], s[:24], dsl[:24], 0.5)
     assert torch.isfinite(ct)
+
+
+def test_oracle_sliding_window_properties():
+    """Blending identical per-voxel predictions must reproduce them exactly for every geometry (volume larger than,
+    equal to, smaller than the window; odd sizes); the number of predictor calls follows sw_batch_size."""
+    from oracle.unetr_oracle import oracle_dice_metric, oracle_post_label, oracle_post_pred, oracle_sliding_window_inference
+    calls = []
+
+    def pred(w):
+        calls.append(w.shape[0])
+        return torch.cat([w * 2 + 1, -w], dim=1)
+
+    for size, roi, ov in ((20, 8, 0.25), (16, 16, 0.25), (6, 8, 0.25), (19, 8, 0.8), (9, 8, 0.0)):
+        x = torch.randn(2, 1, size, size, size)
+        calls.clear()
+        out = oracle_sliding_window_inference(x, (roi,) * 3, 4, pred, overlap=ov)
+        assert out.shape == (2, 2, size, size, size)
+        assert torch.allclose(out[:, :1], x * 2 + 1, atol=1e-5) and torch.allclose(out[:, 1:], -x, atol=1e-5)
+        assert all(c <= 4 for c in calls) and sum(calls) % 2 == 0
+    # Dice metric: perfect prediction -> 1 for present classes, NaN (dropped) for absent ones
+    y = torch.zeros(2, 1, 4, 4, 4); y[0, 0, :2] = 1
+    oh = oracle_post_label(y, 3)
+    raw, val = oracle_dice_metric(oh, oh, "mean")
+    assert torch.isnan(raw[:, 2]).all() and torch.isnan(raw[1, 1]) and val.item() == 1.0
+    logits = torch.randn(2, 3, 4, 4, 4)
+    assert torch.equal(oracle_post_pred(logits, 3).argmax(1), logits.argmax(1))
+
+
+def test_host_window_geometry_matches_oracle(pkg):
+    """the host-side window enumeration of inference.sliding_window_inference == the oracle's dense_patch_slices order"""
+    import math
+    inf = pkg.inference
+    for size, roi, ov in ((48, 32, 0.25), (40, 32, 0.5), (96, 96, 0.25), (100, 96, 0.25), (33, 32, 0.8), (160, 96, 0.25)):
+        image = [size] * 3
+        interval = inf._scan_interval(image, [roi] * 3, ov)
+        starts = inf._dense_patch_starts(image, [roi] * 3, interval)
+        exp_1d = []
+        s = int(roi * (1 - ov)) if roi != size else roi
+        n = int(math.ceil(size / s))
+        first = next(d for d in range(n) if d * s + roi >= size)
+        for i in range(first + 1):
+            st = i * s
+            exp_1d.append(st - max(st + roi - size, 0))
+        assert starts == [(z, y, x) for z in exp_1d for y in exp_1d for x in exp_1d]
