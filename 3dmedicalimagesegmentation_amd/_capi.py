@@ -69,6 +69,9 @@ _SIGNATURES = {
     "unetr_conv_gemm_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_conv3_fwd_fused": [P, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_pack_1x1": [P, P, c_int, c_int, c_int, P],
+    "unetr_instnorm_stats_finalize": [P, c_int, c_int, c_long, c_int, c_float, P, P],
     "unetr_conv3_wgrad": [P, c_long, P, c_long, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_debug_tr16": [P, P, P],
     "unetr_instnorm_stats": [P, c_long, c_int, c_long, c_int, c_float, P, P, c_size_t, P],
@@ -91,7 +94,7 @@ _SIGNATURES = {
     "unetr_adamw_reduced": [P, P, c_int, c_float, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],
 }
 
-EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_ranking_workspace_floats")
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_conv3_packed_1x1_bytes", "unetr_ranking_workspace_floats")
 
 _lib = None
 
@@ -112,10 +115,20 @@ def load():
         fn.restype = c_int
     lib.unetr_conv3_packed_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.unetr_conv3_packed_bytes.restype = c_size_t
+    lib.unetr_conv3_packed_1x1_bytes.argtypes = [c_int, c_int, c_int]
+    lib.unetr_conv3_packed_1x1_bytes.restype = c_size_t
     lib.unetr_ranking_workspace_floats.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.unetr_ranking_workspace_floats.restype = c_size_t
     _lib = lib
     return lib
+
+
+def call_rc(name, *args):
+    """like call(), but hands 'unsupported shape' (3) back to the caller, which then takes the unfused route"""
+    rc = getattr(load(), name)(*args)
+    if rc not in (0, 3):
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+    return rc
 
 
 def call(name, *args):

@@ -296,10 +296,37 @@ __global__ void conv3_pack_pair_kernel(const float* __restrict__ w, uint16_t* __
     }
 }
 
-template <class P, int NTB, bool PAIR, bool VEC>
+// per-wave InstanceNorm partial sums of one output tile: (sum, sum of squares) over the wave's valid voxels for each of
+// its NTB*16 channels, reduced over the four lane groups and written by lane group 0 -- prow[0*Cout + ch], prow[Cout + ch]
+template <int NTB>
+__device__ __forceinline__ void tile_stats(const f32x4 (&acc)[4][NTB], const bool (&okv)[4][4], float* __restrict__ prow, int Cout,
+                                           int ch0, int g) {
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float v = okv[i][rr] ? acc[i][j][rr] : 0.f;
+                s1 += v; s2 += v * v;
+            }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (g == 0) { prow[ch0 + j * 16] = s1; prow[Cout + ch0 + j * 16] = s2; }
+    }
+}
+
+// FUSE: the residual block's forward in one pass over the input window -- besides y = conv3x3x3(x) the kernel emits
+//   * part : per-(tile, wave) InstanceNorm partial sums of y (the separate statistics pass over y disappears), and
+//   * y3 = conv1x1x1(x) with weights wp3 (+ its partial sums part3) when wp3 != NULL: MONAI's UnetResBlock.conv3 reads
+//     the same input as conv1, i.e. the centre tap of the window already staged in LDS (one extra MFMA per 16 voxels).
+template <class P, int NTB, bool PAIR, bool VEC, bool FUSE>
 __global__ void __launch_bounds__(256)
 conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
-                      int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
+                      int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles,
+                      float* __restrict__ part, const char* __restrict__ wp3, float* __restrict__ y3, long ldy3,
+                      float* __restrict__ part3) {
     constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16 + 16;
     __shared__ __attribute__((aligned(16))) char halo[NHALO * PITCH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -314,6 +341,14 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
             for (int j = 0; j < NTB; ++j) wres[tp][j] = *(const u32x4*)(wp + ((long)tp * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
     }
 
+    const bool has3 = FUSE && wp3 != nullptr;
+    u32x4 w3res[NTB];         // 1x1x1 weights: PAIR keeps them for the whole launch, the slab path reloads them per slab
+    if constexpr (FUSE && PAIR) {
+#pragma unroll
+        for (int j = 0; j < NTB; ++j)
+            w3res[j] = has3 ? *(const u32x4*)(wp3 + ((long)(nt0 + j) * 16 + r) * 64 + g * 16) : (u32x4){0u, 0u, 0u, 0u};
+    }
+
     HaloRegs<P, NCH> R;
     int tile = blockIdx.x;
     if (tile < ntiles) {
@@ -326,10 +361,14 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
         tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         f32x4 acc[4][NTB];
+        f32x4 acc3[FUSE ? 4 : 1][NTB];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NTB; ++j) {
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (FUSE) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 
         for (int slab = 0; slab < nslab; ++slab) {
             __syncthreads();                       // everyone is done reading the previous window
@@ -358,6 +397,12 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                         u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
 #pragma unroll
                         for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, wres[tp][j]);
+                        if constexpr (FUSE) {
+                            if (tp == 6 && has3) {     // w3res is zero on the tap-12 half of the K range
+#pragma unroll
+                                for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], a, w3res[j]);
+                            }
+                        }
                     }
                 }
             } else {
@@ -365,6 +410,11 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                 const char* wbase = wp + ((long)slab * Cout + nt0 * 16 + r) * 64 + g * 16;
                 const long wtap = (long)nslab * Cout * 64;
                 u32x4 bcur[GT][NTB], bnxt[GT][NTB];
+                if constexpr (FUSE) {
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j)
+                        w3res[j] = has3 ? *(const u32x4*)(wp3 + ((long)slab * Cout + (nt0 + j) * 16 + r) * 64 + g * 16) : (u32x4){0u, 0u, 0u, 0u};
+                }
 #pragma unroll
                 for (int t = 0; t < GT; ++t)
 #pragma unroll
@@ -386,6 +436,12 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                             u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
 #pragma unroll
                             for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, bcur[t][j]);
+                            if constexpr (FUSE) {
+                                if (tap == 13 && has3) {
+#pragma unroll
+                                    for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], a, w3res[j]);
+                                }
+                            }
                         }
                     }
 #pragma unroll
@@ -432,7 +488,39 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                         for (int j = 0; j < NTB; ++j)
                             if (okv[i][rr]) yrow[i][rr][j * 16] = acc[i][j][rr];
             }
+            if constexpr (FUSE) {
+                // partial-sum row of this (tile, wave): [b][((tz*nty + ty)*ntx + tx)*4 + wv][2][Cout]
+                const long prow = (((long)b * ntz + tz) * nty + ty) * ntx + tx;
+                tile_stats<NTB>(acc, okv, part + (prow * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+                if (has3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int yo = y0 + i, xo = x0 + 4 * g + rr;
+                            float* q = y3 + ((((long)b * D + zo) * H + yo) * W + xo) * ldy3 + nt0 * 16 + r;
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j)
+                                if (okv[i][rr]) q[j * 16] = acc3[i][j][rr];
+                        }
+                    tile_stats<NTB>(acc3, okv, part3 + (prow * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+                }
+            }
         }
+    }
+}
+
+// 1x1x1 weights w3[Cout][Cin] in the B-fragment layout the fused kernel reads at the centre tap:
+// pair mode: wp3[n][32], k = 16 + ci (the tap-13 half of pair 6), zero elsewhere; slab mode: wp3[slab][n][SL], k = ci - slab*SL
+template <class T>
+__global__ void conv3_pack_1x1_kernel(const float* __restrict__ w3, T* __restrict__ wp3, int Cin, int Cout, int pair, int SL) {
+    const int nslab = pair ? 1 : (Cin + SL - 1) / SL, RW = pair ? 32 : SL;
+    const long total = (long)nslab * Cout * RW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % RW); const long t = i / RW; const int n = (int)(t % Cout), slab = (int)(t / Cout);
+        const int ci = pair ? kk - 16 : slab * SL + kk;
+        const float v = (ci >= 0 && ci < Cin) ? w3[(long)n * Cin + ci] : 0.f;
+        if constexpr (sizeof(T) == 2) wp3[i] = f2bf(v); else wp3[i] = v;
     }
 }
 
@@ -657,9 +745,11 @@ int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st
     return unetr_check_launch();
 }
 
+struct FuseArgs { float* part; const void* wp3; float* y3; long ldy3; float* part3; };
+
 template <class P>
 int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accumulate, int B, int D, int H, int W, int Cin, int Cout,
-          hipStream_t st) {
+          hipStream_t st, const FuseArgs* fz = nullptr) {
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long spatial = (long)B * ntx * nty * ntz;
     const int ntn = Cout / 16;
@@ -675,12 +765,14 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
         if (pair && ntb > 2) ntb = 2;
         const long cap = 512;   // 2 resident workgroups per CU (VGPR-limited); more would queue behind them
         dim3 pgrid((unsigned)std::min<long>(spatial, cap), ntn / ntb);
+#define LAUNCH_PIPE_F(NTB_, PAIR_, VEC_, FUSE_)                                                                                   \
+    hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, VEC_, FUSE_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
+                       accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial, fz ? fz->part : nullptr,                       \
+                       fz ? (const char*)fz->wp3 : nullptr, fz ? fz->y3 : nullptr, fz ? fz->ldy3 : 0, fz ? fz->part3 : nullptr)
 #define LAUNCH_PIPE(NTB_, PAIR_)                                                                                                  \
     do {                                                                                                                          \
-        if (vec) hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, true>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, \
-                                    y, ldy, accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial);                            \
-        else hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, false>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp,   \
-                                y, ldy, accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial);                                \
+        if (fz) { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, true); else LAUNCH_PIPE_F(NTB_, PAIR_, false, true); }                \
+        else { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, false); else LAUNCH_PIPE_F(NTB_, PAIR_, false, false); }                 \
     } while (0)
         if constexpr (P::CH == 8) {
             if (pair) {
@@ -695,6 +787,7 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
         }
         return unetr_check_launch();
     }
+    if (fz) return UNETR_ERR_UNSUPPORTED;       // fused statistics / 1x1 need the persistent kernel
     dim3 grid((unsigned)spatial, ntn / ntb);
 #define LAUNCH_FWD(NTB_)                                                                                                          \
     do {                                                                                                                          \
@@ -770,6 +863,50 @@ extern "C" int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, floa
     if (prec == UNETR_PREC_BF16) return fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, accumulate, B, D, H, W, Cin, Cout, (hipStream_t)stream);
     if (prec == UNETR_PREC_F32) return fwd_t<PrecF32>(x, ldx, wpack, y, ldy, accumulate, B, D, H, W, Cin, Cout, (hipStream_t)stream);
     return UNETR_ERR_ARG;
+}
+
+// Forward of the first half of MONAI's UnetResBlock in one launch (unetr.py:90-98 and the decoder blocks :135-174):
+// y = conv3x3x3(x), its InstanceNorm statistics, and optionally y3 = conv1x1x1(x) with its statistics.
+extern "C" int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack, float* y, long ldy, float* stats,
+                                     const void* w3pack, float* y3, long ldy3, float* stats3, float eps,
+                                     int B, int D, int H, int W, int Cin, int Cout, int prec,
+                                     float* ws, size_t ws_bytes, void* stream) {
+    if (!x || !wpack || !y || !stats || B <= 0) return UNETR_ERR_ARG;
+    if ((w3pack != nullptr) != (y3 != nullptr) || (w3pack != nullptr) != (stats3 != nullptr)) return UNETR_ERR_ARG;
+    if (Cout % 16) return UNETR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = cdiv(W, TX) * cdiv(H, TY) * cdiv(D, TZ) * 4;          // (tile, wave) partial rows per batch item
+    const size_t per = (size_t)B * nchunk * 2 * Cout;
+    if (!ws || per * (w3pack ? 2 : 1) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr};
+    int rc;
+    if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
+    else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
+    else return UNETR_ERR_ARG;
+    if (rc) return rc;
+    const long V = (long)D * H * W;
+    rc = unetr_instnorm_stats_finalize(ws, nchunk, B, V, Cout, eps, stats, stream);
+    if (rc == UNETR_OK && w3pack) rc = unetr_instnorm_stats_finalize(ws + per, nchunk, B, V, Cout, eps, stats3, stream);
+    return rc;
+}
+
+extern "C" size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec) {
+    const int SL = prec == UNETR_PREC_BF16 ? 32 : 16;
+    return (size_t)((Cin + SL - 1) / SL) * Cout * 64;
+}
+
+extern "C" int unetr_conv3_pack_1x1(const float* w3, void* w3pack, int Cin, int Cout, int prec, void* stream) {
+    if (!w3 || !w3pack || Cin <= 0 || Cout <= 0) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == UNETR_PREC_BF16) {
+        const int pair = (use_pair<PrecBF16>(Cin) && conv_pipe_enabled()) ? 1 : 0;
+        hipLaunchKernelGGL((conv3_pack_1x1_kernel<uint16_t>), dim3(cdiv((long)((Cin + 31) / 32) * Cout * 32, 256)), dim3(256), 0, st, w3,
+                           (uint16_t*)w3pack, Cin, Cout, pair, 32);
+    } else if (prec == UNETR_PREC_F32) {
+        hipLaunchKernelGGL((conv3_pack_1x1_kernel<float>), dim3(cdiv((long)((Cin + 15) / 16) * Cout * 16, 256)), dim3(256), 0, st, w3,
+                           (float*)w3pack, Cin, Cout, 0, 16);
+    } else return UNETR_ERR_ARG;
+    return unetr_check_launch();
 }
 
 extern "C" int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,

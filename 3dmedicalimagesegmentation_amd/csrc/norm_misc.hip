@@ -599,6 +599,38 @@ extern "C" int unetr_instnorm_stats(const float* x, long ld, int B, long V, int 
     return unetr_check_launch();
 }
 
+// statistics from partial sums produced elsewhere (the fused conv forward): part [B][nchunk][2][C]
+__global__ void __launch_bounds__(256)
+in_stats_final_block_kernel(const float* __restrict__ part, int nchunk, long V, int C, float eps, float* __restrict__ stats) {
+    __shared__ double sm[2][4];
+    const int i = blockIdx.x, b = i / C, c = i - b * C, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    for (int k = threadIdx.x; k < nchunk; k += 256) {
+        const float* p = part + ((long)b * nchunk + k) * 2 * C;
+        s += (double)p[c];
+        q += (double)p[C + c];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) { sm[0][wave] = s; sm[1][wave] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+        q = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+        double mu = s / (double)V, var = q / (double)V - mu * mu;
+        if (var < 0.0) var = 0.0;
+        stats[2 * i] = (float)mu;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+extern "C" int unetr_instnorm_stats_finalize(const float* part, int nchunk, int B, long V, int C, float eps, float* stats,
+                                             void* stream) {
+    if (!part || !stats || nchunk <= 0 || B <= 0 || C <= 0 || V <= 0) return UNETR_ERR_ARG;
+    hipLaunchKernelGGL(in_stats_final_block_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, part, nchunk, V, C, eps, stats);
+    return unetr_check_launch();
+}
+
 extern "C" int unetr_instnorm_apply(const float* x, long ldx, const float* sa, const float* x2, long ldx2, const float* sb,
                                     float* y, long ldy, int B, long V, int C, int lrelu, void* stream) {
     if (!x || !sa || !y || (x2 && !sb)) return UNETR_ERR_ARG;

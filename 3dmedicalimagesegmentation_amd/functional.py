@@ -13,7 +13,7 @@ import weakref
 import torch
 
 from . import _capi
-from ._capi import GemmDesc, GemmBf16Desc, call
+from ._capi import GemmDesc, GemmBf16Desc, call, call_rc
 
 LN_EPS = 1e-5
 IN_EPS = 1e-5
@@ -415,6 +415,34 @@ def conv3(x, ldx, w, dims, prec, mode=0, out=None, ldo=None, accumulate=False):
     return out
 
 
+def conv3_fused(x, ldx, w, w3, dims, prec):
+    """First half of a residual block in one launch: c = conv3x3x3(x, w) with its InstanceNorm statistics and, when w3 is
+    given, c3 = conv1x1x1(x, w3) with its statistics (both convs read the same staged window).  Returns
+    (c, stats, c3, stats3) or None when the shape has to take the unfused kernels."""
+    B, D, H, W = dims
+    cout, cin = w.shape[0], w.shape[1]
+    if _use_gemm_conv() or cout % 16 != 0 or os.environ.get("UNETR_AMD_CONV_FUSE", "1") == "0":
+        return None
+    lib = _capi.load()
+    dev = x.device
+    wp = torch.empty(lib.unetr_conv3_packed_bytes(cin, cout, 0, prec), dtype=torch.uint8, device=dev)
+    call("unetr_conv3_pack_weight", w.data_ptr(), wp.data_ptr(), cin, cout, 0, prec, _stream())
+    c = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=dev)
+    st = torch.empty(B, cout, 2, dtype=torch.float32, device=dev)
+    wp3 = c3 = st3 = None
+    if w3 is not None:
+        wp3 = torch.empty(lib.unetr_conv3_packed_1x1_bytes(cin, cout, prec), dtype=torch.uint8, device=dev)
+        call("unetr_conv3_pack_1x1", w3.data_ptr(), wp3.data_ptr(), cin, cout, prec, _stream())
+        c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=dev)
+        st3 = torch.empty(B, cout, 2, dtype=torch.float32, device=dev)
+    ws = workspace(dev)
+    rc = call_rc("unetr_conv3_fwd_fused", x.data_ptr(), ldx, wp.data_ptr(), c.data_ptr(), cout, st.data_ptr(), _p(wp3), _p(c3), cout,
+                 _p(st3), IN_EPS, B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
+    if rc != 0:
+        return None
+    return c, st, c3, st3
+
+
 def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None):
     """dw of the 3x3x3 conv; with dy3/out3 also the weight gradient of the 1x1x1 conv sharing the input x."""
     if _use_gemm_conv():
@@ -668,14 +696,22 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec):
     """MONAI UnetResBlock (instance norm, in != out): lrelu(IN(conv2(lrelu(IN(conv1 x)))) + IN(conv3 x))."""
     B, D, H, W = dims
     V = D * H * W
-    c1 = conv3(x, ldx, w1, dims, prec)
-    s1 = instnorm_stats(c1, cout, B, V, cout)
+    f1 = conv3_fused(x, ldx, w1, w3, dims, prec)
+    if f1 is not None:
+        c1, s1, c3, s3 = f1
+    else:
+        c1 = conv3(x, ldx, w1, dims, prec)
+        s1 = instnorm_stats(c1, cout, B, V, cout)
+        c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
+        gemm(x, w3, c3, B * V, cout, cin, lda=ldx, ldb=cin, ldc=cout, prec=prec)
+        s3 = instnorm_stats(c3, cout, B, V, cout)
     a1 = instnorm_apply(c1, s1, B, V, cout, True)
-    c2 = conv3(a1, cout, w2, dims, prec)
-    s2 = instnorm_stats(c2, cout, B, V, cout)
-    c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
-    gemm(x, w3, c3, B * V, cout, cin, lda=ldx, ldb=cin, ldc=cout, prec=prec)
-    s3 = instnorm_stats(c3, cout, B, V, cout)
+    f2 = conv3_fused(a1, cout, w2, None, dims, prec)
+    if f2 is not None:
+        c2, s2 = f2[0], f2[1]
+    else:
+        c2 = conv3(a1, cout, w2, dims, prec)
+        s2 = instnorm_stats(c2, cout, B, V, cout)
     out = instnorm_apply(c2, s2, B, V, cout, True, x2=c3, sb=s3)
     return out, (c1, s1, a1, c2, s2, c3, s3)
 

@@ -143,6 +143,19 @@ int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, float* y, long 
                     int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream);
 /* dy3/dw3 (both or neither): also produce the weight gradient dw3[Cout,Cin] of the 1x1x1 conv that shares the
  * input x (MONAI UnetResBlock.conv3 next to conv1) from its own output gradient dy3, inside the same pass. */
+/* Fused forward of the first half of MONAI's UnetResBlock (unetr.py:90-98, :135-174): y = conv3x3x3(x) together with
+ * its InstanceNorm statistics stats[B,Cout,2] = (mean, rstd), and -- when w3pack != NULL -- y3 = conv1x1x1(x) (the
+ * block's conv3, which reads the same input) with stats3.  wpack from unetr_conv3_pack_weight(mode 0), w3pack from
+ * unetr_conv3_pack_1x1.  Returns "unsupported" for shapes that do not run on the persistent kernel (caller then uses
+ * unetr_conv3_fwd + unetr_gemm + unetr_instnorm_stats). */
+int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack, float* y, long ldy, float* stats,
+                          const void* w3pack, float* y3, long ldy3, float* stats3, float eps,
+                          int B, int D, int H, int W, int Cin, int Cout, int prec,
+                          float* ws, size_t ws_bytes, void* stream);
+size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec);
+int unetr_conv3_pack_1x1(const float* w3 /* [Cout,Cin] */, void* w3pack, int Cin, int Cout, int prec, void* stream);
+/* (mean, rstd) from InstanceNorm partial sums part[B][nchunk][2][C] (sum, sum of squares) */
+int unetr_instnorm_stats_finalize(const float* part, int nchunk, int B, long V, int C, float eps, float* stats, void* stream);
 int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
                       const float* dy3, long ldy3, float* dw3,
                       int B, int D, int H, int W, int Cin, int Cout, int prec,

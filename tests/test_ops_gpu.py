@@ -194,6 +194,38 @@ def test_conv3(pkg, dev, prec, B, dims3, cin, cout):
     assert relerr(Fn.conv_wgrad(xd, cin, dyd, cout, dims, cin, cout, 3, prec), wr.grad) < TOL[prec]
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,dims3,cin,cout,with3", [(2, (8, 8, 16), 16, 16, True), (1, (9, 7, 19), 1, 16, True), (2, (6, 10, 20), 32, 16, True),
+                                                     (1, (12, 12, 12), 64, 32, True), (1, (5, 6, 7), 16, 32, False), (2, (4, 4, 16), 256, 128, True),
+                                                     (1, (10, 9, 33), 4, 16, True)])
+def test_conv3_fused_stats_and_1x1(pkg, dev, prec, B, dims3, cin, cout, with3):
+    """Fused residual-block front: conv3x3x3 + InstanceNorm statistics (+ the 1x1x1 conv on the same input with its
+    statistics) in one launch == torch conv3d / mean / rstd, over ragged volumes and all kernel modes (pair, slab, scalar)."""
+    Fn = pkg.functional
+    D, H, W = dims3
+    x = g(B, D, H, W, cin, seed=1)
+    w = g(cout, cin, 3, 3, 3, seed=2, scale=0.2)
+    w3 = g(cout, cin, 1, 1, 1, seed=3, scale=0.5) if with3 else None
+    xn = x.permute(0, 4, 1, 2, 3)
+    r = Fn.conv3_fused(x.to(dev), cin, w.to(dev), w3.to(dev) if with3 else None, (B, D, H, W), prec)
+    assert r is not None
+    c, st, c3, st3 = r
+
+    def check(out, stats, ref):
+        refl = ref.permute(0, 2, 3, 4, 1)
+        assert relerr(out, refl) < TOL[prec]
+        o = out.cpu().double().reshape(B, -1, cout)              # statistics of what the kernel itself produced
+        mu = o.mean(1)
+        rstd = 1.0 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)
+        assert relerr(stats[..., 0], mu.float()) < 1e-4 + (mu.abs().max() < 1e-3) and relerr(stats[..., 1], rstd.float()) < 1e-4
+
+    check(c, st, F.conv3d(xn, w, padding=1))
+    if with3:
+        check(c3, st3, F.conv3d(xn, w3))
+    else:
+        assert c3 is None and st3 is None
+
+
 def test_tr16_probe(pkg, dev):
     """ds_read_b64_tr_b16: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block of
     16-bit elements; lane i receives column i of the 4 rows (element q = row q)."""
