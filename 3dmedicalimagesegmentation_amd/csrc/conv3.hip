@@ -296,33 +296,41 @@ __global__ void conv3_pack_pair_kernel(const float* __restrict__ w, uint16_t* __
     }
 }
 
-// per-wave InstanceNorm partial sums of one output tile: (sum, sum of squares) over the wave's valid voxels for each of
-// its NTB*16 channels, reduced over the four lane groups and written by lane group 0 -- prow[0*Cout + ch], prow[Cout + ch]
+// InstanceNorm partial sums inside the persistent conv kernel: every lane keeps running (sum, sum of squares) of its
+// valid output voxels per channel tile across the tiles its workgroup walks; a wave's tiles come in non-decreasing batch
+// order (tile_coords), so the sums are flushed -- reduced over the four lane groups, written by lane group 0 to row
+// (b, workgroup, wave) of part[B][rows][2][Cout] -- when the batch index changes and at the end of the walk.
 template <int NTB>
-__device__ __forceinline__ void tile_stats(const f32x4 (&acc)[4][NTB], const bool (&okv)[4][4], float* __restrict__ prow, int Cout,
-                                           int ch0, int g) {
+__device__ __forceinline__ void stats_add(const f32x4 (&acc)[4][NTB], const bool (&okv)[4][4], float (&s1)[NTB], float (&s2)[NTB]) {
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) {
-        float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < NTB; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const float v = okv[i][rr] ? acc[i][j][rr] : 0.f;
-                s1 += v; s2 += v * v;
+                s1[j] += v; s2[j] += v * v;
             }
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (g == 0) { prow[ch0 + j * 16] = s1; prow[Cout + ch0 + j * 16] = s2; }
+}
+template <int NTB>
+__device__ __forceinline__ void stats_flush(float (&s1)[NTB], float (&s2)[NTB], float* __restrict__ prow, int Cout, int ch0, int g) {
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        float a = s1[j], q = s2[j];
+        a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+        a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+        if (g == 0) { prow[ch0 + j * 16] = a; prow[Cout + ch0 + j * 16] = q; }
+        s1[j] = 0.f; s2[j] = 0.f;
     }
 }
 
-// FUSE: the residual block's forward in one pass over the input window -- besides y = conv3x3x3(x) the kernel emits
-//   * part : per-(tile, wave) InstanceNorm partial sums of y (the separate statistics pass over y disappears), and
-//   * y3 = conv1x1x1(x) with weights wp3 (+ its partial sums part3) when wp3 != NULL: MONAI's UnetResBlock.conv3 reads
-//     the same input as conv1, i.e. the centre tap of the window already staged in LDS (one extra MFMA per 16 voxels).
-template <class P, int NTB, bool PAIR, bool VEC, bool FUSE>
-__global__ void __launch_bounds__(256)
+// FUSE >= 1: besides y = conv3x3x3(x) the kernel emits part = InstanceNorm partial sums of y (the separate statistics
+//   pass over y disappears; the partial buffer must be zero-filled before the launch);
+// FUSE == 2: also y3 = conv1x1x1(x) with weights wp3 and its partial sums part3: MONAI's UnetResBlock.conv3 reads the same
+//   input as conv1, i.e. the centre tap of the window already staged in LDS (one extra MFMA per 16 voxels).
+// two resident waves per SIMD (256 registers) is requested only where the variant fits without scratch
+template <class P, int NTB, bool PAIR, bool VEC, int FUSE>
+__global__ void __launch_bounds__(256, (FUSE == 2 ? (PAIR && NTB == 1) : (FUSE == 1 && (NTB == 1 || (!PAIR && NTB == 2)))) ? 2 : 1)
 conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
                       int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles,
                       float* __restrict__ part, const char* __restrict__ wp3, float* __restrict__ y3, long ldy3,
@@ -341,13 +349,23 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
             for (int j = 0; j < NTB; ++j) wres[tp][j] = *(const u32x4*)(wp + ((long)tp * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
     }
 
-    const bool has3 = FUSE && wp3 != nullptr;
-    u32x4 w3res[NTB];         // 1x1x1 weights: PAIR keeps them for the whole launch, the slab path reloads them per slab
-    if constexpr (FUSE && PAIR) {
+    constexpr bool has3 = FUSE == 2;
+    u32x4 w3res[has3 ? NTB : 1];   // 1x1x1 weights: PAIR keeps them for the whole launch, the slab path reloads them per slab
+    if constexpr (has3 && PAIR) {
 #pragma unroll
-        for (int j = 0; j < NTB; ++j)
-            w3res[j] = has3 ? *(const u32x4*)(wp3 + ((long)(nt0 + j) * 16 + r) * 64 + g * 16) : (u32x4){0u, 0u, 0u, 0u};
+        for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)(nt0 + j) * 16 + r) * 64 + g * 16);
     }
+    float rs1[FUSE ? NTB : 1], rs2[FUSE ? NTB : 1], rt1[has3 ? NTB : 1], rt2[has3 ? NTB : 1];
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) { rs1[j] = 0.f; rs2[j] = 0.f; }
+    }
+    if constexpr (has3) {
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) { rt1[j] = 0.f; rt2[j] = 0.f; }
+    }
+    int cur_b = -1;
+    const long srows = (long)gridDim.x * 4;       // partial rows per batch item
 
     HaloRegs<P, NCH> R;
     int tile = blockIdx.x;
@@ -361,14 +379,23 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
         tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         f32x4 acc[4][NTB];
-        f32x4 acc3[FUSE ? 4 : 1][NTB];
+        f32x4 acc3[has3 ? 4 : 1][has3 ? NTB : 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NTB; ++j) {
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (FUSE) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (has3) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        if constexpr (FUSE) {
+            if (b != cur_b) {
+                if (cur_b >= 0) {
+                    stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+                    if constexpr (has3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+                }
+                cur_b = b;
+            }
+        }
 
         for (int slab = 0; slab < nslab; ++slab) {
             __syncthreads();                       // everyone is done reading the previous window
@@ -397,8 +424,8 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                         u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
 #pragma unroll
                         for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, wres[tp][j]);
-                        if constexpr (FUSE) {
-                            if (tp == 6 && has3) {     // w3res is zero on the tap-12 half of the K range
+                        if constexpr (has3) {
+                            if (tp == 6) {             // w3res is zero on the tap-12 half of the K range
 #pragma unroll
                                 for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], a, w3res[j]);
                             }
@@ -410,10 +437,9 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                 const char* wbase = wp + ((long)slab * Cout + nt0 * 16 + r) * 64 + g * 16;
                 const long wtap = (long)nslab * Cout * 64;
                 u32x4 bcur[GT][NTB], bnxt[GT][NTB];
-                if constexpr (FUSE) {
+                if constexpr (has3) {
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j)
-                        w3res[j] = has3 ? *(const u32x4*)(wp3 + ((long)slab * Cout + (nt0 + j) * 16 + r) * 64 + g * 16) : (u32x4){0u, 0u, 0u, 0u};
+                    for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)slab * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
                 }
 #pragma unroll
                 for (int t = 0; t < GT; ++t)
@@ -436,8 +462,8 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                             u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
 #pragma unroll
                             for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, bcur[t][j]);
-                            if constexpr (FUSE) {
-                                if (tap == 13 && has3) {
+                            if constexpr (has3) {
+                                if (tap == 13) {
 #pragma unroll
                                     for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], a, w3res[j]);
                                 }
@@ -488,24 +514,25 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                         for (int j = 0; j < NTB; ++j)
                             if (okv[i][rr]) yrow[i][rr][j * 16] = acc[i][j][rr];
             }
-            if constexpr (FUSE) {
-                // partial-sum row of this (tile, wave): [b][((tz*nty + ty)*ntx + tx)*4 + wv][2][Cout]
-                const long prow = (((long)b * ntz + tz) * nty + ty) * ntx + tx;
-                tile_stats<NTB>(acc, okv, part + (prow * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
-                if (has3) {
+            if constexpr (FUSE) stats_add<NTB>(acc, okv, rs1, rs2);
+            if constexpr (has3) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int yo = y0 + i, xo = x0 + 4 * g + rr;
-                            float* q = y3 + ((((long)b * D + zo) * H + yo) * W + xo) * ldy3 + nt0 * 16 + r;
+                    for (int rr = 0; rr < 4; ++rr) {
+                        float* q = y3 + (yrow[i][rr] - y);          // same pitch as y (checked by the host)
 #pragma unroll
-                            for (int j = 0; j < NTB; ++j)
-                                if (okv[i][rr]) q[j * 16] = acc3[i][j][rr];
-                        }
-                    tile_stats<NTB>(acc3, okv, part3 + (prow * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
-                }
+                        for (int j = 0; j < NTB; ++j)
+                            if (okv[i][rr]) q[j * 16] = acc3[i][j][rr];
+                    }
+                stats_add<NTB>(acc3, okv, rt1, rt2);
             }
+        }
+    }
+    if constexpr (FUSE) {
+        if (cur_b >= 0) {
+            stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+            if constexpr (has3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
         }
     }
 }
@@ -745,11 +772,11 @@ int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st
     return unetr_check_launch();
 }
 
-struct FuseArgs { float* part; const void* wp3; float* y3; long ldy3; float* part3; };
+struct FuseArgs { float* part; const void* wp3; float* y3; long ldy3; float* part3; int rows; };
 
 template <class P>
 int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accumulate, int B, int D, int H, int W, int Cin, int Cout,
-          hipStream_t st, const FuseArgs* fz = nullptr) {
+          hipStream_t st, FuseArgs* fz = nullptr) {
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long spatial = (long)B * ntx * nty * ntz;
     const int ntn = Cout / 16;
@@ -769,11 +796,20 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
     hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, VEC_, FUSE_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
                        accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial, fz ? fz->part : nullptr,                       \
                        fz ? (const char*)fz->wp3 : nullptr, fz ? fz->y3 : nullptr, fz ? fz->ldy3 : 0, fz ? fz->part3 : nullptr)
+#define LAUNCH_PIPE_V(NTB_, PAIR_, FUSE_)                                                                                         \
+    do { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, FUSE_); else LAUNCH_PIPE_F(NTB_, PAIR_, false, FUSE_); } while (0)
 #define LAUNCH_PIPE(NTB_, PAIR_)                                                                                                  \
     do {                                                                                                                          \
-        if (fz) { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, true); else LAUNCH_PIPE_F(NTB_, PAIR_, false, true); }                \
-        else { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, false); else LAUNCH_PIPE_F(NTB_, PAIR_, false, false); }                 \
+        if (fz && fz->wp3) LAUNCH_PIPE_V(NTB_, PAIR_, 2);                                                                         \
+        else if (fz) LAUNCH_PIPE_V(NTB_, PAIR_, 1);                                                                               \
+        else LAUNCH_PIPE_V(NTB_, PAIR_, 0);                                                                                       \
     } while (0)
+        if (fz) {   // rows of the partial-sum buffers not visited by any wave must read as zero
+            fz->rows = (int)pgrid.x * 4;
+            const size_t nb = (size_t)B * fz->rows * 2 * Cout * sizeof(float);
+            (void)hipMemsetAsync(fz->part, 0, nb, st);
+            if (fz->wp3) (void)hipMemsetAsync(fz->part3, 0, nb, st);
+        }
         if constexpr (P::CH == 8) {
             if (pair) {
                 if (ntb == 1) LAUNCH_PIPE(1, true); else LAUNCH_PIPE(2, true);
@@ -873,20 +909,20 @@ extern "C" int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack
                                      float* ws, size_t ws_bytes, void* stream) {
     if (!x || !wpack || !y || !stats || B <= 0) return UNETR_ERR_ARG;
     if ((w3pack != nullptr) != (y3 != nullptr) || (w3pack != nullptr) != (stats3 != nullptr)) return UNETR_ERR_ARG;
-    if (Cout % 16) return UNETR_ERR_UNSUPPORTED;
+    if (Cout % 16 || (w3pack && ldy3 != ldy)) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int nchunk = cdiv(W, TX) * cdiv(H, TY) * cdiv(D, TZ) * 4;          // (tile, wave) partial rows per batch item
-    const size_t per = (size_t)B * nchunk * 2 * Cout;
+    const int max_rows = 512 * 4;                                            // (workgroup, wave) partial rows per batch item
+    const size_t per = (size_t)B * max_rows * 2 * Cout;
     if (!ws || per * (w3pack ? 2 : 1) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
-    FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr};
+    FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr, 0};
     int rc;
     if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
     else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
     else return UNETR_ERR_ARG;
     if (rc) return rc;
     const long V = (long)D * H * W;
-    rc = unetr_instnorm_stats_finalize(ws, nchunk, B, V, Cout, eps, stats, stream);
-    if (rc == UNETR_OK && w3pack) rc = unetr_instnorm_stats_finalize(ws + per, nchunk, B, V, Cout, eps, stats3, stream);
+    rc = unetr_instnorm_stats_finalize(ws, fz.rows, B, V, Cout, eps, stats, stream);
+    if (rc == UNETR_OK && w3pack) rc = unetr_instnorm_stats_finalize(ws + per, fz.rows, B, V, Cout, eps, stats3, stream);
     return rc;
 }
 

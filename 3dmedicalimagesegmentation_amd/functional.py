@@ -421,7 +421,8 @@ def conv3_fused(x, ldx, w, w3, dims, prec):
     (c, stats, c3, stats3) or None when the shape has to take the unfused kernels."""
     B, D, H, W = dims
     cout, cin = w.shape[0], w.shape[1]
-    if _use_gemm_conv() or cout % 16 != 0 or os.environ.get("UNETR_AMD_CONV_FUSE", "1") == "0":
+    level = int(os.environ.get("UNETR_AMD_CONV_FUSE", "2"))     # tuning hook: 0 unfused, 1 statistics only, 2 + 1x1x1 conv
+    if _use_gemm_conv() or cout % 16 != 0 or level == 0 or (w3 is not None and level < 2):
         return None
     lib = _capi.load()
     dev = x.device
@@ -700,8 +701,12 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec):
     if f1 is not None:
         c1, s1, c3, s3 = f1
     else:
-        c1 = conv3(x, ldx, w1, dims, prec)
-        s1 = instnorm_stats(c1, cout, B, V, cout)
+        f1 = conv3_fused(x, ldx, w1, None, dims, prec)
+        if f1 is not None:
+            c1, s1 = f1[0], f1[1]
+        else:
+            c1 = conv3(x, ldx, w1, dims, prec)
+            s1 = instnorm_stats(c1, cout, B, V, cout)
         c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
         gemm(x, w3, c3, B * V, cout, cin, lda=ldx, ldb=cin, ldc=cout, prec=prec)
         s3 = instnorm_stats(c3, cout, B, V, cout)
