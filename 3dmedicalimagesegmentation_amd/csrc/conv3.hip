@@ -552,42 +552,46 @@ __global__ void conv3_pack_1x1_kernel(const float* __restrict__ w3, T* __restric
 }
 
 // -------------------------------------------------------------------------------------- weight grad
-// workgroup = (voxel-tile group, 32-channel ci slab, 16-channel co tile); 54 (tap, ci-tile) units over 4 waves
-template <class P, bool HAS3 = false> struct WgCfg {
+// workgroup = (voxel-tile group, ci slab of CIS 16-channel tiles, 16-channel co tile); 27*CIS (tap, ci-tile) units over
+// 4 waves.  CIS = 1 for <= 16 input channels (the 96^3 layers): half the window bytes in LDS, half the transposing reads
+// and MFMAs of the 32-channel slab (whose upper ci-tile would be all zeros there).
+template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
     typedef typename ElemOf<P>::type T;
     static constexpr int ES = sizeof(T);
     // image pitches: 16 B of padding when it is free; with the second dy image (HAS3) in bf16 the padding is dropped
     // so that two workgroups still fit a CU (measured: 76 KB per workgroup = one workgroup per CU, 1.35x slower)
-    static constexpr int PX = 32 * ES + ((HAS3 && ES == 2) ? 0 : 16);   // halo image pitch (32 channels)
-    static constexpr int PY = 16 * ES + ((HAS3 && ES == 2) ? 8 : 16);   // dy image pitch (16 channels)
+    static constexpr int PX = 16 * CIS * ES + ((HAS3 && ES == 2) ? 0 : 16);   // halo image pitch (16*CIS channels)
+    static constexpr int PY = 16 * ES + ((HAS3 && ES == 2) ? 8 : 16);        // dy image pitch (16 channels)
     static constexpr int KV = 4 * P::CH;      // voxels per MFMA k-block (32 bf16 / 16 f32)
     static constexpr int NKB = NVOX / KV;
+    static constexpr int NU = 27 * CIS;                       // (tap, ci-tile) units
+    static constexpr int NUX = NU + (HAS3 ? CIS : 0);         // + centre-tap units fed by dy3 (the 1x1x1 conv)
+    static constexpr int UPW = (NUX + 3) / 4;                 // units per wave
 };
-constexpr int WG_UNITS = 54, WG_UPW = 14;  // units per wave (ceil(54/4))
 
-template <class P, bool VECX, bool VECY, bool HAS3>
-__global__ void __launch_bounds__(256)
+template <class P, bool VECX, bool VECY, bool HAS3, int CIS>
+__global__ void __launch_bounds__(256, CIS == 1 ? 3 : 1)     // CIS = 1: 41-43 KB of LDS -> three workgroups per CU if the registers allow
 conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
                    const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
                    int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
-    using C = WgCfg<P, HAS3>;
+    using C = WgCfg<P, HAS3, CIS>;
     typedef typename C::T T;
-    constexpr int CH = P::CH;
+    constexpr int CH = P::CH, WG_UNITS = C::NU, WG_UPW = C::UPW;
     // dy3 != nullptr: also accumulate the 1x1x1 conv's weight gradient dw3[co][ci] = sum_v dy3[v,co] x[v,ci] of the
-    // same residual block (MONAI UnetResBlock.conv3 shares its input with conv1): units 54/55 = centre tap fed by dy3.
+    // same residual block (MONAI UnetResBlock.conv3 shares its input with conv1): the extra units = centre tap fed by dy3.
     __shared__ __attribute__((aligned(16))) char lds[NHALO * C::PX + (HAS3 ? 2 : 1) * NVOX * C::PY];
     char* ximg = lds;
     char* yimg = lds + NHALO * C::PX;
     char* y3img = yimg + NVOX * C::PY;
-    const int nunits = HAS3 ? WG_UNITS + 2 : WG_UNITS;
+    constexpr int nunits = C::NUX;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 16;
+    const int ci0 = blockIdx.y * 16 * CIS, co0 = blockIdx.z * 16;
     // per-unit LDS byte offsets of the shifted window (wave-uniform)
     int uoff[WG_UPW];
 #pragma unroll
     for (int ui = 0; ui < WG_UPW; ++ui) {
         int u = wv + 4 * ui;
-        int tap = u >= WG_UNITS ? 13 : (u >> 1), cit = u & 1;      // units 54/55: centre tap (the 1x1x1 conv)
+        int tap = u >= WG_UNITS ? 13 : (u / CIS), cit = u >= WG_UNITS ? u - WG_UNITS : u % CIS;
         int dz = tap / 9, rem = tap - dz * 9, dyy = rem / 3, dx = rem - dyy * 3;
         uoff[ui] = ((dz * HY + dyy) * HX + dx) * C::PX + cit * 16 * C::ES;
     }
@@ -600,8 +604,10 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
         tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
-        stage_halo<P, 32 / CH, VECX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
-        // dy tile(s): 256 voxels x 16 channels, all loads of a thread in flight together
+        stage_halo<P, 16 * CIS / CH, VECX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
+        // dy tile(s): 256 voxels x 16 channels, all loads of a thread in flight together.  (Issuing these loads before the
+        // window batch -- one memory round trip per tile instead of two -- was measured: no gain at 16 input channels and
+        // the 32-channel-slab variants fall to one wave per SIMD.)
         auto stage_dy = [&](const float* __restrict__ src, long ld, char* img) {
             constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
             f32x4 buf[YIT][NQ];
@@ -703,7 +709,7 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
     for (int ui = 0; ui < WG_UPW; ++ui) {
         int u = wv + 4 * ui;
         if (u < nunits) {
-            int tap = u >> 1, cit = u & 1;
+            int tap = u / CIS, cit = u >= WG_UNITS ? u - WG_UNITS : u % CIS;
             int ci = ci0 + cit * 16 + c;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -847,9 +853,11 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
             int B, int D, int H, int W, int Cin, int Cout, float* ws, size_t ws_bytes, hipStream_t st) {
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long ntiles = (long)B * ntx * nty * ntz;
-    const int nci = cdiv(Cin, 32), nco = cdiv(Cout, 16);
+    const int cis = Cin <= 16 ? 1 : 2;
+    const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
-    long G = std::max<long>(1, 1024 / ((long)nci * nco));
+    // persistent workgroups: all of them resident at once (3 per CU with the 16-channel slab, else 2 rounds of 2 per CU)
+    long G = std::max<long>(1, (cis == 1 ? 768 : 1024) / ((long)nci * nco));
     G = std::min(G, ntiles);
     const long n3 = dy3 ? (long)Cin * Cout : 0;
     while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;
@@ -860,12 +868,13 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
     const int vecx = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
     const int vecy = (((uintptr_t)dy & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
     const bool vy = vecy && (!dy3 || vecy3);
+#define LAUNCH_WG_C(VX_, VY_, H3_, CIS_)                                                                                          \
+    hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, H3_, CIS_>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, \
+                       ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles)
 #define LAUNCH_WG(VX_, VY_)                                                                                                        \
     do {                                                                                                                           \
-        if (dy3) hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, true>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, \
-                                    lddy, ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);                      \
-        else hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, false>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy,  \
-                                lddy, ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);                          \
+        if (dy3) { if (cis == 1) LAUNCH_WG_C(VX_, VY_, true, 1); else LAUNCH_WG_C(VX_, VY_, true, 2); }                            \
+        else { if (cis == 1) LAUNCH_WG_C(VX_, VY_, false, 1); else LAUNCH_WG_C(VX_, VY_, false, 2); }                              \
     } while (0)
     if (vecx && vy) LAUNCH_WG(true, true);
     else if (vecx) LAUNCH_WG(true, false);

@@ -227,6 +227,10 @@ def main():
         try:
             from tools.roofline import encoder_forward_rate
             out["encoder_fwd"] = encoder_forward_rate(pkg, model, x, args.precision)
+            # the same encoder kernels at a token count where the GEMMs are throughput- rather than latency-bound
+            xb = x[:1].expand(32, -1, -1, -1, -1).contiguous()
+            out["encoder_fwd_batch32"] = encoder_forward_rate(pkg, model, xb, args.precision, iters=5)
+            del xb
         except Exception as e:  # noqa: BLE001
             out["encoder_fwd"] = {"error": f"{type(e).__name__}: {e}"}
     log("roofline done")

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd"])
+    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd", "tconv_fwd", "tconv_dgrad", "tconv_wgrad"])
     ap.add_argument("--cin", type=int, default=16)
     ap.add_argument("--cout", type=int, default=16)
     ap.add_argument("--size", type=int, default=96)
@@ -67,6 +67,17 @@ def main():
               "gemm": lambda: Fn.linear_fwd(x, w, None, prec), "gemm_dgrad": lambda: Fn.linear_dgrad(dy, w, prec),
               "gemm_wgrad": lambda: Fn.linear_wgrad(dy, x, prec)}[a.kernel]
         label = f"{a.kernel} M={M} N={N} K={K} {a.prec}"
+    elif a.kernel.startswith("tconv"):
+        x = torch.randn(B, S, S, S, a.cin, generator=g).to(dev)
+        w = (torch.randn(a.cin, a.cout, 2, 2, 2, generator=g) * 0.1).to(dev)
+        dy = torch.randn(B, 2 * S, 2 * S, 2 * S, a.cout, generator=g).to(dev)
+        dims = (B, S, S, S)
+        flops = 2.0 * v * a.cin * a.cout * 8
+        nbytes = 4.0 * v * (a.cin + 8 * a.cout)
+        fn = {"tconv_fwd": lambda: Fn.tconv_fwd(x, a.cin, w, dims, a.cin, a.cout, prec),
+              "tconv_dgrad": lambda: Fn.tconv_dgrad(dy, a.cout, w, dims, a.cin, a.cout, prec),
+              "tconv_wgrad": lambda: Fn.tconv_wgrad(x, a.cin, dy, a.cout, dims, a.cin, a.cout, prec)}[a.kernel]
+        label = f"{a.kernel} {a.cin}->{a.cout} @ {S}^3 B={B} {a.prec}"
     elif a.kernel == "instnorm":
         x = torch.randn(B, S, S, S, a.cout, generator=g).to(dev)
         flops, nbytes = 0.0, 4.0 * v * a.cout

@@ -42,8 +42,17 @@ def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
         cout_w, cin_w = w.shape[0], w.shape[1]
         cin, cout = (cin_w, cout_w) if mode == 0 else (cout_w, cin_w)
         nbytes = 4.0 * v * (cin + cout) + 4.0 * w.numel() + (4.0 * v * cout if accumulate else 0.0)
-        return ("conv3_fwd_kernel (3x3x3 LDS-halo implicit GEMM, " + ("dgrad" if mode else "fwd") + ")",
+        return ("conv3_fwd_pipe_kernel (3x3x3 LDS-halo implicit GEMM, " + ("dgrad" if mode else "fwd") + ")",
                 f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27, nbytes)
+
+    def fam_fused(xt, ldx, w, w3, dims, prec):
+        B, D, H, W = dims
+        v = B * D * H * W
+        cout, cin = w.shape[0], w.shape[1]
+        n3 = 1 if w3 is not None else 0
+        nbytes = 4.0 * v * (cin + cout * (1 + n3)) + 4.0 * w.numel() + (4.0 * w3.numel() if n3 else 0.0)
+        return ("conv3_fwd_pipe_kernel (3x3x3 LDS-halo implicit GEMM, fwd + InstanceNorm sums" + (" + 1x1x1 conv)" if n3 else ")"),
+                f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * (27 + n3), nbytes)
 
     def fam_wgrad(xt, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None):
         B, D, H, W = dims
@@ -51,7 +60,7 @@ def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
         return ("conv3_wgrad_kernel (+reduce)", f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27,
                 4.0 * v * (cin + cout) + 4.0 * cin * cout * 27)
 
-    saved = {"conv3": wrap("conv3", fam_conv3), "conv3_wgrad": wrap("conv3_wgrad", fam_wgrad)}
+    saved = {"conv3": wrap("conv3", fam_conv3), "conv3_wgrad": wrap("conv3_wgrad", fam_wgrad), "conv3_fused": wrap("conv3_fused", fam_fused)}
     try:
         for _ in range(reps):
             loss = crit(model(x), y)
@@ -93,7 +102,7 @@ def _pmc_traffic(fam, label, precision):
         d = json.load(open(path))
     except OSError:
         return None
-    if "conv3_fwd" in fam and ", fwd)" in fam and label.startswith("16->16 ch @ 96x96x96, B=2") and precision == "bf16":
+    if "conv3_fwd" in fam and d.get("family") == fam and label.startswith(d.get("shape", "?")) and precision == "bf16":
         return d.get("traffic_bytes_per_launch")
     return None
 
@@ -136,4 +145,6 @@ def encoder_forward_rate(pkg, model, x_in, precision, iters=10):
     tf = flops / (ms * 1e-3) / 1e12
     peak = MFMA_PEAK_TFLOPS[precision]
     return {"batch": B, "ms": round(ms, 4), "TFLOP/s": round(tf, 2), "peak_TFLOP/s": peak, "frac_of_mfma_peak": round(tf / peak, 5),
-            "algorithmic_flops": flops, "note": "batch 2 = 432 token rows per GEMM: launch/latency-bound, not MFMA-bound"}
+            "algorithmic_flops": flops,
+            "note": (f"batch {B} = {B * L} token rows per GEMM: launch/latency-bound, not MFMA-bound" if B * L < 2048 else
+                     f"batch {B} = {B * L} token rows per GEMM")}
