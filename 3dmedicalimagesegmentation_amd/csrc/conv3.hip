@@ -234,12 +234,22 @@ template <class P, int NCH>
 struct HaloRegs {
     static constexpr int ITERS = (NHALO * NCH + 255) / 256;
     f32x4 v[ITERS][P::CH / 4];
+    unsigned okbits;          // VEC path: bit (j * CH/4 + c4) = this 16-byte piece is inside the volume / channel range
 };
 
+// Window loads into registers.  VEC path: the element offset inside the batch item is 32-bit (the host rejects feature
+// maps of >= 2^31 elements per item) on top of a wave-uniform 64-bit base; out-of-window pieces read element 0 of the item
+// and are zeroed in halo_store from the okbits mask.  Nothing here depends on the loaded values, so the loads stay in
+// flight across the MFMA phase that follows (a select / multiply right after the load is either turned back into a
+// conditional load behind an exec-mask branch with 64-bit address arithmetic, or waits for the data before the MFMAs).
 template <class P, int NCH, bool VEC>
 __device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0,
                                           int D, int H, int W, int c0, int Cin) {
     constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
+    static_assert(HaloRegs<P, NCH>::ITERS * NQ <= 32, "okbits is one 32-bit mask");
+    const float* __restrict__ xb = x + (long)b * D * H * W * ldx;
+    const int ld32 = (int)ldx;
+    unsigned bits = 0;
 #pragma unroll
     for (int j = 0; j < HaloRegs<P, NCH>::ITERS; ++j) {
         const int id = threadIdx.x + j * 256;
@@ -248,23 +258,29 @@ __device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const float* __re
         const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
         const int c = c0 + ch * CH;
         const bool ok = id < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin;
-        const float* q = ok ? x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + c : x;   // branch-free (see stage_halo)
+        if constexpr (VEC) {
+            const int off = ok ? ((gz * H + gy) * W + gx) * ld32 + c : 0;
 #pragma unroll
-        for (int c4 = 0; c4 < NQ; ++c4) {
-            if constexpr (VEC) {
+            for (int c4 = 0; c4 < NQ; ++c4) {
                 const bool okc = ok && c + 4 * c4 + 4 <= Cin;
-                f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : x);
-                R.v[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-            } else {
+                R.v[j][c4] = *(const f32x4*)(xb + (off + (okc ? 4 * c4 : 0)));
+                bits |= okc ? (1u << (j * NQ + c4)) : 0u;
+            }
+        } else {
+            const float* q = ok ? xb + (((long)gz * H + gy) * W + gx) * ldx + c : xb;
+#pragma unroll
+            for (int c4 = 0; c4 < NQ; ++c4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool oke = ok && c + 4 * c4 + e < Cin;
-                    float t = *(oke ? q + 4 * c4 + e : x);
+                    float t = *(oke ? q + 4 * c4 + e : xb);
                     R.v[j][c4][e] = oke ? t : 0.f;
                 }
             }
+            bits = 0xffffffffu;
         }
     }
+    R.okbits = bits;
 }
 
 template <class P, int NCH>
@@ -278,7 +294,11 @@ __device__ __forceinline__ void halo_store(const HaloRegs<P, NCH>& R, int pitch,
             float v[CH];
 #pragma unroll
             for (int c4 = 0; c4 < NQ; ++c4) { v[4 * c4] = R.v[j][c4][0]; v[4 * c4 + 1] = R.v[j][c4][1]; v[4 * c4 + 2] = R.v[j][c4][2]; v[4 * c4 + 3] = R.v[j][c4][3]; }
-            *(u32x4*)(halo + hv * pitch + ch * 16) = P::pack(v);
+            u32x4 w = P::pack(v);
+            // zero the out-of-window pieces on the PACKED words (dword d holds elements of piece d * NQ / 4)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) w[d] = ((R.okbits >> (j * NQ + d * NQ / 4)) & 1u) ? w[d] : 0u;
+            *(u32x4*)(halo + hv * pitch + ch * 16) = w;
         }
     }
 }
@@ -569,8 +589,8 @@ template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
     static constexpr int UPW = (NUX + 3) / 4;                 // units per wave
 };
 
-template <class P, bool VECX, bool VECY, bool HAS3, int CIS>
-__global__ void __launch_bounds__(256, CIS == 1 ? 3 : 1)     // CIS = 1: 41-43 KB of LDS -> three workgroups per CU if the registers allow
+template <class P, bool VECX, bool VECY, bool HAS3, int CIS, bool PIPE_OK>
+__global__ void __launch_bounds__(256, CIS == 1 ? 3 : 1)   // CIS = 1: 41-43 KB of LDS -> three workgroups per CU
 conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
                    const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
                    int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
@@ -599,55 +619,84 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
 #pragma unroll
     for (int ui = 0; ui < WG_UPW; ++ui) acc[ui] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // dy tile(s): 256 voxels x 16 channels
+    constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
+    auto load_dy = [&](const float* __restrict__ src, long ld, int b, int z0, int y0, int x0, f32x4 (&buf)[YIT][NQ]) {
+#pragma unroll
+        for (int j = 0; j < YIT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = id / YCH, ch = id - v * YCH;
+            const int gz = z0 + (v >> 6), gy = y0 + ((v >> 4) & 3), gx = x0 + (v & 15);
+            const int cc = co0 + ch * CH;
+            const bool ok = gz < D && gy < H && gx < W && cc < Cout;
+            const float* q = ok ? src + ((((long)b * D + gz) * H + gy) * W + gx) * ld + cc : src;   // branch-free
+#pragma unroll
+            for (int c4 = 0; c4 < NQ; ++c4) {
+                if constexpr (VECY) {
+                    const bool okc = ok && cc + 4 * c4 + 4 <= Cout;
+                    f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : src);
+                    buf[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool oke = ok && cc + 4 * c4 + e < Cout;
+                        float t = *(oke ? q + 4 * c4 + e : src);
+                        buf[j][c4][e] = oke ? t : 0.f;
+                    }
+                }
+            }
+        }
+    };
+    auto store_dy = [&](const f32x4 (&buf)[YIT][NQ], char* img) {
+#pragma unroll
+        for (int j = 0; j < YIT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = id / YCH, ch = id - v * YCH;
+            float vals[CH];
+#pragma unroll
+            for (int c4 = 0; c4 < NQ; ++c4) { vals[4 * c4] = buf[j][c4][0]; vals[4 * c4 + 1] = buf[j][c4][1]; vals[4 * c4 + 2] = buf[j][c4][2]; vals[4 * c4 + 3] = buf[j][c4][3]; }
+            *(u32x4*)(img + v * C::PY + ch * 16) = P::pack(vals);
+        }
+    };
+    // PIPE (16-channel slab only: the prefetch registers fit next to two resident workgroups per CU): the window and dy
+    // tile of the NEXT tile are loaded into registers while the MFMAs of the current one run.
+    constexpr bool PIPE = CIS == 1 && PIPE_OK;
+    HaloRegs<P, PIPE ? 16 / CH : 1> R;
+    f32x4 ybuf[YIT][NQ], y3buf[HAS3 ? YIT : 1][NQ];
+    if constexpr (PIPE) {
+        if ((int)blockIdx.x < ntiles) {
+            int tx, ty, tz, b;
+            tile_coords(blockIdx.x, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+            halo_load<P, 16 / CH, VECX>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, ci0, Cin);
+            load_dy(dy, lddy, b, tz * TZ, ty * TY, tx * TX, ybuf);
+            if constexpr (HAS3) load_dy(dy3, lddy3, b, tz * TZ, ty * TY, tx * TX, y3buf);
+        }
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int tx, ty, tz, b;
         tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
-        stage_halo<P, 16 * CIS / CH, VECX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
-        // dy tile(s): 256 voxels x 16 channels, all loads of a thread in flight together.  (Issuing these loads before the
-        // window batch -- one memory round trip per tile instead of two -- was measured: no gain at 16 input channels and
-        // the 32-channel-slab variants fall to one wave per SIMD.)
-        auto stage_dy = [&](const float* __restrict__ src, long ld, char* img) {
-            constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
-            f32x4 buf[YIT][NQ];
-#pragma unroll
-            for (int j = 0; j < YIT; ++j) {
-                const int id = threadIdx.x + j * 256;
-                const int v = id / YCH, ch = id - v * YCH;
-                const int gz = z0 + (v >> 6), gy = y0 + ((v >> 4) & 3), gx = x0 + (v & 15);
-                const int cc = co0 + ch * CH;
-                const bool ok = gz < D && gy < H && gx < W && cc < Cout;
-                const float* q = ok ? src + ((((long)b * D + gz) * H + gy) * W + gx) * ld + cc : src;   // branch-free
-#pragma unroll
-                for (int c4 = 0; c4 < NQ; ++c4) {
-                    if constexpr (VECY) {
-                        const bool okc = ok && cc + 4 * c4 + 4 <= Cout;
-                        f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : src);
-                        buf[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bool oke = ok && cc + 4 * c4 + e < Cout;
-                            float t = *(oke ? q + 4 * c4 + e : src);
-                            buf[j][c4][e] = oke ? t : 0.f;
-                        }
-                    }
-                }
+        if constexpr (PIPE) {
+            halo_store<P, 16 / CH>(R, C::PX, ximg);
+            store_dy(ybuf, yimg);
+            if constexpr (HAS3) store_dy(y3buf, y3img);
+            __syncthreads();
+            const int nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                int ax, ay, az, ab;
+                tile_coords(nt, ntiles, ntx, nty, ntz, ax, ay, az, ab);
+                halo_load<P, 16 / CH, VECX>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, ci0, Cin);
+                load_dy(dy, lddy, ab, az * TZ, ay * TY, ax * TX, ybuf);
+                if constexpr (HAS3) load_dy(dy3, lddy3, ab, az * TZ, ay * TY, ax * TX, y3buf);
             }
-#pragma unroll
-            for (int j = 0; j < YIT; ++j) {
-                const int id = threadIdx.x + j * 256;
-                const int v = id / YCH, ch = id - v * YCH;
-                float vals[CH];
-#pragma unroll
-                for (int c4 = 0; c4 < NQ; ++c4) { vals[4 * c4] = buf[j][c4][0]; vals[4 * c4 + 1] = buf[j][c4][1]; vals[4 * c4 + 2] = buf[j][c4][2]; vals[4 * c4 + 3] = buf[j][c4][3]; }
-                *(u32x4*)(img + v * C::PY + ch * 16) = P::pack(vals);
-            }
-        };
-        stage_dy(dy, lddy, yimg);
-        if constexpr (HAS3) stage_dy(dy3, lddy3, y3img);
-        __syncthreads();
+        } else {
+            stage_halo<P, 16 * CIS / CH, VECX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
+            load_dy(dy, lddy, b, z0, y0, x0, ybuf);
+            store_dy(ybuf, yimg);
+            if constexpr (HAS3) { load_dy(dy3, lddy3, b, z0, y0, x0, y3buf); store_dy(y3buf, y3img); }
+            __syncthreads();
+        }
 
         for (int kb = 0; kb < C::NKB; ++kb) {
             if constexpr (CH == 8) {
@@ -723,22 +772,31 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
     }
 }
 
-// dw[i] = sum_g part[g][i]: 16 outputs x 16 g-phases per workgroup, fixed summation order (reproducible)
+// dw[i] = sum_g part[g][i]: 32 outputs x 8 g-phases per workgroup, fixed summation order (reproducible); eight loads of
+// a phase are in flight together (the slabs sit in L2: the pass is latency-, not bandwidth-bound)
 __global__ void __launch_bounds__(256)
 conv3_wgrad_reduce_kernel(const float* __restrict__ part, int G, long n, float* __restrict__ dw) {
-    __shared__ float sm[16][17];
-    const int o = threadIdx.x & 15, ph = threadIdx.x >> 4;
-    for (long i0 = (long)blockIdx.x * 16; i0 < n; i0 += (long)gridDim.x * 16) {
+    __shared__ float sm[8][33];
+    const int o = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    for (long i0 = (long)blockIdx.x * 32; i0 < n; i0 += (long)gridDim.x * 32) {
         const long i = i0 + o;
         float s = 0.f;
-        if (i < n)
-            for (int gI = ph; gI < G; gI += 16) s += part[(long)gI * n + i];
+        if (i < n) {
+            int gI = ph;
+            for (; gI + 56 < G; gI += 64) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = part[(long)(gI + 8 * u) * n + i];
+                s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
+            for (; gI < G; gI += 8) s += part[(long)gI * n + i];
+        }
         sm[ph][o] = s;
         __syncthreads();
         if (ph == 0 && i < n) {
             float t = 0.f;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) t += sm[p][o];
+            for (int p = 0; p < 8; ++p) t += sm[p][o];
             dw[i] = t;
         }
         __syncthreads();
@@ -792,6 +850,7 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
         while (ntb > 1 && spatial * (ntn / ntb) < 512) ntb >>= 1;
     }
     const int vec = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
+    if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
     if (conv_pipe_enabled() && ntb <= 4) {
         // persistent, software-pipelined kernel: a few resident workgroups per CU walk the tiles
         const bool pair = use_pair<P>(Cin);
@@ -853,6 +912,7 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
             int B, int D, int H, int W, int Cin, int Cout, float* ws, size_t ws_bytes, hipStream_t st) {
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long ntiles = (long)B * ntx * nty * ntz;
+    if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
     const int cis = Cin <= 16 ? 1 : 2;
     const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
@@ -869,7 +929,7 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
     const int vecy = (((uintptr_t)dy & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
     const bool vy = vecy && (!dy3 || vecy3);
 #define LAUNCH_WG_C(VX_, VY_, H3_, CIS_)                                                                                          \
-    hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, H3_, CIS_>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, \
+    hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, H3_, CIS_, (CIS_ == 1)>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, \
                        ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles)
 #define LAUNCH_WG(VX_, VY_)                                                                                                        \
     do {                                                                                                                           \
@@ -880,9 +940,9 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
     else if (vecx) LAUNCH_WG(true, false);
     else if (vy) LAUNCH_WG(false, true);
     else LAUNCH_WG(false, false);
-    int blocks = (int)std::min<long>((n + 15) / 16, 16384);
+    int blocks = (int)std::min<long>((n + 31) / 32, 16384);
     hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, (int)G, n, dw);
-    if (dy3) hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((int)std::min<long>((n3 + 15) / 16, 16384)), dim3(256), 0, st, ws3, (int)G, n3, dw3);
+    if (dy3) hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((int)std::min<long>((n3 + 31) / 32, 16384)), dim3(256), 0, st, ws3, (int)G, n3, dw3);
     return unetr_check_launch();
 }
 
