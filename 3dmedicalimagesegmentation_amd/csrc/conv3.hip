@@ -347,10 +347,13 @@ __device__ __forceinline__ void stats_flush(float (&s1)[NTB], float (&s2)[NTB], 
 // FUSE >= 1: besides y = conv3x3x3(x) the kernel emits part = InstanceNorm partial sums of y (the separate statistics
 //   pass over y disappears; the partial buffer must be zero-filled before the launch);
 // FUSE == 2: also y3 = conv1x1x1(x) with weights wp3 and its partial sums part3: MONAI's UnetResBlock.conv3 reads the same
-//   input as conv1, i.e. the centre tap of the window already staged in LDS (one extra MFMA per 16 voxels).
+//   input as conv1, i.e. the centre tap of the window already staged in LDS (one extra MFMA per 16 voxels);
+// FUSE == 3: the same for a single-slab window (Cin <= 32 bf16 / 16 fp32, not PAIR): the 1x1x1 product is formed AFTER the
+//   tile's 3x3x3 result has been stored, re-reading the centre tap from the still-resident window, so the two accumulator
+//   sets are never live together and the kernel keeps two waves per SIMD (FUSE == 2 on this path needs 364 registers).
 // two resident waves per SIMD (256 registers) is requested only where the variant fits without scratch
 template <class P, int NTB, bool PAIR, bool VEC, int FUSE>
-__global__ void __launch_bounds__(256, (FUSE == 2 ? (PAIR && NTB == 1) : (FUSE == 1 && (NTB == 1 || (!PAIR && NTB == 2)))) ? 2 : 1)
+__global__ void __launch_bounds__(256, (FUSE == 2 ? (PAIR && NTB == 1) : (FUSE == 3 ? NTB == 1 : (FUSE == 1 && (NTB == 1 || (!PAIR && NTB == 2))))) ? 2 : 1)
 conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
                       int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles,
                       float* __restrict__ part, const char* __restrict__ wp3, float* __restrict__ y3, long ldy3,
@@ -369,18 +372,18 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
             for (int j = 0; j < NTB; ++j) wres[tp][j] = *(const u32x4*)(wp + ((long)tp * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
     }
 
-    constexpr bool has3 = FUSE == 2;
-    u32x4 w3res[has3 ? NTB : 1];   // 1x1x1 weights: PAIR keeps them for the whole launch, the slab path reloads them per slab
-    if constexpr (has3 && PAIR) {
+    constexpr bool has3 = FUSE == 2, late3 = FUSE == 3, any3 = has3 || late3;
+    u32x4 w3res[any3 ? NTB : 1];   // 1x1x1 weights: PAIR / single-slab keep them for the whole launch, else reloaded per slab
+    if constexpr ((has3 && PAIR) || late3) {
 #pragma unroll
         for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)(nt0 + j) * 16 + r) * 64 + g * 16);
     }
-    float rs1[FUSE ? NTB : 1], rs2[FUSE ? NTB : 1], rt1[has3 ? NTB : 1], rt2[has3 ? NTB : 1];
+    float rs1[FUSE ? NTB : 1], rs2[FUSE ? NTB : 1], rt1[any3 ? NTB : 1], rt2[any3 ? NTB : 1];
     if constexpr (FUSE) {
 #pragma unroll
         for (int j = 0; j < NTB; ++j) { rs1[j] = 0.f; rs2[j] = 0.f; }
     }
-    if constexpr (has3) {
+    if constexpr (any3) {
 #pragma unroll
         for (int j = 0; j < NTB; ++j) { rt1[j] = 0.f; rt2[j] = 0.f; }
     }
@@ -411,7 +414,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
             if (b != cur_b) {
                 if (cur_b >= 0) {
                     stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
-                    if constexpr (has3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+                    if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
                 }
                 cur_b = b;
             }
@@ -547,12 +550,36 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                     }
                 stats_add<NTB>(acc3, okv, rt1, rt2);
             }
+            if constexpr (late3) {
+                // the window of this tile is still in LDS (the next halo_store waits behind the barrier at the loop top)
+                const char* hbase = halo + ((((wv + 1) * HY + 1) * HX) + (r + 1)) * PITCH + g * 16;      // centre tap
+                f32x4 a3[4][NTB];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) {
+                        a3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        P::mma(a3[i][j], a, w3res[j]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        float* q = y3 + (yrow[i][rr] - y);
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j)
+                            if (okv[i][rr]) q[j * 16] = a3[i][j][rr];
+                    }
+                stats_add<NTB>(a3, okv, rt1, rt2);
+            }
         }
     }
     if constexpr (FUSE) {
         if (cur_b >= 0) {
             stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
-            if constexpr (has3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+            if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
         }
     }
 }
@@ -865,10 +892,14 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
     do { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, FUSE_); else LAUNCH_PIPE_F(NTB_, PAIR_, false, FUSE_); } while (0)
 #define LAUNCH_PIPE(NTB_, PAIR_)                                                                                                  \
     do {                                                                                                                          \
+        if constexpr (!(PAIR_)) {                                                                                                 \
+            if (fz && fz->wp3 && late1x1) { LAUNCH_PIPE_V(NTB_, false, 3); break; }                                               \
+        }                                                                                                                         \
         if (fz && fz->wp3) LAUNCH_PIPE_V(NTB_, PAIR_, 2);                                                                         \
         else if (fz) LAUNCH_PIPE_V(NTB_, PAIR_, 1);                                                                               \
         else LAUNCH_PIPE_V(NTB_, PAIR_, 0);                                                                                       \
     } while (0)
+        const bool late1x1 = Cin <= 4 * P::CH;      // single-slab window: the 1x1x1 product is formed after the tile (FUSE 3)
         if (fz) {   // rows of the partial-sum buffers not visited by any wave must read as zero
             fz->rows = (int)pgrid.x * 4;
             const size_t nb = (size_t)B * fz->rows * 2 * Cout * sizeof(float);

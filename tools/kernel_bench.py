@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd", "tconv_fwd", "tconv_dgrad", "tconv_wgrad"])
+    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_fused", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd", "tconv_fwd", "tconv_dgrad", "tconv_wgrad"])
     ap.add_argument("--cin", type=int, default=16)
     ap.add_argument("--cout", type=int, default=16)
     ap.add_argument("--size", type=int, default=96)
@@ -46,7 +46,13 @@ def main():
         dy = torch.randn(B, S, S, S, a.cout, generator=g).to(dev)
         flops = 2.0 * v * a.cin * a.cout * 27
         nbytes = 4.0 * v * (a.cin + a.cout) + 4.0 * w.numel()
-        if a.kernel == "conv3_fwd":
+        if a.kernel == "conv3_fused":     # residual-block front: 3x3x3 conv + InstanceNorm sums + 1x1x1 conv on the same window
+            w3 = (torch.randn(a.cout, a.cin, 1, 1, 1, generator=g) * 0.2).to(dev)
+            fn = lambda: Fn.conv3_fused(x, a.cin, w, w3, (B, S, S, S), prec)
+            nbytes = 4.0 * v * (a.cin + 2 * a.cout) + 4.0 * (w.numel() + w3.numel())
+            flops = 2.0 * v * a.cin * a.cout * 28
+            label = f"conv3_fused(+IN sums +1x1) {a.cin}->{a.cout} @ {S}^3 B={B} {a.prec}"
+        elif a.kernel == "conv3_fwd":
             fn = lambda: Fn.conv3(x, a.cin, w, dims, prec)
         elif a.kernel == "conv3_dgrad":
             fn = lambda: Fn.conv3(dy, a.cout, w, dims, prec, mode=1)

@@ -8,15 +8,17 @@ cd /tmp; export TMPDIR=/tmp
 # KERNEL / FILTER select the kernel_bench mode and the kernel-name substring (default: the 16->16 @ 96^3 forward conv)
 KERNEL=${KERNEL:-conv3_fwd}
 FILTER=${FILTER:-conv3_fwd}
-ARGS="$KERNEL --cin 16 --cout 16 --size 96 --batch 2 --prec bf16 --iters 3 --warmup 1"
-python3 $R/tools/kernel_bench.py $KERNEL --cin 16 --cout 16 --size 96 --batch 2 --prec bf16 --iters 20 --graph > $O/time.json 2>/dev/null
+CIN=${CIN:-16}
+COUT=${COUT:-16}
+ARGS="$KERNEL --cin $CIN --cout $COUT --size 96 --batch 2 --prec bf16 --iters 3 --warmup 1"
+python3 $R/tools/kernel_bench.py $KERNEL --cin $CIN --cout $COUT --size 96 --batch 2 --prec bf16 --iters 20 --graph > $O/time.json 2>/dev/null
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   T=$(echo $C | cut -d' ' -f1)
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$T -- python3 $R/tools/kernel_bench.py $ARGS > $O/$T.log 2>&1 || echo "pmc $T failed"
 done
 python3 - <<PY
 import csv, glob, json, collections
-out = {"command": "tools/kernel_bench.py $ARGS", "kernel_filter": "$FILTER"}
+out = {"command": "tools/kernel_bench.py $ARGS", "kernel_filter": "$FILTER", "family": """${FAMILY:-}""", "shape": """${SHAPE:-}"""}
 out["time"] = json.load(open("$O/time.json"))
 for d in ["FETCH_SIZE", "WRITE_SIZE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU"]:
     for f in glob.glob(f"$O/{d}/*/*_counter_collection.csv"):
