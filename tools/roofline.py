@@ -92,18 +92,22 @@ def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
 
 
 def _pmc_traffic(fam, label, precision):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (tools/pmc_conv3.sh:
-    FETCH_SIZE x 2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE, separate passes), when it is the same
-    kernel / shape / precision; otherwise null."""
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary (tools/pmc_conv3.sh:
+    FETCH_SIZE x 2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE, separate passes) whose "family" / "shape"
+    keys name the same kernel group; otherwise null."""
+    import glob
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_conv3_fwd_16to16_96cube.json")
-    try:
-        d = json.load(open(path))
-    except OSError:
+    if precision != "bf16":
         return None
-    if "conv3_fwd" in fam and d.get("family") == fam and label.startswith(d.get("shape", "?")) and precision == "bf16":
-        return d.get("traffic_bytes_per_launch")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    for path in sorted(glob.glob(os.path.join(root, "r*_pmc_*.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("family") == fam and d.get("shape") and label.startswith(d["shape"]):
+            return d.get("traffic_bytes_per_launch")
     return None
 
 
