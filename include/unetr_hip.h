@@ -97,6 +97,22 @@ int unetr_tconv_dgrad(const float* dy, long ldy, const float* w, float* dx, long
 int unetr_tconv_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
                       int B, int D, int H, int W, int Cin, int Cout, int prec,
                       float* ws, size_t ws_bytes, void* stream);
+/* Dedicated kernels for the same transposed conv at large-volume / small-channel layers (persistent workgroups over
+ * 64-voxel tiles, LDS table of output-voxel bases, dy gathered voxel-major and read through transposing LDS loads).
+ * Same arguments and results as unetr_tconv_fwd / unetr_tconv_wgrad; return "unsupported" (3) for shapes outside their
+ * range (M = B*D*H*W < 2048, channel counts, alignment) -- the caller then uses the generic entry points above. */
+int unetr_tconv2_fwd(const float* x, long ldx, const float* w, float* y, long ldy,
+                     int B, int D, int H, int W, int Cin, int Cout, int prec,
+                     float* ws, size_t ws_bytes, void* stream);
+int unetr_tconv2_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+                       int B, int D, int H, int W, int Cin, int Cout, int prec,
+                       float* ws, size_t ws_bytes, void* stream);
+int unetr_tconv2_dgrad(const float* dy, long ldy, const float* w, float* dx, long ldx, int accumulate,
+                       int B, int D, int H, int W, int Cin, int Cout, int prec,
+                       float* ws, size_t ws_bytes, void* stream);
+int unetr_tconv2_fwd_supported(long M, int Cin, int Cout, long ldx, long ldy);
+int unetr_tconv2_wgrad_supported(long M, int Cin, int Cout, long ldx, long lddy);
+
 
 /* ---- column sums: out[n] (+)= sum_m x[m*ld+n]  (bias / position-embedding gradients) ---------------- */
 int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate,

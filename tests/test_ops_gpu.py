@@ -156,7 +156,9 @@ def ncdhw(x):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("B,S,cin,cout", [(2, 6, 768, 32), (1, 5, 32, 16), (2, 12, 64, 64)])
+@pytest.mark.parametrize("B,S,cin,cout", [(2, 6, 768, 32), (1, 5, 32, 16), (2, 12, 64, 64),
+                                          # shapes the dedicated tconv2 kernels take (>= 2048 input voxels, small channel counts):
+                                          (2, 16, 32, 16), (1, 17, 16, 8), (1, 13, 64, 32), (1, 16, 48, 24), (2, 12, 32, 32), (1, 14, 16, 64)])
 def test_tconv(pkg, dev, prec, B, S, cin, cout):
     Fn = pkg.functional
     x, w, dy = g(B, cin, S, S, S, seed=1), g(cin, cout, 2, 2, 2, seed=2, scale=0.1), g(B, cout, 2 * S, 2 * S, 2 * S, seed=3)
