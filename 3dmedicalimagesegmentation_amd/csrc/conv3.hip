@@ -944,7 +944,10 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long ntiles = (long)B * ntx * nty * ntz;
     if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
-    const int cis = Cin <= 16 ? 1 : 2;
+    // 16-channel slabs everywhere (measured: 32->16 @ 96^3 200 -> 170 us, 64->32 @ 48^3 133 -> 88 us, step -0.16 ms): the dy tile is
+    // re-staged once per slab, but three pipelined workgroups per CU beat two with the 32-channel window.  UNETR_WG_CIS1 = largest
+    // Cin that still takes the 16-channel variant (tuning hook).
+    const int cis = Cin <= (getenv("UNETR_WG_CIS1") ? atoi(getenv("UNETR_WG_CIS1")) : (1 << 30)) ? 1 : 2;
     const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
     // persistent workgroups: all of them resident at once (3 per CU with the 16-channel slab, else 2 rounds of 2 per CU)
