@@ -75,6 +75,7 @@ _SIGNATURES = {
     "unetr_conv3_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd_fused": [P, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_dgrad_fused": [P, c_long, P, P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_pack_1x1": [P, P, c_int, c_int, c_int, P],
     "unetr_instnorm_stats_finalize": [P, c_int, c_int, c_long, c_int, c_float, P, P],
     "unetr_conv3_wgrad": [P, c_long, P, c_long, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],

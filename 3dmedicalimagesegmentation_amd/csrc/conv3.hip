@@ -352,12 +352,16 @@ __device__ __forceinline__ void stats_flush(float (&s1)[NTB], float (&s2)[NTB], 
 //   tile's 3x3x3 result has been stored, re-reading the centre tap from the still-resident window, so the two accumulator
 //   sets are never live together and the kernel keeps two waves per SIMD (FUSE == 2 on this path needs 364 registers).
 // two resident waves per SIMD (256 registers) is requested only where the variant fits without scratch
+// FUSE == 4 (data-gradient side of the same block): y += x3 . w3 with a SECOND input x3 ([voxels, K3], e.g. the gradient of
+//   the 1x1x1 branch) multiplied by a 1x1x1 weight matrix in the tile epilogue: dx = conv3x3x3^T(dc1) + conv1x1x1^T(dc3) in
+//   one pass, instead of a GEMM writing dx followed by an accumulating conv that re-reads it.  x3 fragments are loaded
+//   straight from global memory in MFMA operand shape (16 voxels x one 16-byte chunk per lane group).
 template <class P, int NTB, bool PAIR, bool VEC, int FUSE>
 __global__ void __launch_bounds__(256, (FUSE == 2 ? (PAIR && NTB == 1) : (FUSE == 3 ? NTB == 1 : (FUSE == 1 && (NTB == 1 || (!PAIR && NTB == 2))))) ? 2 : 1)
 conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
                       int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles,
                       float* __restrict__ part, const char* __restrict__ wp3, float* __restrict__ y3, long ldy3,
-                      float* __restrict__ part3) {
+                      float* __restrict__ part3, int K3) {
     constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16 + 16;
     __shared__ __attribute__((aligned(16))) char halo[NHALO * PITCH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -378,8 +382,9 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
 #pragma unroll
         for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)(nt0 + j) * 16 + r) * 64 + g * 16);
     }
-    float rs1[FUSE ? NTB : 1], rs2[FUSE ? NTB : 1], rt1[any3 ? NTB : 1], rt2[any3 ? NTB : 1];
-    if constexpr (FUSE) {
+    constexpr bool STATS = FUSE >= 1 && FUSE <= 3;
+    float rs1[STATS ? NTB : 1], rs2[STATS ? NTB : 1], rt1[any3 ? NTB : 1], rt2[any3 ? NTB : 1];
+    if constexpr (STATS) {
 #pragma unroll
         for (int j = 0; j < NTB; ++j) { rs1[j] = 0.f; rs2[j] = 0.f; }
     }
@@ -410,7 +415,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if constexpr (has3) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-        if constexpr (FUSE) {
+        if constexpr (STATS) {
             if (b != cur_b) {
                 if (cur_b >= 0) {
                     stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
@@ -514,6 +519,35 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                     okv[i][rr] = zo < D && yo < H && xo < W;
                     yrow[i][rr] = okv[i][rr] ? y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r : y + nt0 * 16 + r;
                 }
+            if constexpr (FUSE == 4) {
+                // acc += x3[voxel, :] . w3: A rows = the 16 x-positions of output row i (lane r), chunk g of each 64-byte k-block
+                const float* x3 = y3;
+                const int n3 = (K3 + 4 * CH - 1) / (4 * CH);
+                for (int kb = 0; kb < n3; ++kb) {
+                    u32x4 w3f[NTB];
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) w3f[j] = *(const u32x4*)(wp3 + ((long)kb * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
+                    const int c3 = kb * 4 * CH + g * CH;
+                    float av[4][CH];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int yo = y0 + i, xo = x0 + r;
+                        const bool ok = zo < D && yo < H && xo < W && c3 + CH <= K3;
+                        const float* q = x3 + (ok ? ((((long)b * D + zo) * H + yo) * W + xo) * ldy3 + c3 : 0);
+#pragma unroll
+                        for (int e = 0; e < CH / 4; ++e) {
+                            const f32x4 t = *(const f32x4*)(q + 4 * e);
+                            av[i][4 * e] = ok ? t[0] : 0.f; av[i][4 * e + 1] = ok ? t[1] : 0.f; av[i][4 * e + 2] = ok ? t[2] : 0.f; av[i][4 * e + 3] = ok ? t[3] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 a = P::pack(av[i]);
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, w3f[j]);
+                    }
+                }
+            }
             if (accumulate) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -537,7 +571,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                         for (int j = 0; j < NTB; ++j)
                             if (okv[i][rr]) yrow[i][rr][j * 16] = acc[i][j][rr];
             }
-            if constexpr (FUSE) stats_add<NTB>(acc, okv, rs1, rs2);
+            if constexpr (STATS) stats_add<NTB>(acc, okv, rs1, rs2);
             if constexpr (has3) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -576,7 +610,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
             }
         }
     }
-    if constexpr (FUSE) {
+    if constexpr (STATS) {
         if (cur_b >= 0) {
             stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
             if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
@@ -586,14 +620,15 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
 
 // 1x1x1 weights w3[Cout][Cin] in the B-fragment layout the fused kernel reads at the centre tap:
 // pair mode: wp3[n][32], k = 16 + ci (the tap-13 half of pair 6), zero elsewhere; slab mode: wp3[slab][n][SL], k = ci - slab*SL
+// transposed = 1 (data gradient): rows n are INPUT channels of the conv and k its output channels: element = w3[k][n]
 template <class T>
-__global__ void conv3_pack_1x1_kernel(const float* __restrict__ w3, T* __restrict__ wp3, int Cin, int Cout, int pair, int SL) {
+__global__ void conv3_pack_1x1_kernel(const float* __restrict__ w3, T* __restrict__ wp3, int Cin, int Cout, int pair, int SL, int transposed) {
     const int nslab = pair ? 1 : (Cin + SL - 1) / SL, RW = pair ? 32 : SL;
     const long total = (long)nslab * Cout * RW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % RW); const long t = i / RW; const int n = (int)(t % Cout), slab = (int)(t / Cout);
         const int ci = pair ? kk - 16 : slab * SL + kk;
-        const float v = (ci >= 0 && ci < Cin) ? w3[(long)n * Cin + ci] : 0.f;
+        const float v = (ci >= 0 && ci < Cin) ? (transposed ? w3[(long)ci * Cout + n] : w3[(long)n * Cin + ci]) : 0.f;
         if constexpr (sizeof(T) == 2) wp3[i] = f2bf(v); else wp3[i] = v;
     }
 }
@@ -863,7 +898,7 @@ int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st
     return unetr_check_launch();
 }
 
-struct FuseArgs { float* part; const void* wp3; float* y3; long ldy3; float* part3; int rows; };
+struct FuseArgs { float* part; const void* wp3; float* y3; long ldy3; float* part3; int rows; int k3; };   // k3 > 0: FUSE 4 (y3 = second input)
 
 template <class P>
 int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accumulate, int B, int D, int H, int W, int Cin, int Cout,
@@ -887,11 +922,13 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
 #define LAUNCH_PIPE_F(NTB_, PAIR_, VEC_, FUSE_)                                                                                   \
     hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, VEC_, FUSE_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
                        accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial, fz ? fz->part : nullptr,                       \
-                       fz ? (const char*)fz->wp3 : nullptr, fz ? fz->y3 : nullptr, fz ? fz->ldy3 : 0, fz ? fz->part3 : nullptr)
+                       fz ? (const char*)fz->wp3 : nullptr, fz ? fz->y3 : nullptr, fz ? fz->ldy3 : 0, fz ? fz->part3 : nullptr,            \
+                       fz ? fz->k3 : 0)
 #define LAUNCH_PIPE_V(NTB_, PAIR_, FUSE_)                                                                                         \
     do { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, FUSE_); else LAUNCH_PIPE_F(NTB_, PAIR_, false, FUSE_); } while (0)
 #define LAUNCH_PIPE(NTB_, PAIR_)                                                                                                  \
     do {                                                                                                                          \
+        if (fz && fz->k3 > 0) { LAUNCH_PIPE_V(NTB_, PAIR_, 4); break; }                                                           \
         if constexpr (!(PAIR_)) {                                                                                                 \
             if (fz && fz->wp3 && late1x1) { LAUNCH_PIPE_V(NTB_, false, 3); break; }                                               \
         }                                                                                                                         \
@@ -900,7 +937,7 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
         else LAUNCH_PIPE_V(NTB_, PAIR_, 0);                                                                                       \
     } while (0)
         const bool late1x1 = Cin <= 4 * P::CH;      // single-slab window: the 1x1x1 product is formed after the tile (FUSE 3)
-        if (fz) {   // rows of the partial-sum buffers not visited by any wave must read as zero
+        if (fz && fz->k3 == 0) {   // rows of the partial-sum buffers not visited by any wave must read as zero
             fz->rows = (int)pgrid.x * 4;
             const size_t nb = (size_t)B * fz->rows * 2 * Cout * sizeof(float);
             (void)hipMemsetAsync(fz->part, 0, nb, st);
@@ -1017,7 +1054,7 @@ extern "C" int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack
     const int max_rows = 512 * 4;                                            // (workgroup, wave) partial rows per batch item
     const size_t per = (size_t)B * max_rows * 2 * Cout;
     if (!ws || per * (w3pack ? 2 : 1) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
-    FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr, 0};
+    FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr, 0, 0};
     int rc;
     if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
     else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
@@ -1034,18 +1071,41 @@ extern "C" size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec) {
     return (size_t)((Cin + SL - 1) / SL) * Cout * 64;
 }
 
-extern "C" int unetr_conv3_pack_1x1(const float* w3, void* w3pack, int Cin, int Cout, int prec, void* stream) {
-    if (!w3 || !w3pack || Cin <= 0 || Cout <= 0) return UNETR_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
+static int pack_1x1(const float* w3, void* w3pack, int K, int N, int prec, int allow_pair, int transposed, hipStream_t st) {
+    // rows n < N, contraction index k < K
     if (prec == UNETR_PREC_BF16) {
-        const int pair = (use_pair<PrecBF16>(Cin) && conv_pipe_enabled()) ? 1 : 0;
-        hipLaunchKernelGGL((conv3_pack_1x1_kernel<uint16_t>), dim3(cdiv((long)((Cin + 31) / 32) * Cout * 32, 256)), dim3(256), 0, st, w3,
-                           (uint16_t*)w3pack, Cin, Cout, pair, 32);
+        const int pair = (allow_pair && use_pair<PrecBF16>(K) && conv_pipe_enabled()) ? 1 : 0;
+        hipLaunchKernelGGL((conv3_pack_1x1_kernel<uint16_t>), dim3(cdiv((long)((K + 31) / 32) * N * 32, 256)), dim3(256), 0, st, w3,
+                           (uint16_t*)w3pack, K, N, pair, 32, transposed);
     } else if (prec == UNETR_PREC_F32) {
-        hipLaunchKernelGGL((conv3_pack_1x1_kernel<float>), dim3(cdiv((long)((Cin + 15) / 16) * Cout * 16, 256)), dim3(256), 0, st, w3,
-                           (float*)w3pack, Cin, Cout, 0, 16);
+        hipLaunchKernelGGL((conv3_pack_1x1_kernel<float>), dim3(cdiv((long)((K + 15) / 16) * N * 16, 256)), dim3(256), 0, st, w3,
+                           (float*)w3pack, K, N, 0, 16, transposed);
     } else return UNETR_ERR_ARG;
     return unetr_check_launch();
+}
+
+extern "C" int unetr_conv3_pack_1x1(const float* w3, void* w3pack, int Cin, int Cout, int prec, void* stream) {
+    if (!w3 || !w3pack || Cin <= 0 || Cout <= 0) return UNETR_ERR_ARG;
+    return pack_1x1(w3, w3pack, Cin, Cout, prec, 1, 0, (hipStream_t)stream);
+}
+
+// Data gradient of MONAI's UnetResBlock input in one launch: dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3).
+// wpack_dgrad from unetr_conv3_pack_weight(mode 1); w3 is the 1x1x1 weight [Cout, Cin] itself (packed here into ws).
+extern "C" int unetr_conv3_dgrad_fused(const float* dc1, long ld1, const void* wpack_dgrad, const float* dc3, long ld3, const float* w3,
+                                       float* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout, int prec,
+                                       float* ws, size_t ws_bytes, void* stream) {
+    if (!dc1 || !wpack_dgrad || !dc3 || !w3 || !dx || B <= 0) return UNETR_ERR_ARG;
+    if (Cin % 16 || Cout % 4 || (ld3 & 3) || ((uintptr_t)dc3 & 15)) return UNETR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = unetr_conv3_packed_1x1_bytes(Cout, Cin, prec);
+    if (!ws || need > ws_bytes) return UNETR_ERR_WORKSPACE;
+    int rc = pack_1x1(w3, ws, Cout, Cin, prec, 0, 1, st);          // rows n = block input channel, k = block output channel
+    if (rc) return rc;
+    FuseArgs fz{nullptr, ws, const_cast<float*>(dc3), ld3, nullptr, 0, Cout};
+    // the data gradient is the same kernel with contraction over the block's Cout channels and Cin outputs
+    if (prec == UNETR_PREC_BF16) return fwd_t<PrecBF16>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
+    if (prec == UNETR_PREC_F32) return fwd_t<PrecF32>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
+    return UNETR_ERR_ARG;
 }
 
 extern "C" int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,

@@ -444,6 +444,22 @@ def conv3_fused(x, ldx, w, w3, dims, prec):
     return c, st, c3, st3
 
 
+def conv3_dgrad_fused(dc1, dc3, w1, w3, dx, dims, prec):
+    """dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3) in one launch (the input gradient of a residual block);
+    returns False when the shape has to take the two-kernel route."""
+    B, D, H, W = dims
+    cout, cin = w1.shape[0], w1.shape[1]
+    if _use_gemm_conv() or cin % 16 != 0 or int(os.environ.get("UNETR_AMD_CONV_FUSE", "2")) < 2:
+        return False
+    lib = _capi.load()
+    wp = torch.empty(lib.unetr_conv3_packed_bytes(cin, cout, 1, prec), dtype=torch.uint8, device=dc1.device)
+    call("unetr_conv3_pack_weight", w1.data_ptr(), wp.data_ptr(), cin, cout, 1, prec, _stream())
+    ws = workspace(dc1.device)
+    rc = call_rc("unetr_conv3_dgrad_fused", dc1.data_ptr(), cout, wp.data_ptr(), dc3.data_ptr(), cout, w3.data_ptr(), dx.data_ptr(), cin,
+                 B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
+    return rc == 0
+
+
 def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None):
     """dw of the 3x3x3 conv; with dy3/out3 also the weight gradient of the 1x1x1 conv sharing the input x."""
     if _use_gemm_conv():
@@ -741,8 +757,9 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     dx = None
     if need_dx:
         dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=x.device)
-        gemm(dc3, w3, dx, B * V, cin, cout, lda=cout, ldb=cin, ldc=cin, prec=prec, b_trans=True)
-        conv3(dc1, cout, w1, dims, prec, mode=1, out=dx, ldo=cin, accumulate=True)
+        if not conv3_dgrad_fused(dc1, dc3, w1, w3, dx, dims, prec):
+            gemm(dc3, w3, dx, B * V, cin, cout, lda=cout, ldb=cin, ldc=cin, prec=prec, b_trans=True)
+            conv3(dc1, cout, w1, dims, prec, mode=1, out=dx, ldo=cin, accumulate=True)
     return dx, dw1, dw2, dw3
 
 

@@ -170,6 +170,12 @@ int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack, float* y,
                           float* ws, size_t ws_bytes, void* stream);
 size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec);
 int unetr_conv3_pack_1x1(const float* w3 /* [Cout,Cin] */, void* w3pack, int Cin, int Cout, int prec, void* stream);
+/* Data gradient of the residual block's input in one launch: dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3)
+ * (autograd of UnetResBlock.conv1 + conv3, both fed by the block input).  wpack_dgrad from unetr_conv3_pack_weight(mode 1)
+ * of conv1's weight; w3 = conv3's weight [Cout, Cin] as stored; dc1 / dc3 [B,D,H,W,Cout] channels-last with pitches. */
+int unetr_conv3_dgrad_fused(const float* dc1, long ld1, const void* wpack_dgrad, const float* dc3, long ld3, const float* w3,
+                            float* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout, int prec,
+                            float* ws, size_t ws_bytes, void* stream);
 /* (mean, rstd) from InstanceNorm partial sums part[B][nchunk][2][C] (sum, sum of squares) */
 int unetr_instnorm_stats_finalize(const float* part, int nchunk, int B, long V, int C, float eps, float* stats, void* stream);
 int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,

@@ -228,6 +228,24 @@ def test_conv3_fused_stats_and_1x1(pkg, dev, prec, B, dims3, cin, cout, with3):
         assert c3 is None and st3 is None
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 16), 32, 16), (1, (9, 7, 19), 16, 16), (1, (6, 10, 20), 64, 32), (1, (5, 6, 7), 16, 32),
+                                              (2, (4, 4, 16), 256, 128), (1, (10, 9, 33), 48, 16)])
+def test_conv3_dgrad_fused(pkg, dev, prec, B, dims3, cin, cout):
+    """Input gradient of a residual block in one launch: conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3) == autograd of
+    conv3d(x, w1) and conv3d(x, w3) fed by dc1 / dc3."""
+    Fn = pkg.functional
+    D, H, W = dims3
+    x = g(B, cin, D, H, W, seed=1).requires_grad_(True)
+    w1, w3 = g(cout, cin, 3, 3, 3, seed=2, scale=0.2), g(cout, cin, 1, 1, 1, seed=3, scale=0.5)
+    dc1, dc3 = g(B, cout, D, H, W, seed=4), g(B, cout, D, H, W, seed=5)
+    ((F.conv3d(x, w1, padding=1) * dc1).sum() + (F.conv3d(x, w3) * dc3).sum()).backward()
+    dx = torch.empty(B, D, H, W, cin, device=dev)
+    ok = Fn.conv3_dgrad_fused(cl(dc1).to(dev), cl(dc3).to(dev), w1.to(dev), w3.to(dev), dx, (B, D, H, W), prec)
+    assert ok
+    assert relerr(ncdhw(dx.cpu()), x.grad) < TOL[prec]
+
+
 def test_tr16_probe(pkg, dev):
     """ds_read_b64_tr_b16: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block of
     16-bit elements; lane i receives column i of the 4 rows (element q = row q)."""
