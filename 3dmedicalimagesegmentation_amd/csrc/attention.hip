@@ -26,7 +26,7 @@ template <class P, int DH> struct AttnCfg {
     static constexpr int DT = DH / 16;            // 16-wide tiles over the head dim
     static constexpr int PC = DH * (16 / CH) + 16;  // byte pitch of a chunk-image row
     static constexpr int IMG_C = 32 * PC;         // bytes of a 32-row chunk image
-    static constexpr int IMG_T = BF ? DH * PT : 0;  // bytes of the transposed image (bf16 only)
+    static constexpr int IMG_T = 0;               // no transposed image: bf16 fragments with k = tile row come out through ds_read_b64_tr_b16
 };
 
 template <class P, int DH> using AccArr = f32x4[AttnCfg<P, DH>::DT];
@@ -39,7 +39,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ src, long r
     using C = AttnCfg<P, DH>;
     constexpr int CH = C::CH;
     const int tid = threadIdx.x;
-    if (WANT_C || !C::BF) {
+    if (WANT_C || WANT_T) {
         constexpr int NCH = DH / CH;
         for (int id = tid; id < 32 * NCH; id += 256) {
             int r = id / NCH, ch = id - r * NCH;
@@ -58,18 +58,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ src, long r
             *(u32x4*)(img_c + r * C::PC + ch * 16) = P::pack(v);
         }
     }
-    if (WANT_T && C::BF) {
-        for (int id = tid; id < DH * 4; id += 256) {
-            int d = id % DH, rg = id / DH;  // 8 rows rg*8 .. rg*8+7 of column d
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int r = row0 + rg * 8 + j;
-                v[j] = r < nrows ? src[(long)r * rs + d] : 0.f;
-            }
-            *(u32x4*)(img_t + d * PT + rg * 16) = PrecBF16::pack(v);
-        }
-    }
+    (void)img_t;
 }
 
 // this lane's DH-vector (one token's head slice) as KB MFMA chunks: chunk index kb*4 + (lane>>4)
@@ -127,13 +116,19 @@ __device__ __forceinline__ void prod_T(AccArr<P, DH>& out, f32x4 x0, f32x4 x1, c
     } else {
         float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         u32x4 b = PrecBF16::pack(xv);
+        // A[d = dt*16 + c][k] with k = tile rows {4g..4g+3, 16+4g..16+4g+3}: transposing read of the row-major chunk image
+        // (lane (q = c>>2, p = c&3) addresses row R0 + q, columns 4p..4p+3 of the 16-column block; it receives column c)
+        typedef short s16x4_ __attribute__((ext_vector_type(4)));
+        typedef short s16x8_ __attribute__((ext_vector_type(8)));
+        const int q = c >> 2, p = c & 3;
+        (void)img_t;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
-            const char* row = img_t + (dt * 16 + c) * PT;
-            uint64_t lo = *(const uint64_t*)(row + 8 * g);         // tile rows 4g .. 4g+3
-            uint64_t hi = *(const uint64_t*)(row + 32 + 8 * g);    // tile rows 16+4g .. 16+4g+3
-            u32x4 a = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-            PrecBF16::mma(out[dt], a, b);
+            const char* base = img_c + (dt * 16 + 4 * p) * 2;
+            s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(base + (4 * g + q) * C::PC));
+            s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(base + (16 + 4 * g + q) * C::PC));
+            s16x8_ t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            PrecBF16::mma(out[dt], __builtin_bit_cast(u32x4, t), b);
         }
     }
 }
@@ -144,14 +139,17 @@ __device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16, 64); 
 constexpr float NEG_BIG = -1.0e30f;
 
 // ------------------------------------------------------------------------------------------ forward
-template <class P, int DH>
+// RES (all three kernels): the images of EVERY 32-row tile of the head are staged up front into their own LDS block (one
+// barrier, all global loads of the workgroup in flight together) and the tile loop then runs without barriers or global
+// loads.  At L = 216 the tiled form spent 7 load -> barrier -> MFMA round trips per workgroup (16-20 us per launch, 96
+// workgroups); used whenever the blocks fit the 160 KB LDS, else the tiled loop.
+template <class P, int DH, bool RES>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, uint16_t* __restrict__ outb, float* __restrict__ lse,
                 int L, int heads, float scale) {
     using C = AttnCfg<P, DH>;
-    __shared__ __attribute__((aligned(16))) char lds[C::IMG_C + (C::BF ? C::IMG_T : C::IMG_C)];
-    char* kimg = lds;
-    char* vimg = lds + C::IMG_C;
+    constexpr int TILE_B = 2 * C::IMG_C;       // K and V chunk images
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int head = blockIdx.y, b = blockIdx.z, Hd = heads * DH;
     const long rs = 3L * Hd;
@@ -165,11 +163,23 @@ attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, uint16_t
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m = NEG_BIG, l = 0.f;
+    if constexpr (RES) {
+        for (int k0 = 0; k0 < L; k0 += 32) {
+            char* base = lds + (k0 >> 5) * TILE_B;
+            stage_tile<P, DH, true, false>(kb_, rs, k0, L, base, nullptr);
+            stage_tile<P, DH, false, true>(vb, rs, k0, L, base + C::IMG_C, base + C::IMG_C);
+        }
+        __syncthreads();
+    }
     for (int k0 = 0; k0 < L; k0 += 32) {
-        __syncthreads();
-        stage_tile<P, DH, true, false>(kb_, rs, k0, L, kimg, nullptr);
-        stage_tile<P, DH, false, true>(vb, rs, k0, L, vimg, vimg);
-        __syncthreads();
+        char* kimg = lds + (RES ? (k0 >> 5) * TILE_B : 0);
+        char* vimg = kimg + C::IMG_C;
+        if constexpr (!RES) {
+            __syncthreads();
+            stage_tile<P, DH, true, false>(kb_, rs, k0, L, kimg, nullptr);
+            stage_tile<P, DH, false, true>(vb, rs, k0, L, vimg, vimg);
+            __syncthreads();
+        }
         f32x4 s[2];
         float tmax = NEG_BIG;
 #pragma unroll
@@ -228,15 +238,13 @@ __global__ void attn_delta_kernel(const float* __restrict__ out, const float* __
 }
 
 // ------------------------------------------------------------------------------- backward: dQ pass
-template <class P, int DH>
+template <class P, int DH, bool RES>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                    const float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb, int L, int heads, float scale) {
     using C = AttnCfg<P, DH>;
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::IMG_C + C::IMG_T];
-    char* kimg = lds;
-    char* vimg = lds + C::IMG_C;
-    char* ktimg = lds + 2 * C::IMG_C;
+    constexpr int TILE_B = 2 * C::IMG_C + C::IMG_T;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int head = blockIdx.y, b = blockIdx.z, Hd = heads * DH;
     const long rs = 3L * Hd;
@@ -251,11 +259,24 @@ attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout
     f32x4 dq[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (RES) {
+        for (int k0 = 0; k0 < L; k0 += 32) {
+            char* base = lds + (k0 >> 5) * TILE_B;
+            stage_tile<P, DH, true, true>(kb_, rs, k0, L, base, base + 2 * C::IMG_C);
+            stage_tile<P, DH, true, false>(vb, rs, k0, L, base + C::IMG_C, nullptr);
+        }
+        __syncthreads();
+    }
     for (int k0 = 0; k0 < L; k0 += 32) {
-        __syncthreads();
-        stage_tile<P, DH, true, true>(kb_, rs, k0, L, kimg, ktimg);
-        stage_tile<P, DH, true, false>(vb, rs, k0, L, vimg, nullptr);
-        __syncthreads();
+        char* kimg = lds + (RES ? (k0 >> 5) * TILE_B : 0);
+        char* vimg = kimg + C::IMG_C;
+        char* ktimg = kimg + 2 * C::IMG_C;
+        if constexpr (!RES) {
+            __syncthreads();
+            stage_tile<P, DH, true, true>(kb_, rs, k0, L, kimg, ktimg);
+            stage_tile<P, DH, true, false>(vb, rs, k0, L, vimg, nullptr);
+            __syncthreads();
+        }
         f32x4 ds[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -283,18 +304,13 @@ attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout
 }
 
 // ---------------------------------------------------------------------------- backward: dK/dV pass
-template <class P, int DH>
+template <class P, int DH, bool RES>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
                     const float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb, int L, int heads, float scale) {
     using C = AttnCfg<P, DH>;
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::IMG_C + 2 * C::IMG_T + 256];
-    char* qimg = lds;
-    char* doimg = lds + C::IMG_C;
-    char* qtimg = lds + 2 * C::IMG_C;
-    char* dotimg = qtimg + C::IMG_T;
-    float* lse_t = (float*)(dotimg + C::IMG_T);  // [32] lse, [32] delta
-    float* del_t = lse_t + 32;
+    constexpr int TILE_B = 2 * C::IMG_C + 2 * C::IMG_T + 256;    // q, dout chunk images, their transposed images, [32] lse + [32] delta
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int head = blockIdx.y, b = blockIdx.z, Hd = heads * DH;
     const long rs = 3L * Hd;
@@ -309,16 +325,32 @@ attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dou
     f32x4 dk[C::DT], dv[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
-    for (int q0 = 0; q0 < L; q0 += 32) {
-        __syncthreads();
-        stage_tile<P, DH, true, true>(qb, rs, q0, L, qimg, qtimg);
-        stage_tile<P, DH, true, true>(dob, (long)Hd, q0, L, doimg, dotimg);
+    auto stage_q = [&](int q0, char* base) {
+        stage_tile<P, DH, true, true>(qb, rs, q0, L, base, base + 2 * C::IMG_C);
+        stage_tile<P, DH, true, true>(dob, (long)Hd, q0, L, base + C::IMG_C, base + 2 * C::IMG_C + C::IMG_T);
         if (threadIdx.x < 32) {
+            float* lt = (float*)(base + 2 * C::IMG_C + 2 * C::IMG_T);
             int qq = q0 + threadIdx.x;
-            lse_t[threadIdx.x] = qq < L ? lse[((long)b * heads + head) * L + qq] : 1.0e30f;
-            del_t[threadIdx.x] = qq < L ? delta[((long)b * heads + head) * L + qq] : 0.f;
+            lt[threadIdx.x] = qq < L ? lse[((long)b * heads + head) * L + qq] : 1.0e30f;
+            lt[32 + threadIdx.x] = qq < L ? delta[((long)b * heads + head) * L + qq] : 0.f;
         }
+    };
+    if constexpr (RES) {
+        for (int q0 = 0; q0 < L; q0 += 32) stage_q(q0, lds + (q0 >> 5) * TILE_B);
         __syncthreads();
+    }
+    for (int q0 = 0; q0 < L; q0 += 32) {
+        char* qimg = lds + (RES ? (q0 >> 5) * TILE_B : 0);
+        char* doimg = qimg + C::IMG_C;
+        char* qtimg = qimg + 2 * C::IMG_C;
+        char* dotimg = qtimg + C::IMG_T;
+        const float* lse_t = (const float*)(dotimg + C::IMG_T);
+        const float* del_t = lse_t + 32;
+        if constexpr (!RES) {
+            __syncthreads();
+            stage_q(q0, qimg);
+            __syncthreads();
+        }
         f32x4 p[2], ds[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -354,17 +386,33 @@ attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dou
     }
 }
 
+constexpr size_t ATTN_LDS_MAX = 150 * 1024;
+
+template <class K, class... A>
+static void launch_dyn(K kern, dim3 grid, size_t lds, hipStream_t st, A... args) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, args...);
+}
+
 template <class P, int DH>
 int launch_fwd(const float* qkv, float* out, uint16_t* outb, float* lse, int B, int L, int heads, float scale, hipStream_t st) {
-    hipLaunchKernelGGL((attn_fwd_kernel<P, DH>), dim3(cdiv(L, 64), heads, B), dim3(256), 0, st, qkv, out, outb, lse, L, heads, scale);
+    using C = AttnCfg<P, DH>;
+    const size_t tile = 2 * C::IMG_C, nt = cdiv(L, 32);
+    dim3 grid(cdiv(L, 64), heads, B);
+    if (tile * nt <= ATTN_LDS_MAX) launch_dyn(attn_fwd_kernel<P, DH, true>, grid, tile * nt, st, qkv, out, outb, lse, L, heads, scale);
+    else launch_dyn(attn_fwd_kernel<P, DH, false>, grid, tile, st, qkv, out, outb, lse, L, heads, scale);
     return unetr_check_launch();
 }
 template <class P, int DH>
 int launch_bwd(const float* qkv, const float* dout, const float* lse, const float* delta, float* dqkv, uint16_t* dqkvb, int B, int L,
                int heads, float scale, hipStream_t st) {
+    using C = AttnCfg<P, DH>;
     dim3 grid(cdiv(L, 64), heads, B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, DH>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    const size_t nt = cdiv(L, 32), tq = 2 * C::IMG_C + C::IMG_T, tk = 2 * C::IMG_C + 2 * C::IMG_T + 256;
+    if (tq * nt <= ATTN_LDS_MAX) launch_dyn(attn_bwd_dq_kernel<P, DH, true>, grid, tq * nt, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    else launch_dyn(attn_bwd_dq_kernel<P, DH, false>, grid, tq, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    if (tk * nt <= ATTN_LDS_MAX) launch_dyn(attn_bwd_dkv_kernel<P, DH, true>, grid, tk * nt, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    else launch_dyn(attn_bwd_dkv_kernel<P, DH, false>, grid, tk, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
     return unetr_check_launch();
 }
 
