@@ -220,28 +220,12 @@ attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, uint16_t
     }
 }
 
-// delta[b,h,q] = sum_d dout[q, h*DH+d] * out[q, h*DH+d]
-__global__ void attn_delta_kernel(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ delta,
-                                  int B, int L, int heads, int DH) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)B * heads * L;
-    if (i >= total) return;
-    int q = (int)(i % L); long t = i / L; int h = (int)(t % heads); int b = (int)(t / heads);
-    const float* o = out + ((long)b * L + q) * heads * DH + h * DH;
-    const float* d = dout + ((long)b * L + q) * heads * DH + h * DH;
-    float s = 0.f;
-    for (int j = 0; j < DH; j += 4) {
-        f32x4 a = *(const f32x4*)(o + j), bb = *(const f32x4*)(d + j);
-        s += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
-    }
-    delta[i] = s;
-}
-
 // ------------------------------------------------------------------------------- backward: dQ pass
 template <class P, int DH, bool RES>
 __global__ void __launch_bounds__(256)
-attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
-                   const float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb, int L, int heads, float scale) {
+attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+                   const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb,
+                   int L, int heads, float scale) {
     using C = AttnCfg<P, DH>;
     constexpr int TILE_B = 2 * C::IMG_C + C::IMG_T;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -255,7 +239,23 @@ attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout
     u32x4 qf[C::KB], dof[C::KB];
     load_vec_frags<P, DH>(qb + (long)qc * rs, qf);
     load_vec_frags<P, DH>(dout + ((long)b * L + qc) * Hd + head * DH, dof);
-    const float lq = lse[((long)b * heads + head) * L + qc], dq_ = delta[((long)b * heads + head) * L + qc];
+    const float lq = lse[((long)b * heads + head) * L + qc];
+    // delta[b,h,q] = sum_d dout[q,d] * out[q,d] for this lane's query: each lane group sums its chunks, two shuffles
+    // finish the row; written out for the dK/dV pass that follows on the same stream (no separate delta launch)
+    float dq_ = 0.f;
+    {
+        const float* orow = out + ((long)b * L + qc) * Hd + head * DH;
+        const float* drow = dout + ((long)b * L + qc) * Hd + head * DH;
+#pragma unroll
+        for (int kb = 0; kb < C::KB; ++kb)
+#pragma unroll
+            for (int c4 = 0; c4 < C::CH / 4; ++c4) {
+                const f32x4 a = *(const f32x4*)(orow + (kb * 4 + g) * C::CH + 4 * c4), d = *(const f32x4*)(drow + (kb * 4 + g) * C::CH + 4 * c4);
+                dq_ += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+            }
+        dq_ = grp_sum(dq_);
+        if (g == 0 && q < L) delta[((long)b * heads + head) * L + q] = dq_;
+    }
     f32x4 dq[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -404,15 +404,15 @@ int launch_fwd(const float* qkv, float* out, uint16_t* outb, float* lse, int B, 
     return unetr_check_launch();
 }
 template <class P, int DH>
-int launch_bwd(const float* qkv, const float* dout, const float* lse, const float* delta, float* dqkv, uint16_t* dqkvb, int B, int L,
-               int heads, float scale, hipStream_t st) {
+int launch_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv, uint16_t* dqkvb,
+               int B, int L, int heads, float scale, hipStream_t st) {
     using C = AttnCfg<P, DH>;
     dim3 grid(cdiv(L, 64), heads, B);
     const size_t nt = cdiv(L, 32), tq = 2 * C::IMG_C + C::IMG_T, tk = 2 * C::IMG_C + 2 * C::IMG_T + 256;
-    if (tq * nt <= ATTN_LDS_MAX) launch_dyn(attn_bwd_dq_kernel<P, DH, true>, grid, tq * nt, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
-    else launch_dyn(attn_bwd_dq_kernel<P, DH, false>, grid, tq, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
-    if (tk * nt <= ATTN_LDS_MAX) launch_dyn(attn_bwd_dkv_kernel<P, DH, true>, grid, tk * nt, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
-    else launch_dyn(attn_bwd_dkv_kernel<P, DH, false>, grid, tk, st, qkv, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    if (tq * nt <= ATTN_LDS_MAX) launch_dyn(attn_bwd_dq_kernel<P, DH, true>, grid, tq * nt, st, qkv, out, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    else launch_dyn(attn_bwd_dq_kernel<P, DH, false>, grid, tq, st, qkv, out, dout, lse, delta, dqkv, dqkvb, L, heads, scale);
+    if (tk * nt <= ATTN_LDS_MAX) launch_dyn(attn_bwd_dkv_kernel<P, DH, true>, grid, tk * nt, st, qkv, dout, lse, (const float*)delta, dqkv, dqkvb, L, heads, scale);
+    else launch_dyn(attn_bwd_dkv_kernel<P, DH, false>, grid, tk, st, qkv, dout, lse, (const float*)delta, dqkv, dqkvb, L, heads, scale);
     return unetr_check_launch();
 }
 
@@ -445,8 +445,6 @@ extern "C" int unetr_attention_bwd(const float* qkv, const float* out, const flo
         return UNETR_ERR_ARG;
     if (dh & 3) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    long total = (long)B * heads * L;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, out, dout, delta, B, L, heads, dh);
-#define CALL_BWD(PP, DD) launch_bwd<PP, DD>(qkv, dout, lse, delta, dqkv, (uint16_t*)dqkv_bf16, B, L, heads, scale, st)
+#define CALL_BWD(PP, DD) launch_bwd<PP, DD>(qkv, out, dout, lse, delta, dqkv, (uint16_t*)dqkv_bf16, B, L, heads, scale, st)
     ATTN_DISPATCH(CALL_BWD)
 }
