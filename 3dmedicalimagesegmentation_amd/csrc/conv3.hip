@@ -394,6 +394,22 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
     }
     int cur_b = -1;
     const long srows = (long)gridDim.x * 4;       // partial rows per batch item
+    if constexpr (STATS) {
+        // this wave's rows of every batch item start at zero (a wave only flushes the batch items its tiles touch)
+        const int nb = ntiles / (ntx * nty * ntz);
+        if (g == 0) {
+            for (int bb = 0; bb < nb; ++bb) {
+                float* p0 = part + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + nt0 * 16 + r;
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) { p0[j * 16] = 0.f; p0[Cout + j * 16] = 0.f; }
+                if constexpr (any3) {
+                    float* p3 = part3 + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + nt0 * 16 + r;
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) { p3[j * 16] = 0.f; p3[Cout + j * 16] = 0.f; }
+                }
+            }
+        }
+    }
 
     HaloRegs<P, NCH> R;
     int tile = blockIdx.x;
@@ -937,12 +953,7 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
         else LAUNCH_PIPE_V(NTB_, PAIR_, 0);                                                                                       \
     } while (0)
         const bool late1x1 = Cin <= 4 * P::CH;      // single-slab window: the 1x1x1 product is formed after the tile (FUSE 3)
-        if (fz && fz->k3 == 0) {   // rows of the partial-sum buffers not visited by any wave must read as zero
-            fz->rows = (int)pgrid.x * 4;
-            const size_t nb = (size_t)B * fz->rows * 2 * Cout * sizeof(float);
-            (void)hipMemsetAsync(fz->part, 0, nb, st);
-            if (fz->wp3) (void)hipMemsetAsync(fz->part3, 0, nb, st);
-        }
+        if (fz && fz->k3 == 0) fz->rows = (int)pgrid.x * 4;      // (workgroup, wave) partial rows per batch item, zeroed in-kernel
         if constexpr (P::CH == 8) {
             if (pair) {
                 if (ntb == 1) LAUNCH_PIPE(1, true); else LAUNCH_PIPE(2, true);
