@@ -55,6 +55,7 @@ _SIGNATURES = {
     "unetr_gemm_bf16": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_size_t, P],
     "unetr_cast_bf16": [P, P, c_long, P],
     "unetr_gemm_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, c_int, P],
+    "unetr_gemm_bf16_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, P],
     "unetr_colsum_grouped": [ctypes.POINTER(ColsumProblem), c_int, P],
     "unetr_tconv_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],

@@ -220,6 +220,110 @@ int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t
     return unetr_check_launch();
 }
 
+// ---- grouped weight-gradient GEMM on bf16-stored operands: dW_i[N_i, K_i] = dY_i[M, N_i]^T * X_i[M, K_i] ------------------
+// Both operands are reduction-major ([token][feature]), i.e. the b_kn layout on BOTH sides: a stage is 64 tokens x 128
+// features of dY and of X, staged by LDS-DMA into two swizzled images (bkn_x<16>), and all MFMA fragments (k = token) come
+// out through ds_read_b64_tr_b16.  One launch covers up to 48 problems (descriptors in the kernel arguments); tokens beyond
+// M in the last stage read a clamped row and are zeroed in the A fragments (M is a multiple of 8: whole lane groups).
+constexpr int GW_MAX = 48;
+struct GwProblem { const uint16_t* dy; const uint16_t* x; float* dw; int M, N, K, tile0, ntn; };
+struct GwArgs { int n; GwProblem p[GW_MAX]; };
+
+template <int NS>
+__global__ void __launch_bounds__(256)
+gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
+    constexpr int BT = 128, BKT = 64;                      // output tile 128 x 128, 64 tokens per stage
+    constexpr int IMG = BKT * BT * 2, STAGE = 2 * IMG, PCS = IMG / 16 / 256, G = 2 * PCS, CPR = 16;
+    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+    int pi = 0;
+    const int t = blockIdx.x;
+    for (int i = 1; i < ga.n; ++i) pi = (t >= ga.p[i].tile0) ? i : pi;
+    const GwProblem& pr = ga.p[pi];
+    const int lt = t - pr.tile0, tn = lt % pr.ntn, tk = lt / pr.ntn;
+    const int n0 = tn * BT, k0 = tk * BT, M = pr.M;
+    const int nk = (M + BKT - 1) / BKT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+
+    // per-thread source offsets (row inside the stage, clamped column) of the DMA pieces
+    int prow[PCS], acol[PCS], bcol[PCS];
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+        const int id = tid + i * 256, r = id / CPR, sl = id % CPR, c = sl ^ bkn_x<CPR>(r);
+        prow[i] = r;
+        acol[i] = min(n0 + c * 8, pr.N - 8);
+        bcol[i] = min(k0 + c * 8, pr.K - 8);
+    }
+    auto issue = [&](int kt, int buf) {
+        char* la = lds + buf * STAGE;
+        char* lb = la + IMG;
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const long row = min(kt * BKT + prow[i], M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(pr.dy + row * pr.N + acol[i]), (lds_void_t*)(la + (wave * 64 + i * 256) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const long row = min(kt * BKT + prow[i], M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(pr.x + row * pr.K + bcol[i]), (lds_void_t*)(lb + (wave * 64 + i * 256) * 16), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s);
+    const int cc = lane & 15, g = lane >> 4, q = cc >> 2, p = cc & 3;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NS - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+        const char* la = lds + (kt % NS) * STAGE;
+        const char* lb = la + IMG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int r0 = kb * 32 + 8 * g + q, r1 = r0 + 4;
+            const int x0s = bkn_x<CPR>(r0), x1s = bkn_x<CPR>(r1);
+            const bool live = kt * BKT + kb * 32 + 8 * g < M;          // this lane group's 8 tokens exist
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = (wm * 4 + i) * 2 + (p >> 1);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(la + r0 * (BT * 2) + (ch ^ x0s) * 16 + (p & 1) * 8));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(la + r1 * (BT * 2) + (ch ^ x1s) * 16 + (p & 1) * 8));
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const u32x4 w = __builtin_bit_cast(u32x4, v);
+                a[i] = live ? w : (u32x4){0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = (wn * 4 + j) * 2 + (p >> 1);
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(lb + r0 * (BT * 2) + (ch ^ x0s) * 16 + (p & 1) * 8));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(lb + r1 * (BT * 2) + (ch ^ x1s) * 16 + (p & 1) * 8));
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                b[j] = __builtin_bit_cast(u32x4, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) PrecBF16::mma(acc[i][j], a[i], b[j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + (wm * 4 + i) * 16 + 4 * g + r, k = k0 + (wn * 4 + j) * 16 + cc;
+                if (n < pr.N && k < pr.K) pr.dw[(long)n * pr.K + k] = acc[i][j][r];
+            }
+}
+
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n8) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const f32x4 a = ((const f32x4*)src)[2 * i], b = ((const f32x4*)src)[2 * i + 1];
@@ -276,5 +380,27 @@ extern "C" int unetr_cast_bf16(const float* src, void* dst, long n, void* stream
     const long n8 = al ? n / 8 : 0;
     if (n8) hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(n8, 256), 4096)), dim3(256), 0, st, src, (uint16_t*)dst, n8);
     if (n8 * 8 < n) hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3(cdiv(n - n8 * 8, 256)), dim3(256), 0, st, src, (uint16_t*)dst, n8 * 8, n);
+    return unetr_check_launch();
+}
+
+// dw_i[N_i, K_i] = dy_i[M_i, N_i]^T * x_i[M_i, K_i] on bf16-stored dy / x (dense row-major), one launch per <= 48 problems
+extern "C" int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs, int n, void* stream) {
+    if (!probs || n <= 0) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += GW_MAX) {
+        GwArgs ga;
+        ga.n = std::min(GW_MAX, n - base);
+        int tiles = 0;
+        for (int i = 0; i < ga.n; ++i) {
+            const unetr_grouped_problem& q = probs[base + i];
+            if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N < 8 || q.K < 8) return UNETR_ERR_ARG;
+            if (q.M % 8 || q.N % 8 || q.K % 8 || ((uintptr_t)q.dy & 15) || ((uintptr_t)q.x & 15)) return UNETR_ERR_UNSUPPORTED;
+            GwProblem& g = ga.p[i];
+            g.dy = (const uint16_t*)q.dy; g.x = (const uint16_t*)q.x; g.dw = q.dw; g.M = q.M; g.N = q.N; g.K = q.K;
+            g.tile0 = tiles; g.ntn = cdiv(q.N, 128);
+            tiles += g.ntn * cdiv(q.K, 128);
+        }
+        hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2>), dim3(tiles), dim3(256), 0, st, ga);
+    }
     return unetr_check_launch();
 }

@@ -99,7 +99,7 @@ def _ret(w, g, deferred=False):
 # In arena mode the Linear weight/bias gradients of the ViT are not needed by anything inside backward, so they
 # are queued and executed at the end of the backward pass as ONE grouped GEMM launch + ONE grouped column-sum
 # launch (csrc: gemm_grouped_wgrad_kernel, colsum_grouped_kernel) instead of ~90 small latency-bound launches.
-_DEFER = {"wgrad": [], "colsum": [], "params": [], "armed": False, "prec": 0, "keep": [], "side": None}
+_DEFER = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0, "keep": [], "side": None}
 
 
 def _arm_flush():
@@ -108,11 +108,16 @@ def _arm_flush():
         torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
 
 
-def wgrad_or_defer(dy, x, prec, w):
-    """dw[N,K] = dy^T x for Linear weight `w`; returns (grad_or_None_for_autograd)."""
+def wgrad_or_defer(dy, x, prec, w, dyb=None, xb=None):
+    """dw[N,K] = dy^T x for Linear weight `w`; returns (grad_or_None_for_autograd).  dyb / xb: bf16 twins of dy / x -- the
+    deferred launch then runs the bf16-storage grouped kernel (unetr_gemm_bf16_grouped_wgrad)."""
     out = _gout(w)
     if out is None:
         return linear_wgrad(dy, x, prec)
+    if dyb is not None and xb is not None and dy.shape[0] % 8 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+        _DEFER["wgrad_b"].append((dyb, xb, out))
+        _arm_flush()
+        return _ret(w, out, deferred=True)
     _DEFER["wgrad"].append((dy, x, out))
     _DEFER["prec"] = prec
     _arm_flush()
@@ -129,7 +134,13 @@ def colsum_or_defer(x, M, N, ld, b, view_shape=None):
     return _ret(b, out, deferred=True)
 
 
-def _launch_deferred(wq, cq):
+def _launch_deferred(wq, cq, wbq=()):
+    if wbq:
+        arr = (_capi.GroupedProblem * len(wbq))()
+        for i, (dyb, xb, out) in enumerate(wbq):
+            arr[i].dy, arr[i].x, arr[i].dw = dyb.data_ptr(), xb.data_ptr(), out.data_ptr()
+            arr[i].M, arr[i].N, arr[i].K = dyb.shape[0], dyb.shape[1], xb.shape[1]
+        call("unetr_gemm_bf16_grouped_wgrad", arr, len(wbq), _stream())
     if wq:
         arr = (_capi.GroupedProblem * len(wq))()
         for i, (dy, x, out) in enumerate(wq):
@@ -149,24 +160,24 @@ def flush_deferred_side():
     data-gradient chain of the blocks below; the end-of-backward flush joins the side stream.  Measured inside the captured
     step: 9.17 ms against 8.60 ms for the single grouped launch at the end -- the 432-tile weight-gradient launches take
     the CUs the chain's small kernels need for their next dispatch, and twelve launches lose the fill of one."""
-    wq, cq = _DEFER["wgrad"], _DEFER["colsum"]
-    if not (wq or cq) or os.environ.get("UNETR_AMD_WGRAD_OVERLAP", "0") != "1":
+    wq, cq, wbq = _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"]
+    if not (wq or cq or wbq) or os.environ.get("UNETR_AMD_WGRAD_OVERLAP", "0") != "1":
         return
-    dev = (wq[0][0] if wq else cq[0][0]).device
+    dev = (wq[0][0] if wq else (wbq[0][0] if wbq else cq[0][0])).device
     main, side = torch.cuda.current_stream(dev), side_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        _launch_deferred(wq, cq)
-    _DEFER["keep"].append((wq, cq))
+        _launch_deferred(wq, cq, wbq)
+    _DEFER["keep"].append((wq, cq, wbq))
     _DEFER["side"] = side
-    _DEFER["wgrad"], _DEFER["colsum"] = [], []
+    _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"] = [], [], []
 
 
 def flush_deferred():
     """Runs at the end of the backward pass (autograd engine callback) on the backward stream."""
-    wq, cq, params = _DEFER["wgrad"], _DEFER["colsum"], _DEFER["params"]
-    _DEFER["wgrad"], _DEFER["colsum"], _DEFER["params"], _DEFER["armed"] = [], [], [], False
-    _launch_deferred(wq, cq)
+    wq, cq, wbq, params = _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"], _DEFER["params"]
+    _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"], _DEFER["params"], _DEFER["armed"] = [], [], [], [], False
+    _launch_deferred(wq, cq, wbq)
     if _DEFER["side"] is not None:
         torch.cuda.current_stream(_DEFER["side"].device).wait_stream(_DEFER["side"])     # join: everything below sees the gradients
         _DEFER["side"] = None
@@ -602,9 +613,11 @@ class PatchEmbedFn(torch.autograd.Function):
         hid = w.shape[0]
         patches = torch.empty(B * L, pd, dtype=torch.float32, device=x_in.device)
         call("unetr_patch_gather", x_in.data_ptr(), patches.data_ptr(), B, C, D, H, W, patch, _stream())
+        ctx.pb = None
         if _bf16_path(prec, pd):
             z = torch.empty(B * L, hid, dtype=torch.float32, device=x_in.device)
-            gemm_bf16(cast_bf16(patches), weight_bf16(w), B * L, hid, pd, C=z, bias=b, res=pos, ldr=hid, res_mod=L)
+            ctx.pb = cast_bf16(patches)
+            gemm_bf16(ctx.pb, weight_bf16(w), B * L, hid, pd, C=z, bias=b, res=pos, ldr=hid, res_mod=L)
         else:
             z = linear_fwd(patches, w, b, prec, res=pos, res_mod=L)
         ctx.save_for_backward(patches, w, b, pos)
@@ -616,7 +629,7 @@ class PatchEmbedFn(torch.autograd.Function):
         patches, w, b, pos = ctx.saved_tensors
         B, L, hid, prec = ctx.meta
         dz = dz.contiguous()
-        dw = wgrad_or_defer(dz, patches, prec, w)
+        dw = wgrad_or_defer(dz, patches, prec, w, _twin(dz) if ctx.pb is not None else None, ctx.pb)
         db = colsum_or_defer(dz, B * L, hid, hid, b)
         dpos = colsum_or_defer(dz, B, L * hid, L * hid, pos, view_shape=(1, L, hid))
         return None, dw, db, dpos, None, None
@@ -651,7 +664,9 @@ class TransformerBlockFn(torch.autograd.Function):
             gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, C=a, Cb=ab, bias=b1, act=1, pre=u)
             x2 = torch.empty(M, hid, **f32)
             gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
+            ctx.twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs
         else:
+            ctx.twins = None
             y1, m1, r1 = layernorm_fwd(x, n1w, n1b)
             qkv = linear_fwd(y1, wqkv, None, prec)
             att, lse = attention_fwd(qkv, B, L, heads, dh, prec)
@@ -676,15 +691,19 @@ class TransformerBlockFn(torch.autograd.Function):
         fast = _bf16_path(prec, hid, mlp)
         f32 = dict(dtype=torch.float32, device=x.device)
         # MLP
+        y1b = attb = y2b = ab = dx2b = dub = None
         if fast:
             # data gradients dX = dY . W read W [out, in] as the [K_reduce, N_out] operand (b_kn) -- no transposed copy
+            if ctx.twins is not None:
+                y1b, attb, y2b, ab = ctx.twins
+            dx2b = _twin(dx2)
             du, dub = torch.empty(M, mlp, **f32), torch.empty(M, mlp, dtype=torch.bfloat16, device=x.device)
-            gemm_bf16(_twin(dx2), weight_bf16(w2), M, mlp, hid, b_kn=True, C=du, Cb=dub, act=2, aux=u, ldaux=mlp)
+            gemm_bf16(dx2b, weight_bf16(w2), M, mlp, hid, b_kn=True, C=du, Cb=dub, act=2, aux=u, ldaux=mlp)
         else:
             du = linear_dgrad(dx2, w2, prec, aux=u)
-        dw2 = wgrad_or_defer(dx2, a, prec, w2)
+        dw2 = wgrad_or_defer(dx2, a, prec, w2, dx2b, ab)
         db2 = colsum_or_defer(dx2, M, hid, hid, b2)
-        dw1 = wgrad_or_defer(du, y2, prec, w1)
+        dw1 = wgrad_or_defer(du, y2, prec, w1, dub, y2b)
         db1 = colsum_or_defer(du, M, du.shape[1], du.shape[1], b1)
         if fast:
             dy2 = torch.empty(M, hid, **f32)
@@ -700,11 +719,11 @@ class TransformerBlockFn(torch.autograd.Function):
             gemm_bf16(dx1b, weight_bf16(wp), M, hid, hid, b_kn=True, C=datt)
         else:
             datt = linear_dgrad(dx1, wp, prec)
-        dwp = wgrad_or_defer(dx1, att, prec, wp)
+        dwp = wgrad_or_defer(dx1, att, prec, wp, dx1b, attb)
         dbp = colsum_or_defer(dx1, M, hid, hid, bp)
         dqkvb = torch.empty(M, 3 * hid, dtype=torch.bfloat16, device=x.device) if fast else None
         dqkv = attention_bwd(qkv, att, datt, lse, B, L, heads, dh, prec, dqkv_bf16=dqkvb)
-        dwqkv = wgrad_or_defer(dqkv, y1, prec, wqkv)
+        dwqkv = wgrad_or_defer(dqkv, y1, prec, wqkv, dqkvb, y1b)
         if fast:
             dy1 = torch.empty(M, hid, **f32)
             gemm_bf16(dqkvb, weight_bf16(wqkv), M, hid, 3 * hid, b_kn=True, C=dy1)

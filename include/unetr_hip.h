@@ -83,6 +83,9 @@ int unetr_cast_bf16(const float* src, void* dst, long n, void* stream);
  * 48 problems (descriptors travel in the kernel-argument block), filling the chip without split-K slabs. */
 typedef struct { const float* dy; const float* x; float* dw; int M, N, K; } unetr_grouped_problem;
 int unetr_gemm_grouped_wgrad(const unetr_grouped_problem* probs, int n, int prec, void* stream);
+/* the same grouped weight gradients on bf16-STORED dy / x (the pointers in unetr_grouped_problem then address bf16 data,
+ * dense row-major [M,N] / [M,K]; M, N, K multiples of 8): LDS-DMA staging, transposing LDS reads for both operands */
+int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs, int n, void* stream);
 typedef struct { const float* x; float* out; long ld; int M, N; } unetr_colsum_problem;
 int unetr_colsum_grouped(const unetr_colsum_problem* probs, int n, void* stream);
 

@@ -50,6 +50,25 @@ def test_gemm_bf16_storage(pkg, dev, M, N, K):
         assert relerr(dx, (dy.double() @ w.double()).float()) < 2e-5
 
 
+def test_gemm_bf16_grouped_wgrad(pkg, dev):
+    """grouped dW_i = dY_i^T X_i on bf16-stored operands (both read through transposing LDS loads; 432 tokens = a ragged
+    last 64-token stage; ragged N / K tiles) against fp64 products of the same bf16 inputs"""
+    capi = pkg._capi
+    shapes = [(432, 768, 768), (432, 2304, 768), (432, 768, 3072), (216, 200, 136), (64, 8, 8), (1000, 384, 128)]
+    arr = (capi.GroupedProblem * len(shapes))()
+    keep, refs, outs = [], [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = g(M, N, seed=10 + i).bfloat16(), g(M, K, seed=20 + i).bfloat16()
+        dyd, xd, out = dy.to(dev), x.to(dev), torch.full((N, K), float("nan"), device=dev)
+        keep += [dyd, xd]
+        outs.append(out)
+        refs.append((dy.double().t() @ x.double()).float())
+        arr[i].dy, arr[i].x, arr[i].dw, arr[i].M, arr[i].N, arr[i].K = dyd.data_ptr(), xd.data_ptr(), out.data_ptr(), M, N, K
+    capi.call("unetr_gemm_bf16_grouped_wgrad", arr, len(shapes), torch.cuda.current_stream().cuda_stream)
+    for out, ref, shp in zip(outs, refs, shapes):
+        assert relerr(out, ref) < 2e-5, shp
+
+
 def test_gemm_bf16_epilogues(pkg, dev):
     Fn = pkg.functional
     M, N, K, L = 432, 512, 256, 216
