@@ -668,7 +668,7 @@ template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
 };
 
 template <class P, bool VECX, bool VECY, bool HAS3, int CIS, bool PIPE_OK>
-__global__ void __launch_bounds__(256, CIS == 1 ? 3 : 1)   // CIS = 1: 41-43 KB of LDS -> three workgroups per CU
+__global__ void __launch_bounds__(256, CIS == 1 ? (HAS3 ? 2 : 3) : 1)   // CIS = 1: 41-43 KB of LDS -> three workgroups per CU (two with the second dy image: 168 registers would spill)
 conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
                    const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
                    int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
@@ -999,7 +999,7 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
     const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
     // persistent workgroups: all of them resident at once (3 per CU with the 16-channel slab, else 2 rounds of 2 per CU)
-    long G = std::max<long>(1, (cis == 1 ? 768 : 1024) / ((long)nci * nco));
+    long G = std::max<long>(1, (cis == 1 ? (dy3 ? 512 : 768) : 1024) / ((long)nci * nco));
     G = std::min(G, ntiles);
     const long n3 = dy3 ? (long)Cin * Cout : 0;
     while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;

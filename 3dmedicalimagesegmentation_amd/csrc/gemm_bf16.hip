@@ -225,7 +225,7 @@ int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t
 // features of dY and of X, staged by LDS-DMA into two swizzled images (bkn_x<16>), and all MFMA fragments (k = token) come
 // out through ds_read_b64_tr_b16.  One launch covers up to 48 problems (descriptors in the kernel arguments); tokens beyond
 // M in the last stage read a clamped row and are zeroed in the A fragments (M is a multiple of 8: whole lane groups).
-constexpr int GW_MAX = 48;
+constexpr int GW_MAX = 64;     // 12 blocks x 4 Linear layers + patch embedding in ONE launch
 struct GwProblem { const uint16_t* dy; const uint16_t* x; float* dw; int M, N, K, tile0, ntn; };
 struct GwArgs { int n; GwProblem p[GW_MAX]; };
 
