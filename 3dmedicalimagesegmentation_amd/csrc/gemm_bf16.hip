@@ -31,6 +31,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define LDS_AS_ __attribute__((address_space(3)))
 
 struct EpBf {
+    int vec_ok;          // N, pitches and base pointers allow 16-byte (8-byte bf16) row-segment accesses
     float* C; long ldc;
     uint16_t* Cb; long ldcb;
     const float* bias;
@@ -53,6 +54,26 @@ struct EpBf {
             __bf16 h = (__bf16)v;
             Cb[(long)m * ldcb + n] = __builtin_bit_cast(uint16_t, h);
         }
+    }
+    // four consecutive columns n..n+3 of row m (n % 4 == 0, all pitches multiples of 4 checked by the host)
+    __device__ __forceinline__ void store4(int m, int n, f32x4 v) const {
+        v *= alpha;
+        if (bias) v += *(const f32x4*)(bias + n);
+        if (pre) *(f32x4*)(pre + (long)m * ldc + n) = v;
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+        } else if (act == 2) {
+            const f32x4 a = *(const f32x4*)(aux + (long)m * ldaux + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(a[e]);
+        }
+        if (res) v += *(const f32x4*)(res + (long)(m % res_mod) * ldr + n);
+        if (C) {
+            if (accumulate) v += *(const f32x4*)(C + (long)m * ldc + n);
+            *(f32x4*)(C + (long)m * ldc + n) = v;
+        }
+        if (Cb) *(bf16x4*)(Cb + (long)m * ldcb + n) = __builtin_convertvector(v, bf16x4);
     }
 };
 
@@ -178,23 +199,32 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], b[j], a[i]);    // transposed tile: a lane holds 4 consecutive n of one m
         }
     }
 
+    // The MFMAs above ran with swapped operands, so the accumulator tile is C^T: lane (c, g) holds C[m = tile row c]
+    // [n = 4g .. 4g+3] -- one 16-byte store (or 8-byte bf16 store) per tile instead of four 4-byte ones.
+    const bool vec4 = ep.vec_ok;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j) {
+            const int m = m0 + (wm * WM + i) * 16 + (lane & 15);
+            const int n = n0 + (wn * WN + j) * 16 + 4 * (lane >> 4);
+            if (m >= M || n >= N) continue;
+            if (vec4) {
+                if (splits > 1) *(f32x4*)(ws + ((long)split * M + m) * N + n) = acc[i][j];
+                else ep.store4(m, n, acc[i][j]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + (wm * WM + i) * 16 + 4 * (lane >> 4) + r;
-                const int n = n0 + (wn * WN + j) * 16 + (lane & 15);
-                if (m < M && n < N) {
-                    if (splits > 1) ws[((long)split * M + m) * N + n] = acc[i][j][r];
-                    else ep.store(0, m, n, acc[i][j][r]);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) {
+                        if (splits > 1) ws[((long)split * M + m) * N + n + r] = acc[i][j][r];
+                        else ep.store(0, m, n + r, acc[i][j][r]);
+                    }
             }
+        }
 }
 
 template <int WM, int WN, int WVM, int WVN, bool BKN, int NS>
@@ -350,7 +380,11 @@ extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, con
     if (d->act == 2 && !d->aux) return UNETR_ERR_ARG;
     if ((d->pre || d->accumulate) && !C) return UNETR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    EpBf ep{C, d->ldc, (uint16_t*)Cb, d->ldcb, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : M,
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const int vec_ok = (N % 4 == 0) && (!C || (d->ldc % 4 == 0 && al16(C))) && (!Cb || (d->ldcb % 4 == 0 && ((uintptr_t)Cb & 7) == 0)) &&
+                       (!d->bias || al16(d->bias)) && (!d->res || (d->ldr % 4 == 0 && al16(d->res))) && (!d->pre || al16(d->pre)) &&
+                       (!d->aux || (d->ldaux % 4 == 0 && al16(d->aux))) && al16(ws);
+    EpBf ep{vec_ok, C, d->ldc, (uint16_t*)Cb, d->ldcb, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : M,
             d->pre, d->aux, d->ldaux, d->act, d->accumulate, d->alpha};
     const uint16_t* a = (const uint16_t*)A;
     const uint16_t* b = (const uint16_t*)B;

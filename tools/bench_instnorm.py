@@ -1,0 +1,33 @@
+"""InstanceNorm forward-apply / backward passes at the 96^3 x 16-channel shape (graph-timed): achieved HBM rate per pass."""
+import importlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
+Fn = pkg.functional
+dev = torch.device("cuda:0")
+B, S, C = 2, 96, 16
+V = S ** 3
+mk = lambda: torch.randn(B, S, S, S, C, device=dev)
+c1, c2, c3, dy = mk(), mk(), mk(), mk()
+s1, s2, s3 = (Fn.instnorm_stats(t, C, B, V, C) for t in (c1, c2, c3))
+mb = B * V * C * 4 / 1e6
+cases = {
+    "stats (1 read)": (lambda: Fn.instnorm_stats(c1, C, B, V, C), 1),
+    "apply single (1r+1w)": (lambda: Fn.instnorm_apply(c1, s1, B, V, C, True), 2),
+    "apply dual (2r+1w)": (lambda: Fn.instnorm_apply(c2, s2, B, V, C, True, x2=c3, sb=s3), 3),
+    "bwd single (2r | 2r+1w)": (lambda: Fn.instnorm_bwd(dy, C, c1, s1, B, V, C, True), 5),
+    "bwd dual (3r | 3r+2w)": (lambda: Fn.instnorm_bwd(dy, C, c2, s2, B, V, C, True, x2=c3, sb=s3), 8),
+}
+for name, (fn, passes) in cases.items():
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 30
+    print(f"{name:28s} {ms * 1e3:7.1f} us  {passes * mb / ms / 1e3:6.2f} TB/s")
