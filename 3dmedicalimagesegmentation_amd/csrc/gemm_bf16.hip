@@ -378,7 +378,7 @@ extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, con
     if (K % 64 || d->lda % 8 || d->ldb % 8 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return UNETR_ERR_UNSUPPORTED;
     if (d->b_kn && (N % 8 || N < 8)) return UNETR_ERR_UNSUPPORTED;
     if (d->act == 2 && !d->aux) return UNETR_ERR_ARG;
-    if ((d->pre || d->accumulate) && !C) return UNETR_ERR_ARG;
+    if (d->accumulate && !C) return UNETR_ERR_ARG;       // `pre` (pitch ldc) may be written without C
     hipStream_t st = (hipStream_t)stream;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const int vec_ok = (N % 4 == 0) && (!C || (d->ldc % 4 == 0 && al16(C))) && (!Cb || (d->ldcb % 4 == 0 && ((uintptr_t)Cb & 7) == 0)) &&

@@ -46,7 +46,7 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
             f32x4 g = ((const f32x4*)gamma)[i], b = ((const f32x4*)beta)[i], o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
-            yr[i] = o;
+            if (y) yr[i] = o;
             if (yb) ((bf16x4*)(yb + (long)row * H))[i] = __builtin_convertvector(o, bf16x4);
         }
     }
@@ -531,7 +531,7 @@ inline int grid_for(long total, int per_block = 256, int cap = 8192) {
 // ============================================================================================ C ABI
 extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16,
                                    float* mean, float* rstd, int M, int H, float eps, void* stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0) return UNETR_ERR_ARG;
+    if (!x || !gamma || !beta || (!y && !y_bf16) || !mean || !rstd || M <= 0) return UNETR_ERR_ARG;
     if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
                        (uint16_t*)y_bf16, mean, rstd, M, H, eps);

@@ -112,9 +112,14 @@ def wgrad_or_defer(dy, x, prec, w, dyb=None, xb=None):
     """dw[N,K] = dy^T x for Linear weight `w`; returns (grad_or_None_for_autograd).  dyb / xb: bf16 twins of dy / x -- the
     deferred launch then runs the bf16-storage grouped kernel (unetr_gemm_bf16_grouped_wgrad)."""
     out = _gout(w)
+    twins = dyb is not None and xb is not None and dyb.shape[0] % 8 == 0 and dyb.shape[1] % 8 == 0 and xb.shape[1] % 8 == 0
     if out is None:
-        return linear_wgrad(dy, x, prec)
-    if dyb is not None and xb is not None and dy.shape[0] % 8 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+        if not twins:
+            return linear_wgrad(dy, x, prec)
+        dw = torch.empty(dyb.shape[1], xb.shape[1], dtype=torch.float32, device=dyb.device)
+        _launch_deferred((), (), [(dyb, xb, dw)])
+        return dw
+    if twins:
         _DEFER["wgrad_b"].append((dyb, xb, out))
         _arm_flush()
         return _ret(w, out, deferred=True)
@@ -370,12 +375,12 @@ def bf16_like(t):
     return torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
 
 
-def layernorm_fwd(x, w, b, bf16_out=None):
+def layernorm_fwd(x, w, b, bf16_out=None, want_fp32=True):
     M, H = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if want_fp32 else None
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-    call("unetr_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), _p(bf16_out), mean.data_ptr(),
+    call("unetr_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), _p(y), _p(bf16_out), mean.data_ptr(),
          rstd.data_ptr(), M, H, LN_EPS, _stream())
     return y, mean, rstd
 
@@ -645,12 +650,14 @@ class TransformerBlockFn(torch.autograd.Function):
         hid = x.shape[1]
         dh = hid // heads
         M, mlp = x.shape[0], w1.shape[0]
-        if _bf16_path(prec, hid, mlp):
+        if _bf16_path(prec, hid, mlp) and M % 8 == 0:     # (the bf16 weight-gradient kernel wants whole 8-token groups)
             # bf16-stored operands: every GEMM input below is written as bf16 by its producer (fp32 copies stay for
             # the weight-gradient GEMMs and the LayerNorm / attention backward kernels)
             f32 = dict(dtype=torch.float32, device=x.device)
+            train = any(ctx.needs_input_grad)
             y1b = bf16_like(x)
-            y1, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b)
+            _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
+            y1 = y2 = a = x.new_empty(0)         # the fp32 twins are not materialised: every consumer reads bf16
             qkv = torch.empty(M, 3 * hid, **f32)
             gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=qkv)
             attb = bf16_like(x)
@@ -658,10 +665,12 @@ class TransformerBlockFn(torch.autograd.Function):
             x1 = torch.empty(M, hid, **f32)
             gemm_bf16(attb, weight_bf16(wp), M, hid, hid, C=x1, bias=bp, res=x, ldr=hid)
             y2b = bf16_like(x)
-            y2, m2, r2 = layernorm_fwd(x1, n2w, n2b, bf16_out=y2b)
-            u, a = torch.empty(M, mlp, **f32), torch.empty(M, mlp, **f32)
-            ab = bf16_like(a)
-            gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, C=a, Cb=ab, bias=b1, act=1, pre=u)
+            _, m2, r2 = layernorm_fwd(x1, n2w, n2b, bf16_out=y2b, want_fp32=False)
+            u = torch.empty(M, mlp, **f32) if train else None      # pre-activation, only GELU' in backward reads it
+            ab = torch.empty(M, mlp, dtype=torch.bfloat16, device=x.device)
+            gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, Cb=ab, bias=b1, act=1, pre=u)
+            if u is None:
+                u = x.new_empty(0)
             x2 = torch.empty(M, hid, **f32)
             gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
             ctx.twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs
@@ -688,7 +697,7 @@ class TransformerBlockFn(torch.autograd.Function):
         M, hid = x.shape
         dx2 = dx2.contiguous()
         mlp = w1.shape[0]
-        fast = _bf16_path(prec, hid, mlp)
+        fast = _bf16_path(prec, hid, mlp) and M % 8 == 0
         f32 = dict(dtype=torch.float32, device=x.device)
         # MLP
         y1b = attb = y2b = ab = dx2b = dub = None

@@ -123,7 +123,7 @@ int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumula
 
 /* ---- LayerNorm (nn.LayerNorm(H), eps 1e-5, affine; MONAI TransformerBlock.norm1/2, ViT.norm) -------- */
 int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
-                        void* y_bf16 /* optional bf16 copy of y for unetr_gemm_bf16, or NULL */,
+                        void* y_bf16 /* optional bf16 copy of y for unetr_gemm_bf16, or NULL; y itself may be NULL when only the bf16 copy is wanted */,
                         float* mean, float* rstd, int M, int H, float eps, void* stream);
 /* dgamma == dbeta == NULL: only dx is produced and ws keeps the per-row-block partial sums, laid out
  * [ceil(M/4)][2][H] (dgamma row, dbeta row), for a later unetr_colsum_grouped over all LayerNorms of the step. */
