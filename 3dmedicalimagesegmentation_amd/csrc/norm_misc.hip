@@ -171,8 +171,16 @@ colsum_grouped_kernel(ColsumArgs a) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = ((int)blockIdx.x - pr.blk0) * 64 + tx;
     float s = 0.f;
-    if (n < pr.N)
-        for (int m = ty; m < pr.M; m += 4) s += pr.x[(long)m * pr.ld + n];
+    if (n < pr.N) {
+        int m = ty;
+        for (; m + 28 < pr.M; m += 32) {           // eight independent loads in flight per thread (fixed summation tree)
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pr.x[(long)(m + 4 * u) * pr.ld + n];
+            s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        for (; m < pr.M; m += 4) s += pr.x[(long)m * pr.ld + n];
+    }
     sm[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && n < pr.N) pr.out[n] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
