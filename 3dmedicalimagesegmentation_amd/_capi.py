@@ -44,6 +44,10 @@ class GroupedProblem(ctypes.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int)]
 
 
+class PackProblem(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("Cin", c_int), ("Cout", c_int), ("kind", c_int)]
+
+
 class ColsumProblem(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("ld", c_long), ("M", c_int), ("N", c_int)]
 
@@ -76,7 +80,8 @@ _SIGNATURES = {
     "unetr_conv3_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd_fused": [P, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
-    "unetr_conv3_dgrad_fused": [P, c_long, P, P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_dgrad_fused": [P, c_long, P, P, c_long, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_pack_grouped": [ctypes.POINTER(PackProblem), c_int, c_int, P],
     "unetr_conv3_pack_1x1": [P, P, c_int, c_int, c_int, P],
     "unetr_instnorm_stats_finalize": [P, c_int, c_int, c_long, c_int, c_float, P, P],
     "unetr_conv3_wgrad": [P, c_long, P, c_long, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],

@@ -898,6 +898,49 @@ inline int conv_pipe_enabled() {   // tuning hook: UNETR_CONV_PIPE=0 selects the
     return e ? atoi(e) : 1;
 }
 
+// ---- all weight re-packs of a step in ONE launch (run by the optimizer right after the update) ---------------------------
+// kind 0 / 1: 3x3x3 forward / data-gradient layout (pair layout when the contraction has <= 16 channels in bf16),
+// kind 2: 1x1x1 forward (fused front), kind 3: 1x1x1 transposed (fused input gradient).
+constexpr int PK_MAX = 64;
+struct PkProblem { const float* w; void* out; int Cin, Cout, kind, pair, blk0; long total; };
+struct PkArgs { int n; PkProblem p[PK_MAX]; };
+
+template <class T>
+__global__ void __launch_bounds__(256) conv3_pack_grouped_kernel(PkArgs a, int SL) {
+    int pi = 0;
+    for (int i = 1; i < a.n; ++i) pi = ((int)blockIdx.x >= a.p[i].blk0) ? i : pi;
+    const PkProblem& pr = a.p[pi];
+    const float* __restrict__ w = pr.w;
+    T* __restrict__ wp = (T*)pr.out;
+    const int Cin = pr.Cin, Cout = pr.Cout;
+    const long base = ((long)blockIdx.x - pr.blk0) * 2048;
+    for (int u = 0; u < 8; ++u) {
+        const long i = base + threadIdx.x + u * 256;
+        if (i >= pr.total) break;
+        float v = 0.f;
+        if (pr.kind <= 1) {
+            const int mode = pr.kind, K = mode ? Cout : Cin, N = mode ? Cin : Cout;
+            if (pr.pair) {
+                const int kk = (int)(i & 31); const long t = i >> 5; const int n = (int)(t % N), tp = (int)(t / N);
+                const int tap = 2 * tp + (kk >> 4), k = kk & 15;
+                if (tap < 27 && k < K) v = mode ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
+            } else {
+                const int nslab = (K + SL - 1) / SL;
+                const int kk = (int)(i % SL); long t = i / SL; const int n = (int)(t % N); t /= N; const int slab = (int)(t % nslab), tap = (int)(t / nslab);
+                const int k = slab * SL + kk;
+                if (k < K) v = mode ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
+            }
+        } else {
+            // 1x1x1: rows n, contraction k.  kind 2: n = co, k = ci, element w3[n][k];  kind 3: n = ci, k = co, element w3[k][n]
+            const int K = pr.kind == 2 ? Cin : Cout, N = pr.kind == 2 ? Cout : Cin, RW = pr.pair ? 32 : SL;
+            const int kk = (int)(i % RW); const long t = i / RW; const int n = (int)(t % N), slab = (int)(t / N);
+            const int k = pr.pair ? kk - 16 : slab * SL + kk;
+            if (k >= 0 && k < K) v = pr.kind == 2 ? w[(long)n * K + k] : w[(long)k * N + n];
+        }
+        wp[i] = cvt_elem<T>(v);
+    }
+}
+
 template <class P>
 int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st) {
     typedef typename ElemOf<P>::type T;
@@ -1082,6 +1125,31 @@ extern "C" size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec) {
     return (size_t)((Cin + SL - 1) / SL) * Cout * 64;
 }
 
+extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, int prec, void* stream) {
+    if (!probs || n <= 0 || (prec != UNETR_PREC_BF16 && prec != UNETR_PREC_F32)) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int SL = prec == UNETR_PREC_BF16 ? 32 : 16;
+    for (int base = 0; base < n; base += PK_MAX) {
+        PkArgs a;
+        a.n = std::min(PK_MAX, n - base);
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const unetr_pack_problem& q = probs[base + i];
+            if (!q.w || !q.out || q.Cin <= 0 || q.Cout <= 0 || q.kind < 0 || q.kind > 3) return UNETR_ERR_ARG;
+            const int K = (q.kind == 0 || q.kind == 2) ? q.Cin : q.Cout, N = (q.kind == 0 || q.kind == 2) ? q.Cout : q.Cin;
+            const int pair = (prec == UNETR_PREC_BF16 && q.kind != 3 && K <= 16 && conv_pipe_enabled()) ? 1 : 0;
+            long total;
+            if (q.kind <= 1) total = pair ? 14L * N * 32 : 27L * ((K + SL - 1) / SL) * N * SL;
+            else total = pair ? (long)N * 32 : (long)((K + SL - 1) / SL) * N * SL;
+            a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, q.kind, pair, blocks, total};
+            blocks += cdiv(total, 2048);
+        }
+        if (prec == UNETR_PREC_BF16) hipLaunchKernelGGL((conv3_pack_grouped_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, a, SL);
+        else hipLaunchKernelGGL((conv3_pack_grouped_kernel<float>), dim3(blocks), dim3(256), 0, st, a, SL);
+    }
+    return unetr_check_launch();
+}
+
 static int pack_1x1(const float* w3, void* w3pack, int K, int N, int prec, int allow_pair, int transposed, hipStream_t st) {
     // rows n < N, contraction index k < K
     if (prec == UNETR_PREC_BF16) {
@@ -1103,16 +1171,20 @@ extern "C" int unetr_conv3_pack_1x1(const float* w3, void* w3pack, int Cin, int 
 // Data gradient of MONAI's UnetResBlock input in one launch: dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3).
 // wpack_dgrad from unetr_conv3_pack_weight(mode 1); w3 is the 1x1x1 weight [Cout, Cin] itself (packed here into ws).
 extern "C" int unetr_conv3_dgrad_fused(const float* dc1, long ld1, const void* wpack_dgrad, const float* dc3, long ld3, const float* w3,
-                                       float* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout, int prec,
-                                       float* ws, size_t ws_bytes, void* stream) {
-    if (!dc1 || !wpack_dgrad || !dc3 || !w3 || !dx || B <= 0) return UNETR_ERR_ARG;
+                                       const void* w3pack_t, float* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout,
+                                       int prec, float* ws, size_t ws_bytes, void* stream) {
+    if (!dc1 || !wpack_dgrad || !dc3 || (!w3 && !w3pack_t) || !dx || B <= 0) return UNETR_ERR_ARG;
     if (Cin % 16 || Cout % 4 || (ld3 & 3) || ((uintptr_t)dc3 & 15)) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = unetr_conv3_packed_1x1_bytes(Cout, Cin, prec);
-    if (!ws || need > ws_bytes) return UNETR_ERR_WORKSPACE;
-    int rc = pack_1x1(w3, ws, Cout, Cin, prec, 0, 1, st);          // rows n = block input channel, k = block output channel
-    if (rc) return rc;
-    FuseArgs fz{nullptr, ws, const_cast<float*>(dc3), ld3, nullptr, 0, Cout};
+    const void* w3t = w3pack_t;
+    if (!w3t) {                                                        // pack the transposed 1x1x1 weights into the workspace
+        const size_t need = unetr_conv3_packed_1x1_bytes(Cout, Cin, prec);
+        if (!ws || need > ws_bytes) return UNETR_ERR_WORKSPACE;
+        int rc = pack_1x1(w3, ws, Cout, Cin, prec, 0, 1, st);          // rows n = block input channel, k = block output channel
+        if (rc) return rc;
+        w3t = ws;
+    }
+    FuseArgs fz{nullptr, w3t, const_cast<float*>(dc3), ld3, nullptr, 0, Cout};
     // the data gradient is the same kernel with contraction over the block's Cout channels and Cin outputs
     if (prec == UNETR_PREC_BF16) return fwd_t<PrecBF16>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
     if (prec == UNETR_PREC_F32) return fwd_t<PrecF32>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);

@@ -287,6 +287,8 @@ def invalidate_weight_shadows():
     _WEIGHT_EPOCH[0] += 1
     for ent in _SHADOW.values():
         ent[1] = -1
+    for ent in _PACKS.values():
+        ent[1] = -1
 
 
 def register_weight_shadow(w, shadow):
@@ -304,6 +306,55 @@ def weight_bf16(w):
         cast_bf16(w.detach(), out=ent[0])
         ent[1], ent[2] = w._version, _WEIGHT_EPOCH[0]
     return ent[0]
+
+
+# ---- packed conv weights (MFMA operand layouts of csrc/conv3.hip) ------------------------------------------------------
+# Same freshness rules as the bf16 shadows: a pack is fresh when the optimizer of this package maintains it (one grouped
+# re-pack launch right after the update, refresh_conv_packs) and torch has not modified the parameter since, or it was
+# packed in this weight epoch outside graph capture.  kind 0 / 1: 3x3x3 forward / data gradient, 2 / 3: 1x1x1 forward /
+# transposed.  Without this the step spent ~25 five-microsecond pack launches on its critical path.
+_PACKS = {}
+
+
+def conv_pack_get(w, kind, prec):
+    key = (id(w), kind, prec)
+    ent = _PACKS.get(key)
+    cout, cin = w.shape[0], w.shape[1]
+    if ent is None or ent[4]() is not w or ent[0].device != w.device:
+        lib = _capi.load()
+        nbytes = lib.unetr_conv3_packed_bytes(cin, cout, kind, prec) if kind <= 1 else (
+            lib.unetr_conv3_packed_1x1_bytes(cin, cout, prec) if kind == 2 else lib.unetr_conv3_packed_1x1_bytes(cout, cin, prec))
+        ent = [torch.empty(nbytes, dtype=torch.uint8, device=w.device), -1, -1, False, weakref.ref(w)]
+        _PACKS[key] = ent
+    fresh = ent[1] == w._version and (ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
+    if not fresh:
+        _pack_launch([(w, ent[0], cin, cout, kind)], prec)
+        ent[1], ent[2] = w._version, _WEIGHT_EPOCH[0]
+    return ent[0]
+
+
+def _pack_launch(items, prec):
+    arr = (_capi.PackProblem * len(items))()
+    for i, (w, buf, cin, cout, kind) in enumerate(items):
+        arr[i].w, arr[i].out, arr[i].Cin, arr[i].Cout, arr[i].kind = w.data_ptr(), buf.data_ptr(), cin, cout, kind
+    call("unetr_conv3_pack_grouped", arr, len(items), prec, _stream())
+
+
+def refresh_conv_packs():
+    """optimizer side: re-pack every registered conv weight in one launch per precision; the packs are optimizer-maintained
+    from here on"""
+    by_prec = {}
+    for key, ent in list(_PACKS.items()):
+        w = ent[4]()
+        if w is None:
+            del _PACKS[key]
+            continue
+        if not w.is_cuda or ent[1] != w._version:
+            continue                                  # torch touched the parameter: conv_pack_get re-packs on demand
+        by_prec.setdefault(key[2], []).append((w, ent[0], w.shape[1], w.shape[0], key[1]))
+        ent[3] = True
+    for prec, items in by_prec.items():
+        _pack_launch(items, prec)
 
 
 def shadow_ptr_for_update(w):
@@ -447,10 +498,7 @@ def conv3(x, ldx, w, dims, prec, mode=0, out=None, ldo=None, accumulate=False):
     cin, cout = (cin_w, cout_w) if mode == 0 else (cout_w, cin_w)
     if _use_gemm_conv() or cout % 16 != 0:
         return conv_fwd(x, ldx, conv_pack(w, mode), dims, cin, cout, 3, prec, out=out, ldo=ldo, accumulate=accumulate)
-    lib = _capi.load()
-    nbytes = lib.unetr_conv3_packed_bytes(cin_w, cout_w, mode, prec)
-    wp = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    call("unetr_conv3_pack_weight", w.data_ptr(), wp.data_ptr(), cin_w, cout_w, mode, prec, _stream())
+    wp = conv_pack_get(w, mode, prec)
     if out is None:
         out = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
         ldo = cout
@@ -467,16 +515,13 @@ def conv3_fused(x, ldx, w, w3, dims, prec):
     level = int(os.environ.get("UNETR_AMD_CONV_FUSE", "2"))     # tuning hook: 0 unfused, 1 statistics only, 2 + 1x1x1 conv
     if _use_gemm_conv() or cout % 16 != 0 or level == 0 or (w3 is not None and level < 2):
         return None
-    lib = _capi.load()
     dev = x.device
-    wp = torch.empty(lib.unetr_conv3_packed_bytes(cin, cout, 0, prec), dtype=torch.uint8, device=dev)
-    call("unetr_conv3_pack_weight", w.data_ptr(), wp.data_ptr(), cin, cout, 0, prec, _stream())
+    wp = conv_pack_get(w, 0, prec)
     c = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=dev)
     st = torch.empty(B, cout, 2, dtype=torch.float32, device=dev)
     wp3 = c3 = st3 = None
     if w3 is not None:
-        wp3 = torch.empty(lib.unetr_conv3_packed_1x1_bytes(cin, cout, prec), dtype=torch.uint8, device=dev)
-        call("unetr_conv3_pack_1x1", w3.data_ptr(), wp3.data_ptr(), cin, cout, prec, _stream())
+        wp3 = conv_pack_get(w3, 2, prec)
         c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=dev)
         st3 = torch.empty(B, cout, 2, dtype=torch.float32, device=dev)
     ws = workspace(dev)
@@ -494,11 +539,10 @@ def conv3_dgrad_fused(dc1, dc3, w1, w3, dx, dims, prec):
     cout, cin = w1.shape[0], w1.shape[1]
     if _use_gemm_conv() or cin % 16 != 0 or int(os.environ.get("UNETR_AMD_CONV_FUSE", "2")) < 2:
         return False
-    lib = _capi.load()
-    wp = torch.empty(lib.unetr_conv3_packed_bytes(cin, cout, 1, prec), dtype=torch.uint8, device=dc1.device)
-    call("unetr_conv3_pack_weight", w1.data_ptr(), wp.data_ptr(), cin, cout, 1, prec, _stream())
+    wp = conv_pack_get(w1, 1, prec)
+    w3t = conv_pack_get(w3, 3, prec)
     ws = workspace(dc1.device)
-    rc = call_rc("unetr_conv3_dgrad_fused", dc1.data_ptr(), cout, wp.data_ptr(), dc3.data_ptr(), cout, w3.data_ptr(), dx.data_ptr(), cin,
+    rc = call_rc("unetr_conv3_dgrad_fused", dc1.data_ptr(), cout, wp.data_ptr(), dc3.data_ptr(), cout, w3.data_ptr(), w3t.data_ptr(), dx.data_ptr(), cin,
                  B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
     return rc == 0
 

@@ -74,6 +74,7 @@ class AdamW(torch.optim.Optimizer):
                 call("unetr_adamw", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                      group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i,
                      Fn.shadow_ptr_for_update(p), stream)
+        Fn.refresh_conv_packs()          # one grouped launch: packed conv weights follow the update
         return loss
 
     def _flat_runs(self, params, pattern, max_elems=None):
@@ -149,3 +150,4 @@ class AdamW(torch.optim.Optimizer):
             if before_run is not None:
                 before_run(k, run[2], run[3])
             self._launch_run(group, run, steps, gsrc.data_ptr(), g_bf16, gscale, stream)
+        Fn.refresh_conv_packs()

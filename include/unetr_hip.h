@@ -177,8 +177,14 @@ int unetr_conv3_pack_1x1(const float* w3 /* [Cout,Cin] */, void* w3pack, int Cin
  * (autograd of UnetResBlock.conv1 + conv3, both fed by the block input).  wpack_dgrad from unetr_conv3_pack_weight(mode 1)
  * of conv1's weight; w3 = conv3's weight [Cout, Cin] as stored; dc1 / dc3 [B,D,H,W,Cout] channels-last with pitches. */
 int unetr_conv3_dgrad_fused(const float* dc1, long ld1, const void* wpack_dgrad, const float* dc3, long ld3, const float* w3,
+                            const void* w3pack_t /* optional: kind-3 pack of w3 (unetr_conv3_pack_grouped); NULL = packed here from w3 */,
                             float* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout, int prec,
                             float* ws, size_t ws_bytes, void* stream);
+/* All weight re-packs of a step in one launch (descriptors in the kernel arguments, <= 64 per launch).  kind 0 / 1: what
+ * unetr_conv3_pack_weight(mode 0 / 1) writes; kind 2: unetr_conv3_pack_1x1; kind 3: the transposed 1x1x1 layout that
+ * unetr_conv3_dgrad_fused builds internally.  `out` buffers sized by unetr_conv3_packed_bytes / _packed_1x1_bytes. */
+typedef struct { const float* w; void* out; int Cin, Cout, kind; } unetr_pack_problem;
+int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, int prec, void* stream);
 /* (mean, rstd) from InstanceNorm partial sums part[B][nchunk][2][C] (sum, sum of squares) */
 int unetr_instnorm_stats_finalize(const float* part, int nchunk, int B, long V, int C, float eps, float* stats, void* stream);
 int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
