@@ -33,19 +33,6 @@ def workspace(device):
     return ws
 
 
-_SIDE = {}
-
-
-def side_stream(device):
-    """The second HIP stream used to overlap independent branches of the network (one per device)."""
-    key = (device.type, device.index)
-    st = _SIDE.get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _SIDE[key] = st
-    return st
-
-
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -99,7 +86,7 @@ def _ret(w, g, deferred=False):
 # In arena mode the Linear weight/bias gradients of the ViT are not needed by anything inside backward, so they
 # are queued and executed at the end of the backward pass as ONE grouped GEMM launch + ONE grouped column-sum
 # launch (csrc: gemm_grouped_wgrad_kernel, colsum_grouped_kernel) instead of ~90 small latency-bound launches.
-_DEFER = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0, "keep": [], "side": None}
+_DEFER = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0}
 
 
 def _arm_flush():
@@ -159,34 +146,11 @@ def _launch_deferred(wq, cq, wbq=()):
         call("unetr_colsum_grouped", arr, len(cq), _stream())
 
 
-def flush_deferred_side():
-    """Experiment, OFF by default (UNETR_AMD_WGRAD_OVERLAP=1 enables it): at the end of one transformer block's backward its
-    queued weight-gradient GEMMs and column sums go to the side stream at once, to run next to the latency-bound
-    data-gradient chain of the blocks below; the end-of-backward flush joins the side stream.  Measured inside the captured
-    step: 9.17 ms against 8.60 ms for the single grouped launch at the end -- the 432-tile weight-gradient launches take
-    the CUs the chain's small kernels need for their next dispatch, and twelve launches lose the fill of one."""
-    wq, cq, wbq = _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"]
-    if not (wq or cq or wbq) or os.environ.get("UNETR_AMD_WGRAD_OVERLAP", "0") != "1":
-        return
-    dev = (wq[0][0] if wq else (wbq[0][0] if wbq else cq[0][0])).device
-    main, side = torch.cuda.current_stream(dev), side_stream(dev)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        _launch_deferred(wq, cq, wbq)
-    _DEFER["keep"].append((wq, cq, wbq))
-    _DEFER["side"] = side
-    _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"] = [], [], []
-
-
 def flush_deferred():
     """Runs at the end of the backward pass (autograd engine callback) on the backward stream."""
     wq, cq, wbq, params = _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"], _DEFER["params"]
     _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"], _DEFER["params"], _DEFER["armed"] = [], [], [], [], False
     _launch_deferred(wq, cq, wbq)
-    if _DEFER["side"] is not None:
-        torch.cuda.current_stream(_DEFER["side"].device).wait_stream(_DEFER["side"])     # join: everything below sees the gradients
-        _DEFER["side"] = None
-    _DEFER["keep"] = []
     for p in params:
         for cb in _GRAD_READY_CB:
             cb(p)
@@ -787,7 +751,6 @@ class TransformerBlockFn(torch.autograd.Function):
         dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         if fast:
             _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
-        flush_deferred_side()
         return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None)
 
 

@@ -216,7 +216,6 @@ class UNETR(nn.Module):
         self.out_channels = out_channels
         self.img_size = tuple(img_size)
         self.precision = default_precision()
-        self.overlap_encoder1 = os.environ.get("UNETR_AMD_OVERLAP", "0") == "1"
 
         f = feature_size
         self.vit = _ViT(in_channels, img_size, self.patch_size, hidden_size, mlp_dim, self.num_layers)
@@ -292,25 +291,7 @@ class UNETR(nn.Module):
         pe = self.vit.patch_embedding
         lin = pe.patch_embeddings[1]
         L = pe.position_embeddings.shape[1]
-        # encoder1 (full-resolution convs on the raw image, unetr.py:195) is independent of the ViT: at batch 2 the ViT's
-        # kernels occupy a fraction of the CUs, so encoder1 runs on a second HIP stream next to it.  Autograd replays a
-        # node's backward on its forward stream, so encoder1's backward overlaps the ViT's backward as well.
         Fn._require_gpu(x_in)
-        main = torch.cuda.current_stream(x_in.device)
-        if self.overlap_encoder1:
-            side = Fn.side_stream(x_in.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                enc1_side = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec)
-            x_in.record_stream(side)
-
-            def enc1_fn():
-                main.wait_stream(side)
-                enc1_side.record_stream(main)
-                return enc1_side
-        else:
-            def enc1_fn():
-                return Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec)
         x = Fn.PatchEmbedFn.apply(x_in, lin.weight, lin.bias, pe.position_embeddings, self.patch_size[0], prec)
         hidden_states_out = []
         for blk in self.vit.blocks:
@@ -321,7 +302,7 @@ class UNETR(nn.Module):
             hidden_states_out.append(x)
         x = Fn.LayerNormFn.apply(x, self.vit.norm.weight, self.vit.norm.bias,
                                  Fn._bf16_path(prec, self.hidden_size, self.vit.blocks[0].mlp.linear1.weight.shape[0]))
-        enc1 = enc1_fn()
+        enc1 = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec)
         enc = []
         for tap, blk in ((3, self.encoder2), (6, self.encoder3), (9, self.encoder4)):
             t = Fn.TconvFn.apply(self._tokens_cl(hidden_states_out[tap], B), blk.transp_conv_init.conv.weight, prec)
