@@ -377,3 +377,39 @@ def test_sliding_window_inference_and_dice_metric(pkg, dev):
     raw_h = m(pr.to(dev), lr.to(dev))
     assert torch.isnan(raw_h[:, 1]).all() and torch.allclose(raw_h.cpu(), raw_r, atol=1e-6, equal_nan=True)
     assert torch.allclose(m.aggregate().cpu(), val_r, atol=1e-6)
+
+
+def test_training_trajectory_tracks_oracle(pkg, dev):
+    """24 optimiser steps of the reference loop (unetr_segmentation_3d.py:220-226) on a fixed batch: the HIP path (flat
+    arenas + this package's AdamW, i.e. exactly what bench.py runs) must follow the CPU oracle's loss curve.  Adam
+    amplifies rounding differences step after step (the fp32 CPU oracle itself drifts 1e-3 .. 4e-3 from the fp64 one over
+    40 steps, depending on the width of the model), so the yardstick is the fp64 oracle: tight over the first 10 steps,
+    bounded over all 24."""
+    from oracle.unetr_oracle import OracleUNETR, oracle_train_step, synthetic_volume
+    Fn = pkg.functional
+    x, y = synthetic_volume(2, 1, 32, 2, seed=31)
+    torch.manual_seed(5)
+    ref = OracleUNETR(**C1)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    ref = ref.double()
+    o_ref = torch.optim.AdamW(ref.parameters(), lr=3e-4, weight_decay=1e-5)
+    c64 = [float(oracle_train_step(ref, o_ref, x.double(), y.double())) for _ in range(24)]
+    assert c64[-1] < 0.95 * c64[0]                         # the problem actually trains
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    xd, yd = x.to(dev), y.to(dev)
+    for precision, tight, loose in (("fp32", 2e-3, 2e-2), ("bf16", 1e-2, 3e-2)):
+        hip = pkg.UNETRLogits(**C1)
+        hip.load_state_dict(sd0, strict=True)
+        hip = hip.to(dev)
+        hip.precision = precision
+        flat = hip.use_flat_buffers()
+        opt = pkg.AdamW(hip.parameters(), lr=3e-4, weight_decay=1e-5, flat=flat)
+        devs = []
+        for ref_loss in c64:
+            loss = crit(hip(xd), yd)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            devs.append(abs(float(loss.detach()) - ref_loss) / abs(ref_loss))
+        assert max(devs[:10]) < tight and max(devs) < loose, (precision, max(devs[:10]), max(devs))
+        Fn.clear_grad_sinks()
