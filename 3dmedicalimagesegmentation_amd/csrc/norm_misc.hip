@@ -290,24 +290,42 @@ in_bwd_reduce_kernel(const float* __restrict__ dy, long lddy, const float* __res
     if (ph < nphase) {
         const float* s1 = sa + ((long)b * C + 4 * cv) * 2;
         const float* s2 = x2 ? sb + ((long)b * C + 4 * cv) * 2 : nullptr;
-        for (long v = v0 + ph; v < v1; v += nphase) {
-            long vox = (long)b * V + v;
-            f32x4 g = *(const f32x4*)(dy + vox * lddy + 4 * cv);
-            f32x4 t = *(const f32x4*)(x + vox * ldx + 4 * cv), n1, n2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // statistics of this thread's four channels, loaded once
+        float mu1[4], rs1[4], mu2[4], rs2[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) n1[e] = (t[e] - s1[2 * e]) * s1[2 * e + 1];
-            if (x2) {
-                f32x4 t2 = *(const f32x4*)(x2 + vox * ldx2 + 4 * cv);
+        for (int e = 0; e < 4; ++e) {
+            mu1[e] = s1[2 * e]; rs1[e] = s1[2 * e + 1];
+            mu2[e] = x2 ? s2[2 * e] : 0.f; rs2[e] = x2 ? s2[2 * e + 1] : 0.f;
+        }
+        // four voxels per iteration: all their loads are issued before the first use (a pure-read pass with one voxel in
+        // flight per thread ran at 4.2 TB/s against 6.8 TB/s for the read+write passes)
+        constexpr int U = 4;
+        for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+            f32x4 g[U], t[U], t2[U];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) n2[e] = (t2[e] - s2[2 * e]) * s2[2 * e + 1];
+            for (int u = 0; u < U; ++u) {
+                const long vv = v + (long)u * nphase;
+                const long vox = (long)b * V + (vv < v1 ? vv : v);      // clamped: re-reads voxel v, masked below
+                g[u] = *(const f32x4*)(dy + vox * lddy + 4 * cv);
+                t[u] = *(const f32x4*)(x + vox * ldx + 4 * cv);
+                t2[u] = x2 ? *(const f32x4*)(x2 + vox * ldx2 + 4 * cv) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if (lrelu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = (n1[e] + n2[e]) > 0.f ? g[e] : 0.01f * g[e];
+            for (int u = 0; u < U; ++u) {
+                const float live = (v + (long)u * nphase < v1) ? 1.f : 0.f;
+                f32x4 n1, n2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    n1[e] = (t[u][e] - mu1[e]) * rs1[e];
+                    n2[e] = (t2[u][e] - mu2[e]) * rs2[e];
+                    float ge = g[u][e] * live;
+                    if (lrelu) ge = (n1[e] + n2[e]) > 0.f ? ge : 0.01f * ge;
+                    g[u][e] = ge;
+                }
+                acc[0] += g[u];
+                acc[1] += g[u] * n1;
+                acc[2] += g[u] * n2;
             }
-            acc[0] += g;
-            acc[1] += g * n1;
-            acc[2] += g * n2;
         }
     }
     in_block_reduce<3>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 3 * C, C);
