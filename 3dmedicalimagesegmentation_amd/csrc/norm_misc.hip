@@ -7,9 +7,10 @@
 
 namespace {
 
-constexpr int LN_MAXV = 8;  // float4 per lane -> H <= 2048
+constexpr int LN_MAXV_MAX = 8;  // float4 per lane -> H <= 2048; kernels are instantiated for 3 (H <= 768), 4 and 8
 
 // --------------------------------------------------------------------------------------- LayerNorm
+template <int LN_MAXV>
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                      float* __restrict__ y, uint16_t* __restrict__ yb, float* __restrict__ mean, float* __restrict__ rstd,
@@ -53,6 +54,7 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
 }
 
 constexpr int LN_RPB = 4;   // rows per block in backward (one per wave): 108 workgroups at M = 432 instead of 27
+template <int LN_MAXV>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                      const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
@@ -558,9 +560,10 @@ inline int grid_for(long total, int per_block = 256, int cap = 8192) {
 extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16,
                                    float* mean, float* rstd, int M, int H, float eps, void* stream) {
     if (!x || !gamma || !beta || (!y && !y_bf16) || !mean || !rstd || M <= 0) return UNETR_ERR_ARG;
-    if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                       (uint16_t*)y_bf16, mean, rstd, M, H, eps);
+    if ((H & 3) || H > LN_MAXV_MAX * 256) return UNETR_ERR_UNSUPPORTED;
+#define LN_FWD(V_) hipLaunchKernelGGL(layernorm_fwd_kernel<V_>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, \
+                                      (uint16_t*)y_bf16, mean, rstd, M, H, eps)
+    if (H <= 768) LN_FWD(3); else if (H <= 1024) LN_FWD(4); else LN_FWD(8);
     return unetr_check_launch();
 }
 
@@ -568,12 +571,13 @@ extern "C" int unetr_layernorm_bwd(const float* dy, const float* x, const float*
                                    const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
                                    float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || ((dgamma == nullptr) != (dbeta == nullptr)) || M <= 0) return UNETR_ERR_ARG;
-    if ((H & 3) || H > LN_MAXV * 256) return UNETR_ERR_UNSUPPORTED;
+    if ((H & 3) || H > LN_MAXV_MAX * 256) return UNETR_ERR_UNSUPPORTED;
     int nblk = cdiv(M, LN_RPB);
     if ((size_t)nblk * 2 * H * sizeof(float) > ws_bytes || !ws) return UNETR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, x, gamma, mean, rstd, dx,
-                       (uint16_t*)dx_bf16, dres, ws, M, H);
+#define LN_BWD(V_) hipLaunchKernelGGL(layernorm_bwd_kernel<V_>, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, x, gamma, mean, \
+                                      rstd, dx, (uint16_t*)dx_bf16, dres, ws, M, H)
+    if (H <= 768) LN_BWD(3); else if (H <= 1024) LN_BWD(4); else LN_BWD(8);
     // dgamma == dbeta == NULL: the caller reduces the [nblk][2][H] partials left in ws itself (grouped, off the critical path)
     if (dgamma) hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
     return unetr_check_launch();

@@ -126,7 +126,7 @@ def test_colsum(pkg, dev):
         assert relerr(Fn.colsum(x.to(dev), M, N, N), x.sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("M,H", [(432, 768), (8, 128), (50, 2048)])
+@pytest.mark.parametrize("M,H", [(432, 768), (8, 128), (50, 2048), (33, 1024), (19, 772)])   # the 3 / 4 / 8-vector instantiations
 def test_layernorm(pkg, dev, M, H):
     Fn = pkg.functional
     x, w, b, dy, dres = g(M, H, seed=1) * 2 + 0.5, g(H, seed=2), g(H, seed=3), g(M, H, seed=4), g(M, H, seed=5)
