@@ -257,18 +257,20 @@ def invalidate_weight_shadows():
 
 def register_weight_shadow(w, shadow):
     """flat-arena mode: `shadow` is the bf16 view the optimizer kernel keeps in step with `w`"""
-    _SHADOW[id(w)] = [shadow, w._version, _WEIGHT_EPOCH[0], True, weakref.ref(w)]   # caller has just cast it
+    _SHADOW[id(w)] = [shadow, w._version, _WEIGHT_EPOCH[0], True, weakref.ref(w), w.data_ptr()]   # caller has just cast it
 
 
 def weight_bf16(w):
     ent = _SHADOW.get(id(w))
     if ent is None or ent[4]() is not w or ent[0].shape != w.shape or ent[0].device != w.device:
-        ent = [torch.empty(w.shape, dtype=torch.bfloat16, device=w.device), -1, -1, False, weakref.ref(w)]
+        ent = [torch.empty(w.shape, dtype=torch.bfloat16, device=w.device), -1, -1, False, weakref.ref(w), 0]
         _SHADOW[id(w)] = ent
-    fresh = ent[1] == w._version and (ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
+    # (a re-pointed parameter -- `p.data = other` -- keeps its version counter: the storage address is part of the key)
+    fresh = ent[1] == w._version and ent[5] == w.data_ptr() and (
+        ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
     if not fresh:
         cast_bf16(w.detach(), out=ent[0])
-        ent[1], ent[2] = w._version, _WEIGHT_EPOCH[0]
+        ent[1], ent[2], ent[5] = w._version, _WEIGHT_EPOCH[0], w.data_ptr()
     return ent[0]
 
 
@@ -288,12 +290,13 @@ def conv_pack_get(w, kind, prec):
         lib = _capi.load()
         nbytes = lib.unetr_conv3_packed_bytes(cin, cout, kind, prec) if kind <= 1 else (
             lib.unetr_conv3_packed_1x1_bytes(cin, cout, prec) if kind == 2 else lib.unetr_conv3_packed_1x1_bytes(cout, cin, prec))
-        ent = [torch.empty(nbytes, dtype=torch.uint8, device=w.device), -1, -1, False, weakref.ref(w)]
+        ent = [torch.empty(nbytes, dtype=torch.uint8, device=w.device), -1, -1, False, weakref.ref(w), 0]
         _PACKS[key] = ent
-    fresh = ent[1] == w._version and (ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
+    fresh = ent[1] == w._version and ent[5] == w.data_ptr() and (
+        ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
     if not fresh:
         _pack_launch([(w, ent[0], cin, cout, kind)], prec)
-        ent[1], ent[2] = w._version, _WEIGHT_EPOCH[0]
+        ent[1], ent[2], ent[5] = w._version, _WEIGHT_EPOCH[0], w.data_ptr()
     return ent[0]
 
 
@@ -313,7 +316,7 @@ def refresh_conv_packs():
         if w is None:
             del _PACKS[key]
             continue
-        if not w.is_cuda or ent[1] != w._version:
+        if not w.is_cuda or ent[1] != w._version or ent[5] != w.data_ptr():
             continue                                  # torch touched the parameter: conv_pack_get re-packs on demand
         by_prec.setdefault(key[2], []).append((w, ent[0], w.shape[1], w.shape[0], key[1]))
         ent[3] = True
@@ -325,7 +328,7 @@ def shadow_ptr_for_update(w):
     """optimizer side: where the bf16 copy of `w` lives, if the GEMMs have asked for one; the caller's kernel rewrites
     it together with the fp32 master, which makes the shadow optimizer-maintained from here on"""
     ent = _SHADOW.get(id(w))
-    if ent is None or ent[4]() is not w or ent[1] != w._version:
+    if ent is None or ent[4]() is not w or ent[1] != w._version or ent[5] != w.data_ptr():
         return None
     ent[3] = True
     return ent[0].data_ptr()

@@ -413,3 +413,55 @@ def test_training_trajectory_tracks_oracle(pkg, dev):
             devs.append(abs(float(loss.detach()) - ref_loss) / abs(ref_loss))
         assert max(devs[:10]) < tight and max(devs) < loose, (precision, max(devs[:10]), max(devs))
         Fn.clear_grad_sinks()
+
+
+def test_derived_weight_copies_follow_every_update(pkg, dev):
+    """bf16 weight shadows and packed conv weights are caches of the fp32 masters: whichever way the masters change --
+    this package's AdamW (which maintains the copies itself), a torch optimizer, in-place edits, load_state_dict, a
+    re-pointed .data -- the next forward must see the new values (checked against the oracle carrying the same weights)."""
+    from oracle.unetr_oracle import OracleUNETR, synthetic_volume
+    torch.manual_seed(7)
+    ref = OracleUNETR(**C1)
+    hip = pkg.UNETR(**C1).to(dev)
+    hip.precision = "bf16"                      # both caches are in play in bf16 mode
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    x, y = synthetic_volume(1, 1, 32, 2, seed=8)
+    xd, yd = x.to(dev), y.to(dev)
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+
+    def check(tag):
+        ref.load_state_dict({k: v.detach().cpu() for k, v in hip.state_dict().items()}, strict=True)
+        with torch.no_grad():
+            lr = ref(x)[1]
+            lh = hip(xd)[1]
+        assert relerr(lh, lr) < 5e-2, (tag, relerr(lh, lr))
+        return lh
+
+    base = check("initial")
+    # 1. this package's AdamW, per-tensor mode (shadows / packs registered by the forward above become optimizer-maintained)
+    opt = pkg.AdamW(hip.parameters(), lr=5e-2, weight_decay=0.0)
+    crit(hip(xd)[1], yd).backward()
+    opt.step(); opt.zero_grad(set_to_none=True)
+    after = check("AdamW")
+    assert relerr(after, base) > 1e-2                      # the weights really moved
+    # 2. a torch optimizer (bumps the version counters)
+    sgd = torch.optim.SGD(hip.parameters(), lr=0.5)
+    crit(hip(xd)[1], yd).backward()
+    sgd.step(); sgd.zero_grad(set_to_none=True)
+    check("SGD")
+    # 3. in-place edits of one Linear and one conv weight
+    with torch.no_grad():
+        hip.vit.blocks[0].mlp.linear1.weight.mul_(1.5)
+        hip.decoder2.conv_block.conv1.conv.weight.add_(0.05)
+        hip.encoder1.layer.conv3.conv.weight.mul_(-1.0)
+    check("in-place")
+    # 4. load_state_dict of fresh weights
+    torch.manual_seed(9)
+    hip.load_state_dict(OracleUNETR(**C1).state_dict(), strict=True)
+    check("load_state_dict")
+    # 5. re-pointed .data (same shape, same device, version counter unchanged)
+    w = hip.decoder3.conv_block.conv2.conv.weight
+    w.data = (w.data * 2.0).clone()
+    q = hip.vit.blocks[1].attn.qkv.weight
+    q.data = (q.data * 0.5).clone()
+    check("re-pointed .data")
