@@ -272,9 +272,12 @@ __device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const float* __re
             for (int c4 = 0; c4 < NQ; ++c4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool oke = ok && c + 4 * c4 + e < Cin;
-                    float t = *(oke ? q + 4 * c4 + e : xb);
-                    R.v[j][c4][e] = oke ? t : 0.f;
+                    // predicated scalar load (an exec-masked load, no wait): with a single input channel 15 of the 16
+                    // element slots of a voxel are padding, and loading a clamped address for each of them cost more
+                    // than the real data
+                    float t = 0.f;
+                    if (ok && c + 4 * c4 + e < Cin) t = q[4 * c4 + e];
+                    R.v[j][c4][e] = t;
                 }
             }
             bits = 0xffffffffu;
