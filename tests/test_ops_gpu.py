@@ -451,3 +451,21 @@ def test_ranking_losses(pkg, dev, kind, shape, slice_dim, init_idx):
     assert relerr(loss, ref) < 2e-5
     (loss * 2.0).backward()
     assert relerr(fd.grad, 2.0 * fr.grad) < 2e-4
+
+
+@pytest.mark.gpu
+def test_ranking_losses_vs_reference_fixture(pkg, dev):
+    """The HIP ranking kernels against outputs of the REFERENCE's own code (tests/golden/ranking_ref.npz, written by
+    tests/golden/make_ranking_golden.py from unetr_ranking_pretraining_3d.py:59-133,202-236): all three slice axes, both
+    loss kinds, two feature shapes; loss within 2e-5 relative, input gradient within 2e-4 of its max (fp32 kernels vs
+    the reference's fp64 run; the reference's own fp32 run differs from its fp64 run by up to 2e-6 / loss)."""
+    from test_oracle_cpu import ranking_cases
+    n = 0
+    for key, feat, axis, kind, init_idx, T, loss64, loss32, grad in ranking_cases():
+        fd = feat.to(dev).requires_grad_(True)
+        loss = pkg.ranking_loss(fd, axis, init_idx, T, kind=kind)
+        assert abs(loss.item() - loss64) <= 2e-5 * abs(loss64), (key, loss.item(), loss64)
+        loss.backward()
+        assert relerr(fd.grad, grad) < 2e-4, key
+        n += 1
+    assert n == 12

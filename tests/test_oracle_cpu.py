@@ -108,8 +108,48 @@ def test_golden_fixture_regression():
             assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-9, k
 
 
+RANK_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ranking_ref.npz")
+
+
+def ranking_cases():
+    """(key, feat, axis, kind, init_idx, T, loss_f64, loss_f32, grad) from tests/golden/ranking_ref.npz -- outputs of the
+    REFERENCE's own extract_triplets_more_partitions / BTLoss / ContrastiveLoss (unetr_ranking_pretraining_3d.py:59-133,
+    202-236), executed by tests/golden/make_ranking_golden.py in the build container"""
+    z = np.load(RANK_GOLD)
+    T = float(z["temperature"])
+    for si in range(len(z["shapes"])):
+        feat = torch.from_numpy(z[f"s{si}_feat"])
+        for axis in (2, 3, 4):
+            for kind in ("ranking", "contrastive"):
+                k = f"s{si}_ax{axis}_{kind}"
+                yield (k, feat, axis, kind, int(z[k + "_init_idx"]), T, float(z[k + "_loss_f64"]), float(z[k + "_loss_f32"]),
+                       torch.from_numpy(z[k + "_grad"]))
+
+
+def test_ranking_oracle_pinned_by_reference_outputs():
+    """The oracle's triplet construction and both losses reproduce what the reference's own functions returned on the
+    same inputs: loss to 1e-10 relative in fp64 (same arithmetic, same summation order), input gradient to fp32
+    rounding of the stored fp64 gradient.  This pins oracle_extract_triplets (order and membership of all 576 triplets
+    -- a wrong pairing changes the loss), oracle_bt_loss, oracle_contrastive_loss and oracle_cosine_sim_171."""
+    n = 0
+    for key, feat, axis, kind, init_idx, T, loss64, loss32, grad in ranking_cases():
+        f = feat.double().requires_grad_(True)
+        f1, f2 = torch.split(f, [2, 2], dim=0)
+        r, s, d = oracle_extract_triplets(f1, f2, axis, init_idx)
+        assert len(r) == len(s) == len(d) == 576 and r[0].shape == (feat.shape[1], feat.shape[2] ** 2)
+        loss = (oracle_bt_loss if kind == "ranking" else oracle_contrastive_loss)(r, s, d, T)
+        assert abs(loss.item() - loss64) <= 1e-10 * abs(loss64), key
+        assert abs(loss.item() - loss32) <= 2e-5 * abs(loss64), key      # the reference's fp32 run, for scale
+        loss.backward()
+        err = (f.grad - grad.double()).abs().max().item()
+        assert err <= 2e-7 * grad.abs().max().item(), (key, err)
+        n += 1
+    assert n == 12
+
+
 def test_ranking_losses_triplet_structure():
-    # unetr_ranking_pretraining_3d.py:59-133: 4 partitions x 12 ordered in-partition pairs x 12 other slices = 576
+    # unetr_ranking_pretraining_3d.py:59-133: 4 partitions x 12 ordered in-partition pairs x 12 other slices = 576;
+    # the reference-pinned value checks are in test_ranking_oracle_pinned_by_reference_outputs above
     torch.manual_seed(0)
     f = torch.randn(4, 8, 12, 12, 12)
     f1, f2 = torch.split(f, [2, 2], dim=0)
