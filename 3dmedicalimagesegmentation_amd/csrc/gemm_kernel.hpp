@@ -20,6 +20,14 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ loaders
+// all-ones when ok, zero otherwise, as a value the optimizer treats as unknown (so `bits & mask` stays a v_and_b32 right
+// where it is written instead of becoming a select that hipcc folds into a conditional load)
+__device__ __forceinline__ uint32_t opaque_mask(bool ok) {
+    uint32_t m = ok ? 0xFFFFFFFFu : 0u;
+    asm("" : "+v"(m));
+    return m;
+}
+
 template <bool VEC>
 struct LdRowT {  // element(row,k) = p[b*stride + row*ld + k]        (k contiguous)
     // Branch-free on purpose: out-of-range chunks load from a clamped in-range address and are zeroed by a
@@ -32,21 +40,23 @@ struct LdRowT {  // element(row,k) = p[b*stride + row*ld + k]        (k contiguo
     __device__ __forceinline__ void load(int b, int row, int k, int kend, float* v) const {
         const bool ok = row < rows && k < kend;
         const float* q = p + (long)b * stride + (long)(ok ? row : 0) * ld + (ok ? k : 0);
-        // out-of-range data is masked by a MULTIPLY, not a select: hipcc turns `ok ? loaded : 0` back into a
-        // conditional load (one branch + s_waitcnt per chunk); the clamped address always holds real, finite data
-        const float okf = ok ? 1.f : 0.f;
+        // out-of-range data is masked by an AND on the loaded BITS with an all-ones / zero word the compiler cannot see
+        // through (opaque_mask): a select (`ok ? loaded : 0`) is turned back into a conditional load by hipcc (one branch +
+        // s_waitcnt per chunk), and a multiply by 0 lets one Inf / NaN at the clamped address poison every padded lane
+        const uint32_t mk = opaque_mask(ok);
         if constexpr (VEC) {
 #pragma unroll
             for (int c = 0; c < CH / 4; ++c) {
-                f32x4 t = *(const f32x4*)(q + 4 * c);
-                v[4 * c] = t[0] * okf; v[4 * c + 1] = t[1] * okf; v[4 * c + 2] = t[2] * okf; v[4 * c + 3] = t[3] * okf;
+                u32x4 t = *(const u32x4*)(q + 4 * c);
+                v[4 * c] = __uint_as_float(t[0] & mk); v[4 * c + 1] = __uint_as_float(t[1] & mk);
+                v[4 * c + 2] = __uint_as_float(t[2] & mk); v[4 * c + 3] = __uint_as_float(t[3] & mk);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const bool okj = ok && (k + j < kend);
-                float t = q[okj ? j : 0];
-                v[j] = t * (okj ? 1.f : 0.f);
+                uint32_t t = __float_as_uint(q[okj ? j : 0]);
+                v[j] = __uint_as_float(t & opaque_mask(okj));
             }
         }
     }
@@ -64,8 +74,8 @@ struct LdCol {  // element(row,k) = p[b*stride + k*ld + row]        (row contigu
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const bool ok = okr && (k + j < kend);
-            float t = q[(long)(ok ? k + j : 0) * ld];
-            v[j] = t * (ok ? 1.f : 0.f);       // mask by multiply (see LdRowT)
+            uint32_t t = __float_as_uint(q[(long)(ok ? k + j : 0) * ld]);
+            v[j] = __uint_as_float(t & opaque_mask(ok));       // bit mask, not a multiply (see LdRowT)
         }
     }
 };

@@ -101,7 +101,8 @@ class GradAllReducer:
         self.stream = torch.cuda.Stream(device=fg.device) if self.is_cuda else None
         self._hooks = []
         self._cb = self._on_grad
-        Fn._GRAD_READY_CB.append(self._cb)
+        self._state = flat.get("state") or Fn._DEFAULT_STATE      # the model's ArenaState (UNETR.use_flat_buffers)
+        self._state.ready_cb.append(self._cb)
 
     # broadcast rank 0's parameters so every rank starts from the same weights
     def broadcast_parameters(self, params: Iterable[torch.nn.Parameter]):
@@ -166,9 +167,8 @@ class GradAllReducer:
             h.remove()
         self._hooks = []
         if self.flat is not None:
-            from . import functional as Fn
-            if self._cb in Fn._GRAD_READY_CB:
-                Fn._GRAD_READY_CB.remove(self._cb)
+            if self._cb in self._state.ready_cb:
+                self._state.ready_cb.remove(self._cb)
 
 
 class _null:

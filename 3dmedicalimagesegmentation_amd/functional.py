@@ -23,8 +23,8 @@ _WS_BYTES = 256 << 20
 
 
 def workspace(device):
-    """Scratch for split-K slabs and reduction partials: one buffer per (device, stream), because the encoder1 branch
-    runs on a side stream concurrently with the ViT (stream-ordered reuse inside a stream is safe)."""
+    """Scratch for split-K slabs and reduction partials: one buffer per (device, stream) -- reuse inside a stream is
+    stream-ordered and therefore safe; two streams (e.g. two models stepping concurrently) never share one."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
@@ -39,60 +39,100 @@ def _stream():
 
 # ---- gradient sinks: parameters registered here get their gradients written straight into a slice of one flat
 # arena (UNETR.use_flat_buffers), so AdamW is one launch and the data-parallel all-reduce needs no flatten copies.
-_GRAD_SINK = {}
+# Everything mutable about that fast path -- the sink table, the deferred weight-gradient queues, the readiness
+# callbacks of the data-parallel reducer -- belongs to ONE ArenaState per model (UNETR.use_flat_buffers creates it), so
+# several models in one process do not share a queue.  The module-level table only maps a parameter's storage address
+# to its owner; entries are validated against the live parameter (weak reference + address) on every lookup.
+class ArenaState:
+    def __init__(self):
+        self.sinks = {}            # data_ptr -> (weakref(param), arena view)
+        self.ready_cb = []         # data-parallel reducers: called with a parameter once its arena gradient is final
+        self.defer = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0}
+
+    def reset_deferred(self):
+        """Drop whatever a backward pass that raised left queued (its end-of-pass callback never ran): without this the
+        queue stays armed, no later pass re-arms the flush, and AdamW steps on stale arena gradients."""
+        d = self.defer
+        d["wgrad"], d["wgrad_b"], d["colsum"], d["params"], d["armed"] = [], [], [], [], False
+
+    def clear(self):
+        for k in list(self.sinks):
+            _GRAD_SINK.pop(k, None)
+        self.sinks.clear()
+        self.reset_deferred()
 
 
-def register_grad_sinks(params_and_views):
+_DEFAULT_STATE = ArenaState()
+_GRAD_SINK = {}                    # data_ptr -> ArenaState owning that parameter
+
+
+def register_grad_sinks(params_and_views, state=None):
+    state = state if state is not None else _DEFAULT_STATE
     for p, view in params_and_views:
-        _GRAD_SINK[p.data_ptr()] = (p, view)
+        state.sinks[p.data_ptr()] = (weakref.ref(p), view)
+        _GRAD_SINK[p.data_ptr()] = state
+    return state
 
 
-def clear_grad_sinks():
+def clear_grad_sinks(state=None):
+    """forget the arena registrations (of one model's state, or of every model when called without one)"""
+    if state is not None:
+        state.clear()
+        return
+    for st in set(_GRAD_SINK.values()):
+        st.clear()
+    _DEFAULT_STATE.clear()
     _GRAD_SINK.clear()
+
+
+def _sink(w):
+    """(state, param, view) when tensor `w` IS a registered, still-living parameter at its registered address"""
+    st = _GRAD_SINK.get(w.data_ptr())
+    if st is None:
+        return None
+    ent = st.sinks.get(w.data_ptr())
+    if ent is None:
+        return None
+    p = ent[0]()
+    if p is None or p.data_ptr() != w.data_ptr() or ent[1].shape != w.shape:
+        return None
+    return st, p, ent[1]
 
 
 def _gout(w):
     """Destination for the gradient of parameter tensor `w`: its arena slice when registered and no gradient is
     currently attached (accumulating into an existing .grad must not alias it), else None (fresh tensor)."""
-    ent = _GRAD_SINK.get(w.data_ptr())
-    if ent is None:
+    ent = _sink(w)
+    if ent is None or ent[1].grad is not None:
         return None
-    p, view = ent
-    if p.grad is not None or view.shape != w.shape:
-        return None
-    return view
-
-
-_GRAD_READY_CB = []
+    return ent[2]
 
 
 def _ret(w, g, deferred=False):
     """What a Function.backward returns for parameter `w`: when `g` was (or, if deferred, will be) written into
     w's arena slice, attach the slice as .grad directly (autograd would clone it: the arena keeps a second
     reference) and return None.  Readiness callbacks (data-parallel buckets) fire now, or at flush if deferred."""
-    ent = _GRAD_SINK.get(w.data_ptr())
-    if ent is not None and g is not None and g.data_ptr() == ent[1].data_ptr():
-        ent[0].grad = ent[1]
+    ent = _sink(w) if g is not None else None
+    if ent is not None and g.data_ptr() == ent[2].data_ptr():
+        st, p, view = ent
+        p.grad = view
         if deferred:
-            _DEFER["params"].append(ent[0])
+            st.defer["params"].append(p)
         else:
-            for cb in _GRAD_READY_CB:
-                cb(ent[0])
+            for cb in st.ready_cb:
+                cb(p)
         return None
     return g
 
 
 # ---- deferred, grouped weight gradients -------------------------------------------------------------------
 # In arena mode the Linear weight/bias gradients of the ViT are not needed by anything inside backward, so they
-# are queued and executed at the end of the backward pass as ONE grouped GEMM launch + ONE grouped column-sum
-# launch (csrc: gemm_grouped_wgrad_kernel, colsum_grouped_kernel) instead of ~90 small latency-bound launches.
-_DEFER = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0}
-
-
-def _arm_flush():
-    if not _DEFER["armed"]:
-        _DEFER["armed"] = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+# are queued (per ArenaState) and executed at the end of the backward pass as ONE grouped GEMM launch + ONE grouped
+# column-sum launch (csrc: gemm_grouped_wgrad_kernel, colsum_grouped_kernel) instead of ~90 small latency-bound launches.
+def _arm_flush(st):
+    if not st.defer["armed"]:
+        st.defer["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_deferred(st))
 
 
 def wgrad_or_defer(dy, x, prec, w, dyb=None, xb=None):
@@ -106,13 +146,14 @@ def wgrad_or_defer(dy, x, prec, w, dyb=None, xb=None):
         dw = torch.empty(dyb.shape[1], xb.shape[1], dtype=torch.float32, device=dyb.device)
         _launch_deferred((), (), [(dyb, xb, dw)])
         return dw
+    st = _GRAD_SINK[w.data_ptr()]
     if twins:
-        _DEFER["wgrad_b"].append((dyb, xb, out))
-        _arm_flush()
+        st.defer["wgrad_b"].append((dyb, xb, out))
+        _arm_flush(st)
         return _ret(w, out, deferred=True)
-    _DEFER["wgrad"].append((dy, x, out))
-    _DEFER["prec"] = prec
-    _arm_flush()
+    st.defer["wgrad"].append((dy, x, out))
+    st.defer["prec"] = prec
+    _arm_flush(st)
     return _ret(w, out, deferred=True)
 
 
@@ -121,12 +162,13 @@ def colsum_or_defer(x, M, N, ld, b, view_shape=None):
     if out is None:
         r = colsum(x, M, N, ld)
         return r.view(view_shape) if view_shape is not None else r
-    _DEFER["colsum"].append((x, out, M, N, ld))
-    _arm_flush()
+    st = _GRAD_SINK[b.data_ptr()]
+    st.defer["colsum"].append((x, out, M, N, ld))
+    _arm_flush(st)
     return _ret(b, out, deferred=True)
 
 
-def _launch_deferred(wq, cq, wbq=()):
+def _launch_deferred(wq, cq, wbq=(), prec=0):
     if wbq:
         arr = (_capi.GroupedProblem * len(wbq))()
         for i, (dyb, xb, out) in enumerate(wbq):
@@ -138,7 +180,7 @@ def _launch_deferred(wq, cq, wbq=()):
         for i, (dy, x, out) in enumerate(wq):
             arr[i].dy, arr[i].x, arr[i].dw = dy.data_ptr(), x.data_ptr(), out.data_ptr()
             arr[i].M, arr[i].N, arr[i].K = dy.shape[0], dy.shape[1], x.shape[1]
-        call("unetr_gemm_grouped_wgrad", arr, len(wq), _DEFER["prec"], _stream())
+        call("unetr_gemm_grouped_wgrad", arr, len(wq), prec, _stream())
     if cq:
         arr = (_capi.ColsumProblem * len(cq))()
         for i, (x, out, M, N, ld) in enumerate(cq):
@@ -146,13 +188,15 @@ def _launch_deferred(wq, cq, wbq=()):
         call("unetr_colsum_grouped", arr, len(cq), _stream())
 
 
-def flush_deferred():
+def flush_deferred(st=None):
     """Runs at the end of the backward pass (autograd engine callback) on the backward stream."""
-    wq, cq, wbq, params = _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"], _DEFER["params"]
-    _DEFER["wgrad"], _DEFER["colsum"], _DEFER["wgrad_b"], _DEFER["params"], _DEFER["armed"] = [], [], [], [], False
-    _launch_deferred(wq, cq, wbq)
+    st = st if st is not None else _DEFAULT_STATE
+    d = st.defer
+    wq, cq, wbq, params, prec = d["wgrad"], d["colsum"], d["wgrad_b"], d["params"], d["prec"]
+    st.reset_deferred()
+    _launch_deferred(wq, cq, wbq, prec)
     for p in params:
-        for cb in _GRAD_READY_CB:
+        for cb in st.ready_cb:
             cb(p)
 
 
@@ -162,6 +206,10 @@ def _require_gpu(t):
                            "(got a CPU tensor); there is no CPU fallback.")
     if t.dtype != torch.float32:
         raise RuntimeError(f"3dmedicalimagesegmentation_amd: fp32 storage expected, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's stream with raw pointers: a tensor of another GPU would fault
+        raise RuntimeError(f"3dmedicalimagesegmentation_amd: tensor lives on {t.device} but the current device is "
+                           f"cuda:{torch.cuda.current_device()}; call torch.cuda.set_device({t.device.index}) (one process per GPU)")
 
 
 def _rows(t):
@@ -248,11 +296,28 @@ def bf16_storage_enabled():
 
 
 def invalidate_weight_shadows():
+    """Declare every derived weight copy (bf16 shadows, packed conv weights) stale.  MANDATORY after writing a parameter
+    through ``.data`` in place (``p.data.copy_()``, ``p.data.mul_()``, an EMA swap, a hand-written broadcast) once the
+    copies are optimizer-maintained (this package's AdamW has stepped): such a write changes neither the version counter
+    nor the storage address, so nothing else can notice it.  Everything torch can see is handled automatically: in-place
+    ops on the parameter, torch optimizers, ``load_state_dict``, re-pointed ``.data``, and -- for copies no optimizer of
+    this package maintains -- any change at all between two forward passes (``begin_forward``)."""
     _WEIGHT_EPOCH[0] += 1
     for ent in _SHADOW.values():
         ent[1] = -1
     for ent in _PACKS.values():
         ent[1] = -1
+
+
+def begin_forward(state=None):
+    """Called by UNETR.forward.  (1) A derived weight copy that no optimizer of this package keeps in step is trusted for
+    ONE forward/backward pass only: a new pass starts a new weight epoch, so the first use re-derives it (a ``.data``
+    write between two passes is then always seen; optimizer-maintained copies stay valid, see
+    invalidate_weight_shadows).  (2) Deferred weight-gradient work a failed backward left behind is dropped."""
+    if not torch.cuda.is_current_stream_capturing():
+        _WEIGHT_EPOCH[0] += 1
+    if state is not None:
+        state.reset_deferred()
 
 
 def register_weight_shadow(w, shadow):
@@ -428,9 +493,10 @@ def layernorm_bwd_params(dy, x, w, b, mean, rstd, dres=None, dx_bf16=None):
     dx = torch.empty_like(x)
     call("unetr_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
          _p(dx_bf16), _p(dres), None, None, M, H, part.data_ptr(), part.numel() * 4, _stream())
-    _DEFER["colsum"].append((part, ow, nblk, H, 2 * H))
-    _DEFER["colsum"].append((part[H:], ob, nblk, H, 2 * H))
-    _arm_flush()
+    st = _GRAD_SINK[w.data_ptr()]
+    st.defer["colsum"].append((part, ow, nblk, H, 2 * H))
+    st.defer["colsum"].append((part[H:], ob, nblk, H, 2 * H))
+    _arm_flush(st)
     return dx, _ret(w, ow, deferred=True), _ret(b, ob, deferred=True)
 
 
@@ -651,60 +717,74 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, dw, db, dpos, None, None
 
 
+def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, train):
+    """kernels of one transformer block; returns (x2, tensors backward needs, bf16 twins or None)"""
+    hid = x.shape[1]
+    dh = hid // heads
+    M, mlp = x.shape[0], w1.shape[0]
+    if _bf16_path(prec, hid, mlp) and M % 8 == 0:     # (the bf16 weight-gradient kernel wants whole 8-token groups)
+        # bf16-stored operands: every GEMM input below is written as bf16 by its producer (fp32 copies stay for
+        # the weight-gradient GEMMs and the LayerNorm / attention backward kernels)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        y1b = bf16_like(x)
+        _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
+        y1 = y2 = a = x.new_empty(0)         # the fp32 twins are not materialised: every consumer reads bf16
+        qkv = torch.empty(M, 3 * hid, **f32)
+        gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=qkv)
+        attb = bf16_like(x)
+        att, lse = attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=attb)
+        x1 = torch.empty(M, hid, **f32)
+        gemm_bf16(attb, weight_bf16(wp), M, hid, hid, C=x1, bias=bp, res=x, ldr=hid)
+        y2b = bf16_like(x)
+        _, m2, r2 = layernorm_fwd(x1, n2w, n2b, bf16_out=y2b, want_fp32=False)
+        u = torch.empty(M, mlp, **f32) if train else None      # pre-activation, only GELU' in backward reads it
+        ab = torch.empty(M, mlp, dtype=torch.bfloat16, device=x.device)
+        gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, Cb=ab, bias=b1, act=1, pre=u)
+        if u is None:
+            u = x.new_empty(0)
+        x2 = torch.empty(M, hid, **f32)
+        gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
+        twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs
+    else:
+        twins = None
+        y1, m1, r1 = layernorm_fwd(x, n1w, n1b)
+        qkv = linear_fwd(y1, wqkv, None, prec)
+        att, lse = attention_fwd(qkv, B, L, heads, dh, prec)
+        x1 = linear_fwd(att, wp, bp, prec, res=x)
+        y2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
+        u = torch.empty(M, mlp, dtype=torch.float32, device=x.device)
+        a = linear_fwd(y2, w1, b1, prec, act=1, pre=u)
+        x2 = linear_fwd(a, w2, b2, prec, res=x1)
+    return x2, (y1, m1, r1, qkv, att, lse, x1, y2, m2, r2, u, a), twins
+
+
 class TransformerBlockFn(torch.autograd.Function):
-    """MONAI TransformerBlock: x + attn(norm1(x)); then + mlp(norm2(.)) -- 12 kernels forward."""
+    """MONAI TransformerBlock: x + attn(norm1(x)); then + mlp(norm2(.)).  ``ckpt`` = activation checkpointing
+    (BASELINE.json config[3]): only the block input is kept and backward recomputes the block's forward kernels first."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec):
+    def forward(ctx, x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, ckpt=False):
         _require_gpu(x)
         x = x.contiguous()
-        hid = x.shape[1]
-        dh = hid // heads
-        M, mlp = x.shape[0], w1.shape[0]
-        if _bf16_path(prec, hid, mlp) and M % 8 == 0:     # (the bf16 weight-gradient kernel wants whole 8-token groups)
-            # bf16-stored operands: every GEMM input below is written as bf16 by its producer (fp32 copies stay for
-            # the weight-gradient GEMMs and the LayerNorm / attention backward kernels)
-            f32 = dict(dtype=torch.float32, device=x.device)
-            train = any(ctx.needs_input_grad)
-            y1b = bf16_like(x)
-            _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
-            y1 = y2 = a = x.new_empty(0)         # the fp32 twins are not materialised: every consumer reads bf16
-            qkv = torch.empty(M, 3 * hid, **f32)
-            gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=qkv)
-            attb = bf16_like(x)
-            att, lse = attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=attb)
-            x1 = torch.empty(M, hid, **f32)
-            gemm_bf16(attb, weight_bf16(wp), M, hid, hid, C=x1, bias=bp, res=x, ldr=hid)
-            y2b = bf16_like(x)
-            _, m2, r2 = layernorm_fwd(x1, n2w, n2b, bf16_out=y2b, want_fp32=False)
-            u = torch.empty(M, mlp, **f32) if train else None      # pre-activation, only GELU' in backward reads it
-            ab = torch.empty(M, mlp, dtype=torch.bfloat16, device=x.device)
-            gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, Cb=ab, bias=b1, act=1, pre=u)
-            if u is None:
-                u = x.new_empty(0)
-            x2 = torch.empty(M, hid, **f32)
-            gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
-            ctx.twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs
-        else:
-            ctx.twins = None
-            y1, m1, r1 = layernorm_fwd(x, n1w, n1b)
-            qkv = linear_fwd(y1, wqkv, None, prec)
-            att, lse = attention_fwd(qkv, B, L, heads, dh, prec)
-            x1 = linear_fwd(att, wp, bp, prec, res=x)
-            y2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
-            u = torch.empty(M, mlp, dtype=torch.float32, device=x.device)
-            a = linear_fwd(y2, w1, b1, prec, act=1, pre=u)
-            x2 = linear_fwd(a, w2, b2, prec, res=x1)
-        ctx.save_for_backward(x, n1w, wqkv, wp, n2w, w1, w2, y1, m1, r1, qkv, att, lse, x1, y2, m2, r2, u, a,
-                              n1b, bp, n2b, b1, b2)
-        ctx.meta = (B, L, heads, dh, prec)
+        train = any(ctx.needs_input_grad)
+        x2, acts, twins = _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec,
+                                          train and not ckpt)
+        ctx.ckpt = bool(ckpt) and train
+        if ctx.ckpt:
+            acts, twins = (), None
+        ctx.twins = twins
+        ctx.save_for_backward(x, n1w, wqkv, wp, n2w, w1, w2, n1b, bp, n2b, b1, b2, *acts)
+        ctx.meta = (B, L, heads, x.shape[1] // heads, prec)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        (x, n1w, wqkv, wp, n2w, w1, w2, y1, m1, r1, qkv, att, lse, x1, y2, m2, r2, u, a,
-         n1b, bp, n2b, b1, b2) = ctx.saved_tensors
+        x, n1w, wqkv, wp, n2w, w1, w2, n1b, bp, n2b, b1, b2, *acts = ctx.saved_tensors
         B, L, heads, dh, prec = ctx.meta
+        twins = ctx.twins
+        if ctx.ckpt:
+            _, acts, twins = _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, True)
+        y1, m1, r1, qkv, att, lse, x1, y2, m2, r2, u, a = acts
         M, hid = x.shape
         dx2 = dx2.contiguous()
         mlp = w1.shape[0]
@@ -714,8 +794,8 @@ class TransformerBlockFn(torch.autograd.Function):
         y1b = attb = y2b = ab = dx2b = dub = None
         if fast:
             # data gradients dX = dY . W read W [out, in] as the [K_reduce, N_out] operand (b_kn) -- no transposed copy
-            if ctx.twins is not None:
-                y1b, attb, y2b, ab = ctx.twins
+            if twins is not None:
+                y1b, attb, y2b, ab = twins
             dx2b = _twin(dx2)
             du, dub = torch.empty(M, mlp, **f32), torch.empty(M, mlp, dtype=torch.bfloat16, device=x.device)
             gemm_bf16(dx2b, weight_bf16(w2), M, mlp, hid, b_kn=True, C=du, Cb=dub, act=2, aux=u, ldaux=mlp)
@@ -754,7 +834,7 @@ class TransformerBlockFn(torch.autograd.Function):
         dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         if fast:
             _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
-        return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None)
+        return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -77,10 +77,12 @@ class AdamW(torch.optim.Optimizer):
         Fn.refresh_conv_packs()          # one grouped launch: packed conv weights follow the update
         return loss
 
-    def _flat_runs(self, params, pattern, max_elems=None):
+    def _flat_runs(self, params, pattern, max_elems=None, cuts=()):
         """Contiguous arena ranges (i, j, lo, hi) of parameters that step together: consecutive parameters with a
-        gradient and equal step counts, optionally cut at parameter boundaries into pieces of <= max_elems."""
+        gradient and equal step counts, optionally cut at parameter boundaries into pieces of <= max_elems and at the
+        arena offsets listed in ``cuts`` (the boundaries of the data-parallel communication pieces)."""
         offs = self._flat["offsets"]
+        cuts = set(cuts)
         runs, i, n = [], 0, len(params)
         while i < n:
             if not pattern[i]:
@@ -88,7 +90,7 @@ class AdamW(torch.optim.Optimizer):
                 continue
             j = i
             while (j + 1 < n and pattern[j + 1] and self._host_steps[j + 1] == self._host_steps[i]
-                   and (max_elems is None or offs[j + 1] + params[j + 1].numel() - offs[i] <= max_elems)):
+                   and offs[j + 1] not in cuts and (max_elems is None or offs[j + 1] + params[j + 1].numel() - offs[i] <= max_elems)):
                 j += 1
             runs.append((i, j, offs[i], offs[j] + (params[j].numel() + 3) // 4 * 4))
             i = j + 1
@@ -122,17 +124,18 @@ class AdamW(torch.optim.Optimizer):
         return True
 
     # ---- data-parallel arena update: all-reduce pieces overlap the optimizer kernels of the pieces before them ----
-    def plan_reduced(self, max_elems):
-        """Freeze the current gradient pattern (which parameters have .grad) into arena ranges of <= max_elems.  The
-        plan is reused every step by ``step_reduced`` -- under hipGraph replay ``.grad`` attributes do not change."""
+    def plan_reduced(self, max_elems=None, cuts=()):
+        """Freeze the current gradient pattern (which parameters have .grad) into arena ranges of <= max_elems that never
+        straddle an offset in ``cuts``.  The plan is reused every step by ``step_reduced`` -- under hipGraph replay
+        ``.grad`` attributes do not change."""
         if self._flat is None or len(self.param_groups) != 1:
             raise RuntimeError("plan_reduced needs AdamW(..., flat=model.use_flat_buffers())")
         params = self.param_groups[0]["params"]
         pattern = tuple(p.grad is not None for p in params)
-        return dict(pattern=pattern, runs=self._flat_runs(params, pattern, max_elems))
+        return dict(pattern=pattern, runs=self._flat_runs(params, pattern, max_elems, cuts))
 
     @torch.no_grad()
-    def step_reduced(self, plan, gsrc, gscale, before_run=None):
+    def step_reduced(self, plan, gsrc, gscale, before_run=None, order=None):
         """AdamW over the planned ranges with gradients read from ``gsrc`` (a flat fp32 or bf16 tensor laid out like
         the arena: the all-reduced communication buffer) times ``gscale``.  ``before_run(k, lo, hi)`` runs before range
         k's kernel is launched -- the caller makes the current stream wait for that range's all-reduce there."""
@@ -146,7 +149,9 @@ class AdamW(torch.optim.Optimizer):
         g_bf16 = gsrc.dtype == torch.bfloat16
         if not g_bf16 and gsrc.dtype != torch.float32:
             raise RuntimeError("gradient source must be fp32 or bf16")
-        for k, run in enumerate(plan["runs"]):
+        runs = plan["runs"]
+        for k in (order if order is not None else range(len(runs))):      # order: the order the pieces finish reducing in
+            run = runs[k]
             if before_run is not None:
                 before_run(k, run[2], run[3])
             self._launch_run(group, run, steps, gsrc.data_ptr(), g_bf16, gscale, stream)

@@ -1,0 +1,195 @@
+"""The training step of the reference loop (unetr_segmentation_3d.py:220-226: forward -> DiceCE -> backward ->
+AdamW step -> zero_grad) as ONE object that owns how it is launched on an MI355X:
+
+* single GPU: the whole step -- forward, loss, backward, AdamW -- is captured into one hipGraph and replayed (no per-step
+  host work, no host sync: AdamW's step counters live on the device, the loss stays a device scalar).
+* data parallel (one process per GPU, RCCL over xGMI; new capability, the reference is single-GPU): backward runs in the
+  four passes of ``UNETR.forward_staged`` and the sum-all-reduce of each pass's gradient range (``UNETR.stage_ranges``)
+  is issued on a side HIP stream as soon as that pass has been launched, so it runs underneath the passes that follow
+  (conv-side gradients under ViT blocks 11..8, those under blocks 7..4, ...).  What is left when backward ends -- the
+  last range, cut into ``tail_pieces`` -- overlaps with the AdamW kernels of the ranges already reduced: the optimizer
+  kernel reads the summed gradients straight from the communication buffer and averages on the fly, so there is no copy
+  back and no scaling pass.  Pass 0 (with forward and loss) and passes 1-3 are separate hipGraphs sharing one memory pool;
+  the collectives are ordinary eager RCCL calls between graph launches, nothing depends on capturing a collective.
+  Gradients travel in fp32 by default (the same sum the single-GPU arithmetic would do), bf16 on request.
+
+``bench.py`` and ``tests/test_model_gpu.py`` both drive the step through this class, so what is measured is what is tested.
+"""
+import torch
+
+from . import functional as Fn
+
+
+def split_range(flat, lo, hi, pieces):
+    """cut arena range [lo, hi) at parameter boundaries into <= pieces parts of roughly equal size"""
+    offs = [o for o in flat["offsets"] if lo < o < hi]
+    cuts, target = [lo], (hi - lo) / float(pieces)
+    for o in offs:
+        if len(cuts) < pieces and o - lo >= target * len(cuts) and o > cuts[-1]:
+            cuts.append(o)
+    cuts.append(hi)
+    return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+class TrainStep:
+    def __init__(self, model, criterion, optimizer, x, y, *, use_graph=True, data_parallel=False, process_group=None,
+                 comm_dtype=torch.float32, tail_pieces=3, warmup=2):
+        flat = getattr(model, "_flat", None)
+        self.model, self.crit, self.opt, self.x, self.y = model, criterion, optimizer, x, y
+        self.flat = flat
+        self.dp = bool(data_parallel)
+        self.group = process_group
+        self.world = 1
+        self.dist = None
+        if self.dp:
+            if flat is None:
+                raise RuntimeError("the data-parallel step needs model.use_flat_buffers() and AdamW(flat=...)")
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.dist = dist
+                self.world = dist.get_world_size(process_group)
+        self.comm_dtype = comm_dtype
+        self.in_place = comm_dtype == torch.float32
+        self.loss = None
+        self.graphs = None
+        self.stages = None
+        self._plan = None
+        self.eager_steps = 0
+        self.first_loss = None
+        if self.dp:
+            self.comm_stream = torch.cuda.Stream()
+            self.comm_buf = None if self.in_place else torch.zeros(flat["total"], dtype=comm_dtype, device=flat["grad"].device)
+            ranges = model.stage_ranges()
+            self.pieces = [[r] for r in ranges[:-1]] + [split_range(flat, *ranges[-1], tail_pieces)]   # per backward pass
+            self.cuts = sorted({lo for st in self.pieces for lo, _ in st} | {hi for st in self.pieces for _, hi in st})
+            self._events = []
+        # eager warm-up: allocates workspaces, optimizer state, RCCL communicators -- all of which must exist before capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if use_graph:
+            self._capture()
+
+    # ------------------------------------------------------------------------------------------- single GPU
+    def _fwd_loss(self):
+        out = self.model(self.x)
+        logits = out[1] if isinstance(out, tuple) else out
+        return self.crit(logits, self.y)
+
+    def _single_step(self):
+        self.loss = self._fwd_loss()
+        self.loss.backward()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+
+    # ---------------------------------------------------------------------------------------- data parallel
+    def _pass0(self):
+        _, logits, self.stages = self.model.forward_staged(self.x)
+        self.loss = self.crit(logits, self.y)
+        self.loss.backward()
+
+    def _pass(self, k):
+        st = self.stages[k - 1]
+        roots = [r for r, leaf in st if leaf.grad is not None]
+        if roots:
+            torch.autograd.backward(roots, [leaf.grad for r, leaf in st if leaf.grad is not None])
+
+    def _reduce_after(self, k):
+        """pass k has been launched on the current stream: all-reduce its gradient pieces on the side stream"""
+        main = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(main)
+        g = self.flat["grad"]
+        with torch.cuda.stream(self.comm_stream):
+            for lo, hi in self.pieces[k]:
+                if self.in_place:
+                    buf = g[lo:hi]
+                else:
+                    buf = self.comm_buf[lo:hi]
+                    Fn.cast_bf16(g[lo:hi], out=buf)
+                if self.dist is not None:
+                    self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self.comm_stream)
+                self._events.append((lo, hi, ev))
+
+    def _update(self):
+        """AdamW over the planned runs, each as soon as the piece that holds it has been reduced"""
+        if self._plan is None:
+            self._plan = self.opt.plan_reduced(cuts=self.cuts)
+        runs = self._plan["runs"]
+        main = torch.cuda.current_stream()
+        order, waits = [], {}
+        for lo, hi, ev in self._events:                       # completion order of the pieces
+            ks = [k for k, r in enumerate(runs) if lo <= r[2] and r[3] <= hi]
+            if ks:
+                waits[ks[0]] = ev
+            order += ks
+        assert sorted(order) == list(range(len(runs))), "every AdamW run must lie inside exactly one communication piece"
+        src = self.flat["grad"] if self.in_place else self.comm_buf
+        self.opt.step_reduced(self._plan, src, 1.0 / self.world, order=order,
+                              before_run=lambda k, lo, hi: main.wait_event(waits[k]) if k in waits else None)
+        self._events = []
+
+    def _dp_step_eager(self):
+        self._pass0()
+        self._reduce_after(0)
+        for k in (1, 2, 3):
+            self._pass(k)
+            self._reduce_after(k)
+        self._plan = None                 # eager mode re-plans every step from fresh .grad attributes
+        self._update()
+        self._plan = None
+        self.opt.zero_grad(set_to_none=True)
+
+    def _eager_step(self):
+        self.eager_steps += 1
+        if self.dp:
+            self._dp_step_eager()
+        else:
+            self._single_step()
+        if self.eager_steps == 1:
+            self.first_loss = self.loss.detach().clone()      # loss at the initial weights (bench.py: vs the CPU oracle's)
+
+    # ------------------------------------------------------------------------------------------------ graphs
+    def _capture(self):
+        if not self.dp:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._single_step()
+            self.graphs = [g]
+            return
+        graphs = [torch.cuda.CUDAGraph()]
+        with torch.cuda.graph(graphs[0]):
+            self._pass0()
+        pool = graphs[0].pool()
+        for k in (1, 2, 3):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self._pass(k)
+            graphs.append(g)
+        self.graphs = graphs
+        self._plan = None                 # planned at the first run from the .grad attributes the captured passes set
+
+    def run(self):
+        """one training step; returns nothing (self.loss is the device scalar of this step)"""
+        if self.graphs is None:
+            self._eager_step()
+        elif not self.dp:
+            self.graphs[0].replay()
+        else:
+            for k, g in enumerate(self.graphs):
+                g.replay()
+                self._reduce_after(k)
+            self._update()
+
+    @property
+    def launch(self):
+        if self.graphs is None:
+            return "eager"
+        if not self.dp:
+            return "hipGraph(fwd+loss+bwd+AdamW)"
+        return "4 hipGraphs (fwd+loss+bwd pass 0 | ViT passes 1-3), per-pass all-reduce on a side stream, AdamW per reduced piece"

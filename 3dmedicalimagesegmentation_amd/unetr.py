@@ -216,6 +216,9 @@ class UNETR(nn.Module):
         self.out_channels = out_channels
         self.img_size = tuple(img_size)
         self.precision = default_precision()
+        # config[3] of BASELINE.json ("activation checkpointing on encoder"): when True the transformer blocks keep only
+        # their input for backward and recompute their forward there (functional.TransformerBlockFn)
+        self.encoder_checkpointing = False
 
         f = feature_size
         self.vit = _ViT(in_channels, img_size, self.patch_size, hidden_size, mlp_dim, self.num_layers)
@@ -255,14 +258,31 @@ class UNETR(nn.Module):
                 p.data = v
                 p.grad = None
                 views.append((p, flat_g[o:o + p.numel()].view_as(p)))
-        Fn.register_grad_sinks(views)
+        old = getattr(self, "_arena_state", None)
+        if old is not None:
+            old.clear()
+        self._arena_state = Fn.register_grad_sinks(views, Fn.ArenaState())
         # bf16 shadow of the whole arena: the bf16-storage GEMMs read weights from it, AdamW(flat=...) rewrites it in
         # the optimizer kernel (functional.weight_bf16 re-casts a slice if torch modifies the parameter itself)
         shadow = Fn.cast_bf16(flat_p)
         for p, o in zip(params, offs):
             Fn.register_weight_shadow(p, shadow[o:o + p.numel()].view_as(p))
-        self._flat = dict(param=flat_p, grad=flat_g, offsets=offs, params=params, total=n, shadow=shadow)
+        self._flat = dict(param=flat_p, grad=flat_g, offsets=offs, params=params, total=n, shadow=shadow,
+                          state=self._arena_state)
         return self._flat
+
+    def stage_ranges(self):
+        """Arena ranges [lo, hi) of the gradients each backward stage of ``forward_staged`` completes, in completion
+        order: the conv side (encoder1-4, decoder5-2, out), ViT blocks 8-11 + vit.norm, blocks 4-7, patch embedding +
+        blocks 0-3.  These are the data-parallel buckets (reverse execution order)."""
+        flat = getattr(self, "_flat", None)
+        if flat is None:
+            raise RuntimeError("stage_ranges() needs use_flat_buffers()")
+        index = {id(p): i for i, p in enumerate(flat["params"])}
+        offs = flat["offsets"]
+        first = lambda m: offs[index[id(next(m.parameters()))]]
+        b4, b8, conv = first(self.vit.blocks[4]), first(self.vit.blocks[8]), first(self.encoder1)
+        return [(conv, flat["total"]), (b8, conv), (b4, b8), (0, b4)]
 
     def _prec(self) -> int:
         try:
@@ -284,7 +304,10 @@ class UNETR(nn.Module):
     def _res_w(self, blk):
         return blk.conv1.conv.weight, blk.conv2.conv.weight, blk.conv3.conv.weight
 
-    def _encode(self, x_in, prec):
+    def _encode(self, x_in, prec, stages=None):
+        """ViT + the four skip-path encoders.  ``stages`` (a list, staged mode): the ViT is cut into three groups of four
+        blocks and the conv side is fed detached copies of the ViT outputs it consumes, so that backward can run as four
+        consecutive passes (forward_staged); each list entry receives the (root, leaf) pairs that pass k starts from."""
         B = x_in.shape[0]
         if tuple(x_in.shape[1:]) != (self.in_channels, *self.img_size):
             raise ValueError(f"expected input [B,{self.in_channels},{self.img_size}], got {tuple(x_in.shape)}")
@@ -292,16 +315,35 @@ class UNETR(nn.Module):
         lin = pe.patch_embeddings[1]
         L = pe.position_embeddings.shape[1]
         Fn._require_gpu(x_in)
+
+        def cut(t, k):
+            if stages is None:
+                return t
+            leaf = t.detach().requires_grad_(True)
+            stages[k].append((t, leaf))
+            return leaf
+
+        ckpt = self.encoder_checkpointing and torch.is_grad_enabled()
         x = Fn.PatchEmbedFn.apply(x_in, lin.weight, lin.bias, pe.position_embeddings, self.patch_size[0], prec)
         hidden_states_out = []
-        for blk in self.vit.blocks:
+        for i, blk in enumerate(self.vit.blocks):
             x = Fn.TransformerBlockFn.apply(
                 x, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
                 blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
-                blk.mlp.linear2.bias, B, L, self.num_heads, prec)
-            hidden_states_out.append(x)
+                blk.mlp.linear2.bias, B, L, self.num_heads, prec, ckpt)
+            if i == 3:
+                x = cut(x, 2)              # one leaf for both consumers of hidden state 3 (block 4 and encoder2)
+                hidden_states_out.append(x)
+            elif i == 7:
+                hidden_states_out.append(x)
+                x = cut(x, 1)
+            elif i in (6, 9):
+                hidden_states_out.append(cut(x, 1 if i == 6 else 0))
+            else:
+                hidden_states_out.append(x)
         x = Fn.LayerNormFn.apply(x, self.vit.norm.weight, self.vit.norm.bias,
                                  Fn._bf16_path(prec, self.hidden_size, self.vit.blocks[0].mlp.linear1.weight.shape[0]))
+        x = cut(x, 0)
         enc1 = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec)
         enc = []
         for tap, blk in ((3, self.encoder2), (6, self.encoder3), (9, self.encoder4)):
@@ -311,14 +353,7 @@ class UNETR(nn.Module):
             enc.append(t)
         return x, enc1, enc[0], enc[1], enc[2]
 
-    def forward(self, x_in, freeze_encoder=False):
-        """unetr.py:182-208: returns (enc4 [B,8F,2g,2g,2g], logits [B,C_out,*img_size]), both NCDHW."""
-        prec = self._prec()
-        if freeze_encoder:
-            with torch.no_grad():
-                x, enc1, enc2, enc3, enc4 = self._encode(x_in, prec)
-        else:
-            x, enc1, enc2, enc3, enc4 = self._encode(x_in, prec)
+    def _decode(self, x_in, x, enc1, enc2, enc3, enc4, prec):
         B = x_in.shape[0]
         dec4 = self._tokens_cl(x, B)
         d = self.decoder5
@@ -331,6 +366,48 @@ class UNETR(nn.Module):
         out = Fn.UpBlockFn.apply(dec1, enc1, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec)
         logits = Fn.OutConvFn.apply(out, self.out.conv.conv.weight, self.out.conv.conv.bias)
         return Fn.ToNCDHWFn.apply(enc4), logits
+
+    def forward(self, x_in, freeze_encoder=False):
+        """unetr.py:182-208: returns (enc4 [B,8F,2g,2g,2g], logits [B,C_out,*img_size]), both NCDHW."""
+        prec = self._prec()
+        Fn._require_gpu(x_in)
+        Fn.begin_forward(getattr(self, "_arena_state", None))
+        if freeze_encoder:
+            with torch.no_grad():
+                x, enc1, enc2, enc3, enc4 = self._encode(x_in, prec)
+        else:
+            x, enc1, enc2, enc3, enc4 = self._encode(x_in, prec)
+        return self._decode(x_in, x, enc1, enc2, enc3, enc4, prec)
+
+    # ---- staged backward: what lets the data-parallel all-reduce overlap with backward ---------------------------
+    def forward_staged(self, x_in):
+        """Same arithmetic as ``forward(x_in)`` (the values are bit-identical), but the autograd graph is cut so that
+        backward runs as FOUR consecutive passes whose parameter gradients are complete when each pass ends:
+        0: loss -> conv side (encoder1-4, decoder5-2, out), 1: vit.norm + blocks 11..8, 2: blocks 7..4,
+        3: blocks 3..0 + patch embedding.  ``backward_staged`` drives them; between two passes the caller may start the
+        all-reduce of the arena range that just became final (``stage_ranges``) on a side stream.
+        Returns (enc4, logits, stages)."""
+        prec = self._prec()
+        Fn._require_gpu(x_in)
+        Fn.begin_forward(getattr(self, "_arena_state", None))
+        stages = [[], [], []]
+        x, enc1, enc2, enc3, enc4 = self._encode(x_in, prec, stages)
+        enc4_out, logits = self._decode(x_in, x, enc1, enc2, enc3, enc4, prec)
+        return enc4_out, logits, stages
+
+    @staticmethod
+    def backward_staged(loss, stages, after_stage=None):
+        """``loss.backward()`` in four passes (see forward_staged); ``after_stage(k)`` runs after pass k, k = 0..3."""
+        loss.backward()
+        if after_stage is not None:
+            after_stage(0)
+        for k, st in enumerate(stages, 1):
+            roots = [r for r, leaf in st if leaf.grad is not None]
+            grads = [leaf.grad for r, leaf in st if leaf.grad is not None]
+            if roots:
+                torch.autograd.backward(roots, grads)
+            if after_stage is not None:
+                after_stage(k)
 
 
 class UNETRLogits(UNETR):

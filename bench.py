@@ -2,21 +2,33 @@
 
 A "step" = forward + DiceCE loss + backward + AdamW on one batch of synthetic 96^3 CT-like volumes
 (config[1]: UNETR(img 96, patch 16, hidden 768, 12 layers, 12 heads, 4 classes), batch 2 per GPU), with
-inputs resident in HBM.  N GPUs = N ranks (one per GPU, RCCL), weak scaling: each rank keeps batch 2 and
-gradients are all-reduced (bucketed, side stream).  Prints ONE JSON line on rank 0.
+inputs resident in HBM.  N GPUs = N ranks (one process per GPU, RCCL), weak scaling: each rank keeps batch 2 and
+gradients are all-reduced per backward pass on a side stream, underneath the rest of backward (train_step.py).
 
-Extra objects: "roofline" for the dominant kernel (timed live with HIP events on the launch stream) and
-"cpu_baseline" (the CPU oracle = the reference's operator graph in plain PyTorch, timed on the host cores
-on a bounded sample; rank 0, N=1 only).
+    python bench.py --gpus N --steps K --warmup W
+
+* started WITHOUT a rendezvous environment (no RANK) and N > 1: this process touches no GPU; it starts
+  ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`` as a
+  child, rank 0 of which prints the JSON line, and exits with the child's code.
+* started BY torchrun (RANK / LOCAL_RANK / WORLD_SIZE set): one rank of the job.
+
+Prints ONE JSON line on rank 0.  Extra objects: "roofline" for the dominant kernel of the step (tools/roofline.py),
+"families" (ms/step per kernel family), "encoder_fwd*" (ViT encoder forward alone vs the bf16 MFMA peak) and
+"cpu_baseline" (the CPU oracle = the reference's operator graph in plain PyTorch, timed on the host cores on a bounded
+sample; rank 0, N=1 only -- the only place bench.py touches oracle/).
+
+--config c2 (default) | c4 (160^3, encoder activation checkpointing, batch 1) | c5 (ranking pre-training step at 96^3:
+[4,1,96^3] batch, 'feat' then 'recon' stage of unetr_ranking_pretraining_3d.py:238-296, all three slice axes).
+--stub: a tiny CPU step over gloo that exercises launcher + bucket schedule + JSON contract without a GPU (tests).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,216 +39,136 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=2, help="volumes per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="volumes per GPU (default 2; c4: 1; c5: 4)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
-    ap.add_argument("--no-flat", action="store_true", help="per-tensor grads/AdamW instead of the flat arenas")
-    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (two graphs + eager all-reduce slot) on one rank")
-    ap.add_argument("--fp32-comm", action="store_true", help="all-reduce gradients in fp32 even in bf16 mode")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
+    ap.add_argument("--no-flat", action="store_true", help="per-tensor grads/AdamW instead of the flat arenas (N=1 only)")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (staged backward + per-pass all-reduce slots) on one rank")
+    ap.add_argument("--bf16-comm", action="store_true", help="all-reduce gradients in bf16 (default: fp32, the single-GPU arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--stub", action="store_true", help="CPU/gloo stub step (launcher + schedule test, no GPU)")
+    return ap.parse_args(argv)
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a rendezvous environment: start N ranks as a CHILD torchrun job.  Nothing in this process has
+    touched (or will touch) the GPU, and it never replaces itself with another program."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"launcher: starting {args.gpus} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------ stub rank
+def stub_rank(args, rank, world, real_stdout):
+    """The schedule of the data-parallel step on CPU tensors over gloo: 'backward' fills the gradient arena range by range
+    (in the order of UNETR.stage_ranges), each range is all-reduced asynchronously as soon as it is full, the update
+    consumes the ranges in completion order.  Checks: every rank ends with identical parameters."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1 << 16
+    bounds = [0, n // 8, n // 2, 3 * n // 4, n]
+    ranges = [(bounds[i], bounds[i + 1]) for i in (3, 2, 1, 0)]
+    torch.manual_seed(0)
+    param = torch.randn(n)
+    grad = torch.zeros(n)
+    t0 = None
+    for it in range(args.warmup + args.steps):
+        if it == args.warmup:
+            dist.barrier()
+            t0 = time.perf_counter()
+        works = []
+        for lo, hi in ranges:
+            grad[lo:hi] = torch.sin(param[lo:hi]) * (rank + 1)           # this rank's "backward pass" over the range
+            works.append((lo, hi, dist.all_reduce(grad[lo:hi], async_op=True)))
+        for lo, hi, w in works:
+            w.wait()
+            param[lo:hi] -= 1e-2 * grad[lo:hi] / world
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    cs = torch.tensor([param.double().sum().item()], dtype=torch.float64)
+    lo_, hi_ = cs.clone(), cs.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    out = {"metric": "stub steps/sec (CPU, gloo)", "value": round(world * args.steps / t.item(), 3), "unit": "steps/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t.item() / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "stub: 4 gradient ranges, async all-reduce per range, update in completion order"},
+           "rccl_world": dist.get_world_size(), "backend": "gloo", "ranks_agree": bool(lo_.item() == hi_.item())}
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ one rank
 def main():
     args = parse()
+    rendezvous = "RANK" in os.environ
+    if args.gpus > 1 and not rendezvous:
+        sys.exit(launch_ranks(args))
+
     # RCCL / HIP print banners on stdout; the contract is ONE JSON line there, so keep the real stdout aside
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist_on = world > 1 or (args.force_dist and "RANK" in os.environ)   # --force-dist under torchrun: 1-rank RCCL group
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.stub:
+        sys.exit(stub_rank(args, rank, world, real_stdout))
+
+    import torch
+    dist_on = world > 1 or (args.force_dist and rendezvous)   # --force-dist under torchrun: a real 1-rank RCCL group
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if dist_on:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
-    from oracle.unetr_oracle import synthetic_volume  # data generator only (shared with the tests)
+    from tools.synthetic import synthetic_volume
 
-    torch.manual_seed(1234)  # same initial weights on every rank
-    model = pkg.UNETRLogits(**CFG).to(dev)
-    model.precision = args.precision
-    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
-    flat = None if args.no_flat else model.use_flat_buffers()
-    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
-    x, y = synthetic_volume(args.batch, 1, 96, 4, seed=1234 + rank)
-    x, y = x.to(dev), y.to(dev)
-
-    # ---- data parallel (N > 1): weak scaling, batch `--batch` per rank, gradients averaged over ranks ----------
-    # Arena mode: hipGraph = forward + loss + backward (+ one cast of the gradient arena into the bf16 communication
-    # buffer); then the buffer is all-reduced in <= 6 pieces on a side stream (eager RCCL calls) while AdamW runs on each
-    # piece as soon as it is reduced, reading the summed gradients straight from the buffer.  No collective is captured
-    # inside a hipGraph, so the path does not depend on RCCL's capture support.
-    # --force-dist exercises exactly this path with a single rank (what the 1-GPU box can test).
     ddp_on = dist_on or args.force_dist
-    comm_dtype = torch.bfloat16 if (args.precision == "bf16" and not args.fp32_comm) else torch.float32
-    reducer = None
-    comm_buf = None
-    if ddp_on and flat is None:
-        if not dist_on:
-            raise SystemExit("--force-dist needs the arena mode (drop --no-flat)")
-        reducer = pkg.ddp.GradAllReducer(model.parameters(), process_group=None)
-    if ddp_on and flat is not None:
-        comm_buf = torch.zeros(flat["total"], dtype=comm_dtype, device=dev)
-        if dist_on:
-            for p in model.parameters():
-                dist.broadcast(p.data, src=0)
-            pkg.functional.invalidate_weight_shadows()
-
-    comm_stream = torch.cuda.Stream() if ddp_on else None
-    plan = {"p": None}
-    in_place = comm_buf is not None and comm_dtype == torch.float32     # fp32 comm: all-reduce the gradient arena itself
-
-    def fwd_bwd():
-        logit_map = model(x)
-        loss = crit(logit_map, y)
-        loss.backward()
-        if comm_buf is not None and not in_place:
-            comm_buf.copy_(flat["grad"])        # fp32 -> bf16 communication buffer
-        return loss
-
-    def comm_update():
-        """Arena data-parallel step: the gradient buffer is all-reduced in <= 6 pieces on a side stream while the main
-        stream runs AdamW on each piece as soon as its all-reduce has finished (the optimizer kernel reads the summed
-        gradients from the communication buffer and averages on the fly: no copy back, no separate scaling pass)."""
-        buf = flat["grad"] if in_place else comm_buf
-        if plan["p"] is None:
-            plan["p"] = opt.plan_reduced(max_elems=(flat["total"] + 5) // 6)
-        runs = plan["p"]["runs"]
-        main = torch.cuda.current_stream()
-        comm_stream.wait_stream(main)
-        events = []
-        with torch.cuda.stream(comm_stream):
-            for (_, _, lo, hi) in runs:
-                if dist_on:
-                    dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM)
-                ev = torch.cuda.Event()
-                ev.record(comm_stream)
-                events.append(ev)
-        opt.step_reduced(plan["p"], buf, 1.0 / world, before_run=lambda k, lo, hi: main.wait_event(events[k]))
-
-    def comm():
-        if reducer is not None:
-            reducer.finish()
-
-    def update():
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-
-    def step():
-        loss = fwd_bwd()
-        if comm_buf is not None:
-            comm_update()
-            if graph is None:                     # eager mode re-plans every step from fresh .grad attributes
-                plan["p"] = None
-                opt.zero_grad(set_to_none=True)
-        else:
-            comm()
-            update()
-        return loss
-
-    graph = None
-    use_graph = not args.no_graph and reducer is None
-    # eager warm-up (allocates workspaces / optimizer state / RCCL communicators; needed before graph capture)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            loss = step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    log(f"eager warm-up done, loss {float(loss.item()):.5f}")
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            if comm_buf is None:
-                with torch.cuda.graph(graph):
-                    loss = step()
-            else:
-                with torch.cuda.graph(graph):
-                    loss = fwd_bwd()
-                plan["p"] = None                  # planned from the .grad attributes the captured backward just set
-        except Exception as e:  # noqa: BLE001
-            if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    def run_step():
-        if graph is None:
-            step()
-        elif comm_buf is None:
-            graph.replay()
-        else:
-            graph.replay()
-            comm_update()
-
-    log("graph captured" if graph is not None else "eager mode")
-    for _ in range(args.warmup):
-        run_step()
-
-    def sync_all():
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    sync_all()
-    dt = time.perf_counter() - t0
+    if args.config == "c5":
+        out = run_c5(args, pkg, dev, rank, world)
+    else:
+        out = run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume)
+    out["rccl_world"] = dist.get_world_size() if dist_on else 1
+    names = [torch.cuda.get_device_name(dev)]
     if dist_on:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
-    ms_per_step = dt / args.steps * 1e3
-    value = world * args.batch * args.steps / dt
-
-    out = {
-        "metric": "training volumes/sec (96^3, 4-class)", "value": round(value, 3), "unit": "volumes/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "UNETR(img=96^3,patch=16,hidden=768,layers=12,heads=12,classes=4) fwd+DiceCE+bwd+AdamW, "
-                               f"batch {args.batch}/GPU, configs[1]", "global_batch": world * args.batch,
-                   "launch": ("hipGraph" if comm_buf is None else "hipGraph(fwd+bwd) + chunked all-reduce overlapped with AdamW") if graph is not None else "eager",
-                   "grad_comm_dtype": (str(comm_dtype).replace("torch.", "") if ddp_on else None), "final_loss": float(loss.item())},
-    }
-
-    if rank == 0 and not args.no_roofline:
-        try:
-            from tools.roofline import dominant_kernel_roofline
-            out["roofline"] = dominant_kernel_roofline(pkg, model, crit, x, y, args.precision)
-        except Exception as e:  # noqa: BLE001
-            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
-        try:
-            from tools.roofline import encoder_forward_rate
-            out["encoder_fwd"] = encoder_forward_rate(pkg, model, x, args.precision)
-            # the same encoder kernels at a token count where the GEMMs are throughput- rather than latency-bound
-            xb = x[:1].expand(32, -1, -1, -1, -1).contiguous()
-            out["encoder_fwd_batch32"] = encoder_forward_rate(pkg, model, xb, args.precision, iters=5)
-            del xb
-        except Exception as e:  # noqa: BLE001
-            out["encoder_fwd"] = {"error": f"{type(e).__name__}: {e}"}
-    log("roofline done")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
-        log("cpu baseline done")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, f"rank {rank}: cuda:{local_rank} {names[0]}")
+        names = gathered
+    out["devices"] = names
 
     if dist_on:
         dist.barrier()
@@ -245,8 +177,142 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
-def cpu_baseline(args):
-    """The CPU oracle (plain PyTorch fp32, the reference's operator graph) on this host's cores."""
+def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
+    import torch
+    cfg = dict(CFG)
+    batch = args.batch if args.batch is not None else (1 if args.config == "c4" else 2)
+    if args.config == "c4":
+        cfg["img_size"] = (160, 160, 160)
+    size = cfg["img_size"][0]
+    torch.manual_seed(1234)  # same initial weights on every rank
+    model = pkg.UNETRLogits(**cfg).to(dev)
+    model.precision = args.precision
+    model.encoder_checkpointing = args.config == "c4"
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    if args.no_flat and ddp_on:
+        raise SystemExit("the data-parallel step needs the flat arenas (drop --no-flat)")
+    flat = None if args.no_flat else model.use_flat_buffers()
+    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
+    x, y = synthetic_volume(batch, 1, size, 4, seed=1234 + rank)
+    x, y = x.to(dev), y.to(dev)
+    if dist is not None:
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+        pkg.functional.invalidate_weight_shadows()      # p.data was rewritten behind the version counters
+        if flat is not None:
+            flat["shadow"].copy_(flat["param"])         # (and the arena's bf16 shadow follows)
+
+    comm_dtype = torch.bfloat16 if (args.bf16_comm and args.precision == "bf16") else torch.float32
+    graph_err = None
+    try:
+        step = pkg.TrainStep(model, crit, opt, x, y, use_graph=not args.no_graph, data_parallel=ddp_on, comm_dtype=comm_dtype)
+    except Exception as e:  # noqa: BLE001
+        if args.no_graph:
+            raise
+        graph_err = f"{type(e).__name__}: {e}"
+        log(f"graph capture failed ({graph_err}); falling back to eager launches")
+        torch.cuda.synchronize()
+        if flat is not None:
+            flat["state"].reset_deferred()              # a failed capture may have left deferred weight-gradient work queued
+        opt.zero_grad(set_to_none=True)
+        step = pkg.TrainStep(model, crit, opt, x, y, use_graph=False, data_parallel=ddp_on, comm_dtype=comm_dtype)
+    first_loss = float(step.first_loss.item())
+    log(f"{step.launch}; first-step loss {first_loss:.5f}")
+    for _ in range(args.warmup):
+        step.run()
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    log(f"timed region done: {ms_per_step:.3f} ms/step")
+    value = world * batch * args.steps / dt
+    tag = {"c2": "configs[1]", "c4": "configs[3]: 160^3, encoder activation checkpointing"}[args.config]
+    out = {
+        "metric": f"training volumes/sec ({size}^3, 4-class)", "value": round(value, 3), "unit": "volumes/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"UNETR(img={size}^3,patch=16,hidden=768,layers=12,heads=12,classes=4) fwd+DiceCE+bwd+AdamW, "
+                               f"batch {batch}/GPU, {tag}", "global_batch": world * batch, "launch": step.launch,
+                   "grad_comm_dtype": (str(comm_dtype).replace("torch.", "") if ddp_on else None),
+                   "first_step_loss": first_loss, "final_loss": float(step.loss.item()), "graph_capture_error": graph_err},
+    }
+    if rank == 0 and not args.no_roofline and args.config == "c2":
+        try:
+            from tools import roofline as rl
+            out.update(rl.step_report(pkg, model, crit, x, y, args.precision, ms_per_step))
+        except Exception as e:  # noqa: BLE001
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        log("roofline done")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, cfg, batch, first_loss)
+        log("cpu baseline done")
+    return out
+
+
+def run_c5(args, pkg, dev, rank, world):
+    """BASELINE config[4]: one pre-training step of unetr_ranking_pretraining_3d.py:238-296 at 96^3 = for each of the
+    three slice axes (:241) a 'feat' update (loss on enc4, :259-260) and a 'recon' update (loss on the logits with the
+    encoder frozen, :261-262) on a [4, 1, 96^3] batch (2 volumes x 2 transforms) -- six forward/backward/AdamW passes."""
+    import torch
+    from tools.synthetic import synthetic_volume
+    torch.manual_seed(1234)
+    cfg = dict(CFG, out_channels=2)                     # Task09 spleen: n_classes = 2 (:303)
+    model = pkg.UNETR(**cfg).to(dev)
+    model.precision = args.precision
+    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    x, _ = synthetic_volume(4, 1, 96, 2, seed=1234 + rank)
+    x = x.to(dev)
+
+    def step():
+        last = None
+        for axis in (2, 3, 4):
+            for stage in ("feat", "recon"):
+                if stage == "feat":
+                    inp, _ = model(x)
+                    init_idx = 1                           # enc4 is 12^3: partition size 3
+                else:
+                    _, inp = model(x, freeze_encoder=True)
+                    init_idx = 7                           # logits are 96^3: partition size 24
+                loss = pkg.ranking_loss(inp, axis, init_idx, 0.1, kind="ranking")
+                loss.backward()
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                last = loss
+        return last
+
+    for _ in range(max(1, args.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "ranking pre-training volumes/sec (96^3)", "value": round(world * 4 * 6 * args.steps / dt, 3), "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "configs[4]: ranking pre-training, [4,1,96^3] batch, 3 slice axes x (feat + recon) = 6 "
+                                   "fwd/BT-loss/bwd/AdamW passes per step, eager launches", "final_loss": float(loss.item())}}
+
+
+def cpu_baseline(args, cfg, batch, gpu_first_loss):
+    """The CPU oracle (plain PyTorch fp32, the reference's operator graph) on this host's cores: 1 warm-up + --cpu-steps
+    timed steps at the bench batch.  Its first-step loss (same seed-1234 weights and data as the GPU run) is reported next
+    to the GPU's: a whole-model parity figure that costs nothing inside the timed region."""
+    import torch
     from oracle.unetr_oracle import OracleUNETR, oracle_train_step, synthetic_volume
     # the GPU box gives one GPU a 16-CPU share; os.cpu_count() reports the whole host and oversubscribes badly
     try:
@@ -256,17 +322,23 @@ def cpu_baseline(args):
     cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    ref = OracleUNETR(**CFG)
+    ref = OracleUNETR(**cfg)
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-5)
-    x, y = synthetic_volume(1, 1, 96, 4, seed=1234)
-    oracle_train_step(ref, opt, x, y)  # warm-up
+    size = cfg["img_size"][0]
+    if size > 96:
+        batch, steps = 1, 1
+    else:
+        steps = args.cpu_steps
+    x, y = synthetic_volume(batch, 1, size, 4, seed=1234)
+    l0 = float(oracle_train_step(ref, opt, x, y))  # warm-up; also the first-step loss
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    for _ in range(steps):
         oracle_train_step(ref, opt, x, y)
     dt = time.perf_counter() - t0
-    return {"value": round(args.cpu_steps / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_steps} fwd+DiceCE+bwd+AdamW steps of the same 96^3 UNETR at batch 1 (1 warm-up), torch fp32, "
-                      f"{cores} threads"}
+    return {"value": round(batch * steps / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} fwd+DiceCE+bwd+AdamW steps of the same {size}^3 UNETR at batch {batch} (1 warm-up), torch fp32, "
+                      f"{cores} threads",
+            "first_step_loss": l0, "first_step_loss_rel_diff_vs_gpu": abs(l0 - gpu_first_loss) / abs(l0)}
 
 
 if __name__ == "__main__":

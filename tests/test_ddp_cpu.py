@@ -107,7 +107,7 @@ def _flat_worker(rank, world, port, q):
         v0 = Fn._gout(params[0])
         assert Fn._ret(params[0], v0, deferred=True) is None
         v0.fill_(float(rank + 1))              # the deferred kernel "runs" here
-        Fn._DEFER["armed"] = True
+        Fn._DEFAULT_STATE.defer["armed"] = True
         Fn.flush_deferred()
         red.finish()
         for i in (4, 2, 1, 0):
@@ -198,3 +198,58 @@ def test_reduced_plan_gloo_world2():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_bench_launcher_starts_n_ranks_gloo_stub():
+    """`python bench.py --gpus 2` without a rendezvous environment must start 2 ranks itself (a child torchrun job) and
+    print ONE JSON line from rank 0 -- exercised here on the CPU stub step over gloo (the schedule of the data-parallel
+    step: ranges all-reduced as they fill, update in completion order)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["ranks_agree"] is True and out["scaling"] == "weak" and out["value"] > 0
+    for k in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert k in out
+
+
+def test_stage_ranges_and_piece_plan():
+    """UNETR.stage_ranges tile the arena in backward-completion order and TrainStep's piece plan cuts AdamW runs at piece
+    boundaries (host logic only: arenas are faked on CPU tensors)."""
+    import importlib
+    pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
+    ts = pkg.train_step
+    cfg = dict(in_channels=1, out_channels=2, img_size=(32, 32, 32), feature_size=16, hidden_size=128, mlp_dim=512,
+               num_heads=4, pos_embed="perceptron", norm_name="instance", res_block=True)
+    m = pkg.UNETR(**cfg)
+    params = list(m.parameters())
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 7) // 8 * 8
+    m._flat = dict(param=torch.zeros(n), grad=torch.zeros(n), offsets=offs, params=params, total=n, shadow=None)
+    r = m.stage_ranges()
+    assert r[0][1] == n and r[3][0] == 0 and [a[0] for a in r[:3]] == [b[1] for b in r[1:]]      # contiguous, reverse order
+    names = [k for k, _ in m.named_parameters()]
+    first_conv = offs[names.index("encoder1.layer.conv1.conv.weight")]
+    assert r[0][0] == first_conv and r[1][0] == offs[names.index("vit.blocks.8.mlp.linear1.weight")]
+    assert r[2][0] == offs[names.index("vit.blocks.4.mlp.linear1.weight")]
+    tail = ts.split_range(m._flat, *r[3], 3)
+    assert tail[0][0] == 0 and tail[-1][1] == r[3][1] and all(a[1] == b[0] for a, b in zip(tail, tail[1:])) and len(tail) == 3
+    assert all(lo in offs for lo, _ in tail)
+    opt = pkg.AdamW(params, lr=1e-3, flat=m._flat)
+    for i, p in enumerate(params):
+        if names[i] != "vit.patch_embedding.cls_token":
+            p.grad = m._flat["grad"][offs[i]:offs[i] + p.numel()].view_as(p)
+    cuts = sorted({lo for lo, _ in r} | {lo for lo, _ in tail})
+    plan = opt.plan_reduced(cuts=cuts)
+    for (_, _, lo, hi) in plan["runs"]:
+        assert not any(lo < c < hi for c in cuts)                     # no run straddles a piece boundary
+    covered = sum(hi - lo for _, _, lo, hi in plan["runs"])
+    assert covered >= sum(p.numel() for p in params) - 128

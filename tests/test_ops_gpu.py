@@ -469,3 +469,30 @@ def test_ranking_losses_vs_reference_fixture(pkg, dev):
         assert relerr(fd.grad, grad) < 2e-4, key
         n += 1
     assert n == 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(37, 50, 44), (432, 768, 770), (70, 33, 4100), (16, 16, 70001)])
+def test_gemm_padding_lanes_ignore_inf_nan(pkg, dev, prec, M, N, K):
+    """Ragged M / N / K: the loaders fetch out-of-range lanes from a clamped address (element (0,0), row 0 or column 0 of
+    the operand) and must mask the BITS -- an Inf / NaN sitting there may only affect the outputs that really use it."""
+    Fn = pkg.functional
+    x, w, dy = g(M, K, seed=1), g(N, K, seed=2), g(M, N, seed=3)
+    x[0, 0], w[0, 0], dy[0, 0] = float("inf"), float("nan"), float("-inf")
+    xd, wd, dyd = x.to(dev), w.to(dev), dy.to(dev)
+    y = Fn.linear_fwd(xd, wd, None, prec).cpu()
+    ref = x @ w.t()
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(y), fin)                       # row 0 and column 0 are poisoned, nothing else
+    assert fin[1:, 1:].all() and relerr(y[1:, 1:], ref[1:, 1:]) < TOL[prec]
+    dx = Fn.linear_dgrad(dyd, wd, prec).cpu()                         # dx = dy @ w: row 0 (dy) and column 0 (w[0,0] hits k=0 only)
+    rdx = dy @ w
+    assert torch.equal(torch.isfinite(dx), torch.isfinite(rdx))
+    ok = torch.isfinite(rdx)
+    assert relerr(dx[ok], rdx[ok]) < TOL[prec]
+    dw = Fn.linear_wgrad(dyd, xd, prec).cpu()                         # dw = dy^T x
+    rdw = dy.t() @ x
+    assert torch.equal(torch.isfinite(dw), torch.isfinite(rdw))
+    ok = torch.isfinite(rdw)
+    assert relerr(dw[ok], rdw[ok]) < TOL[prec]

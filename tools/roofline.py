@@ -152,3 +152,14 @@ def encoder_forward_rate(pkg, model, x_in, precision, iters=10):
             "algorithmic_flops": flops,
             "note": (f"batch {B} = {B * L} token rows per GEMM: launch/latency-bound, not MFMA-bound" if B * L < 2048 else
                      f"batch {B} = {B * L} token rows per GEMM")}
+
+
+def step_report(pkg, model, crit, x, y, precision, ms_per_step):
+    """objects bench.py merges into its JSON line"""
+    out = {"roofline": dominant_kernel_roofline(pkg, model, crit, x, y, precision)}
+    out["encoder_fwd"] = encoder_forward_rate(pkg, model, x, precision)
+    for b in (4, 8, 32):
+        xb = x[:1].expand(b, -1, -1, -1, -1).contiguous()
+        out[f"encoder_fwd_batch{b}"] = encoder_forward_rate(pkg, model, xb, precision, iters=5)
+        del xb
+    return out
