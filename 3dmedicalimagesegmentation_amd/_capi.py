@@ -40,6 +40,15 @@ class GemmBf16Desc(ctypes.Structure):
     ]
 
 
+class LnGemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_long), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
+        ("W", c_void_p), ("ldw", c_long), ("bias", c_void_p), ("act", c_int),
+        ("pre", c_void_p), ("ldpre", c_long), ("Cb", c_void_p), ("ldcb", c_long), ("C", c_void_p), ("ldc", c_long),
+        ("xn", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
+    ]
+
+
 class GroupedProblem(ctypes.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int)]
 
@@ -58,6 +67,7 @@ _SIGNATURES = {
     "unetr_gemm": [ctypes.POINTER(GemmDesc), P, P, P, P, c_size_t, P],
     "unetr_gemm_bf16": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_size_t, P],
     "unetr_cast_bf16": [P, P, c_long, P],
+    "unetr_ln_gemm_bf16": [ctypes.POINTER(LnGemmDesc), P],
     "unetr_gemm_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, c_int, P],
     "unetr_gemm_bf16_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, P],
     "unetr_colsum_grouped": [ctypes.POINTER(ColsumProblem), c_int, P],

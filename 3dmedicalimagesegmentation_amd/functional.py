@@ -280,6 +280,24 @@ def gemm_bf16(A, B, M, N, K, *, b_kn=False, C=None, Cb=None, lda=None, ldb=None,
          Cb.data_ptr() if Cb is not None else None, ws.data_ptr(), ws.numel() * 4, _stream())
 
 
+def ln_gemm_bf16(x, gamma, beta, Wb, *, bias=None, act=0, C=None, Cb=None, pre=None, xn=None, mean=None, rstd=None):
+    """C / Cb [M,N] = act(LayerNorm(x)[M,K] @ Wb[N,K]^T + bias) in one launch (csrc/encoder.hip); optionally keeps the
+    normalised rows `xn` (bf16), `mean`, `rstd` and the pre-activation `pre` for backward"""
+    M, K = x.shape
+    N = Wb.shape[0]
+    d = _capi.LnGemmDesc()
+    d.x, d.ldx, d.gamma, d.beta, d.eps = x.data_ptr(), K, gamma.data_ptr(), beta.data_ptr(), LN_EPS
+    d.W, d.ldw, d.bias, d.act = Wb.data_ptr(), K, _p(bias), act
+    d.pre, d.ldpre, d.Cb, d.ldcb, d.C, d.ldc = _p(pre), N, _p(Cb), N, _p(C), N
+    d.xn, d.mean, d.rstd = _p(xn), _p(mean), _p(rstd)
+    d.M, d.N, d.K = M, N, K
+    call("unetr_ln_gemm_bf16", ctypes.byref(d), _stream())
+
+
+def fused_encoder_enabled():
+    return os.environ.get("UNETR_AMD_FUSED_ENCODER", "1") != "0"
+
+
 # ---- bf16 operand storage (bf16 precision mode) ---------------------------------------------------------------
 # The encoder's Linear layers read bf16-STORED operands through unetr_gemm_bf16: activations are emitted as bf16 by
 # the producing kernels (LayerNorm, attention, GELU epilogue), weights come from a bf16 shadow.  A shadow is fresh when
@@ -289,6 +307,19 @@ def gemm_bf16(A, B, M, N, K, *, b_kn=False, C=None, Cb=None, lda=None, ldb=None,
 # Under hipGraph capture a non-maintained shadow is always re-cast, so the cast is part of the captured step.
 _SHADOW = {}
 _WEIGHT_EPOCH = [0]
+_UNMAINTAINED = [0]     # how many arena shadows have been re-derived since the flat optimizer last vouched for them
+
+
+def mark_flat_maintained(params):
+    """flat-arena AdamW has just rewritten the whole bf16 shadow arena together with the masters: every registered shadow
+    of these parameters is in step again (only walks the table after something had to be re-derived)"""
+    if not _UNMAINTAINED[0]:
+        return
+    for w in params:
+        ent = _SHADOW.get(id(w))
+        if ent is not None and ent[4]() is w and ent[5] == w.data_ptr():
+            ent[1], ent[3] = w._version, True
+    _UNMAINTAINED[0] = 0
 
 
 def bf16_storage_enabled():
@@ -335,7 +366,10 @@ def weight_bf16(w):
         ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
     if not fresh:
         cast_bf16(w.detach(), out=ent[0])
-        ent[1], ent[2], ent[5] = w._version, _WEIGHT_EPOCH[0], w.data_ptr()
+        # re-derived here = somebody other than this package's optimizer changed the weight (or may have): the copy is no
+        # longer optimizer-maintained until that optimizer steps again (shadow_ptr_for_update / mark_flat_maintained)
+        ent[1], ent[2], ent[5], ent[3] = w._version, _WEIGHT_EPOCH[0], w.data_ptr(), False
+        _UNMAINTAINED[0] += 1
     return ent[0]
 
 
@@ -361,7 +395,7 @@ def conv_pack_get(w, kind, prec):
         ent[3] or (ent[2] == _WEIGHT_EPOCH[0] and not torch.cuda.is_current_stream_capturing()))
     if not fresh:
         _pack_launch([(w, ent[0], cin, cout, kind)], prec)
-        ent[1], ent[2], ent[5] = w._version, _WEIGHT_EPOCH[0], w.data_ptr()
+        ent[1], ent[2], ent[5], ent[3] = w._version, _WEIGHT_EPOCH[0], w.data_ptr(), False
     return ent[0]
 
 
@@ -726,22 +760,35 @@ def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, h
         # bf16-stored operands: every GEMM input below is written as bf16 by its producer (fp32 copies stay for
         # the weight-gradient GEMMs and the LayerNorm / attention backward kernels)
         f32 = dict(dtype=torch.float32, device=x.device)
-        y1b = bf16_like(x)
-        _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
+        fused = fused_encoder_enabled() and hid <= 1024      # LayerNorm as the prologue of the GEMM that consumes it
         y1 = y2 = a = x.new_empty(0)         # the fp32 twins are not materialised: every consumer reads bf16
         qkv = torch.empty(M, 3 * hid, **f32)
-        gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=qkv)
+        if fused:
+            y1b = bf16_like(x) if train else None
+            m1 = torch.empty(M, **f32) if train else None
+            r1 = torch.empty(M, **f32) if train else None
+            ln_gemm_bf16(x, n1w, n1b, weight_bf16(wqkv), C=qkv, xn=y1b, mean=m1, rstd=r1)
+        else:
+            y1b = bf16_like(x)
+            _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
+            gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=qkv)
         attb = bf16_like(x)
         att, lse = attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=attb)
         x1 = torch.empty(M, hid, **f32)
         gemm_bf16(attb, weight_bf16(wp), M, hid, hid, C=x1, bias=bp, res=x, ldr=hid)
-        y2b = bf16_like(x)
-        _, m2, r2 = layernorm_fwd(x1, n2w, n2b, bf16_out=y2b, want_fp32=False)
         u = torch.empty(M, mlp, **f32) if train else None      # pre-activation, only GELU' in backward reads it
         ab = torch.empty(M, mlp, dtype=torch.bfloat16, device=x.device)
-        gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, Cb=ab, bias=b1, act=1, pre=u)
-        if u is None:
-            u = x.new_empty(0)
+        if fused:
+            y2b = bf16_like(x) if train else None
+            m2 = torch.empty(M, **f32) if train else None
+            r2 = torch.empty(M, **f32) if train else None
+            ln_gemm_bf16(x1, n2w, n2b, weight_bf16(w1), bias=b1, act=1, Cb=ab, pre=u, xn=y2b, mean=m2, rstd=r2)
+        else:
+            y2b = bf16_like(x)
+            _, m2, r2 = layernorm_fwd(x1, n2w, n2b, bf16_out=y2b, want_fp32=False)
+            gemm_bf16(y2b, weight_bf16(w1), M, mlp, hid, Cb=ab, bias=b1, act=1, pre=u)
+        if not train:
+            u = m1 = r1 = m2 = r2 = y1b = y2b = x.new_empty(0)
         x2 = torch.empty(M, hid, **f32)
         gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
         twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs

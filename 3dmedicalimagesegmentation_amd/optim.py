@@ -121,6 +121,8 @@ class AdamW(torch.optim.Optimizer):
         steps = self._advance_steps(0, params, pattern, dev)
         for run in self._flat_runs(params, pattern):
             self._launch_run(group, run, steps, gbase, False, 1.0, stream)
+        if flat.get("shadow") is not None:           # the kernel rewrote the bf16 shadow slices of every parameter that stepped
+            Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has])
         return True
 
     # ---- data-parallel arena update: all-reduce pieces overlap the optimizer kernels of the pieces before them ----
@@ -155,4 +157,6 @@ class AdamW(torch.optim.Optimizer):
             if before_run is not None:
                 before_run(k, run[2], run[3])
             self._launch_run(group, run, steps, gsrc.data_ptr(), g_bf16, gscale, stream)
+        if self._flat.get("shadow") is not None:
+            Fn.mark_flat_maintained([p for p, has in zip(params, plan["pattern"]) if has])
         Fn.refresh_conv_packs()

@@ -117,6 +117,25 @@ int unetr_tconv2_fwd_supported(long M, int Cin, int Cout, long ldx, long ldy);
 int unetr_tconv2_wgrad_supported(long M, int Cin, int Cout, long ldx, long lddy);
 
 
+/* ---- LayerNorm fused into the GEMM that consumes it (bf16 mode, small token counts): y = act(LayerNorm(x) W^T + bias).
+ * The two calls per transformer block it replaces in MONAI's TransformerBlock.forward (built at unetr.py:78-89):
+ * attn.qkv(norm1(x)) and mlp.linear1(norm2(x)) followed by GELU.  x fp32 [M,K] (pitch ldx), gamma / beta [K], W bf16 [N,K]
+ * (pitch ldw, K contiguous).  Outputs (any may be NULL except that one of C / Cb is required): C fp32 / Cb bf16 [M,N]
+ * after the activation (act: 0 none, 1 exact-erf GELU), pre fp32 [M,N] before it; xn bf16 [M,K] = the normalised rows,
+ * mean / rstd [M] (the LayerNorm backward's and the weight gradient's inputs).  K % 64 == 0, K <= 1024, N % 4 == 0. */
+typedef struct {
+    const float* x; long ldx;
+    const float* gamma; const float* beta; float eps;
+    const void* W; long ldw;
+    const float* bias; int act;
+    float* pre; long ldpre;
+    void* Cb; long ldcb;
+    float* C; long ldc;
+    void* xn; float* mean; float* rstd;
+    int M, N, K;
+} unetr_ln_gemm_desc;
+int unetr_ln_gemm_bf16(const unetr_ln_gemm_desc* d, void* stream);
+
 /* ---- column sums: out[n] (+)= sum_m x[m*ld+n]  (bias / position-embedding gradients) ---------------- */
 int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate,
                  float* ws, size_t ws_bytes, void* stream);

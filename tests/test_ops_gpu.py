@@ -496,3 +496,57 @@ def test_gemm_padding_lanes_ignore_inf_nan(pkg, dev, prec, M, N, K):
     assert torch.equal(torch.isfinite(dw), torch.isfinite(rdw))
     ok = torch.isfinite(rdw)
     assert relerr(dw[ok], rdw[ok]) < TOL[prec]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,act", [(432, 2304, 768, 0), (432, 3072, 768, 1), (16, 384, 128, 0), (8, 512, 128, 1), (1000, 576, 192, 0),
+                                       (70, 200, 256, 1), (432, 768, 1024, 0)])
+def test_ln_gemm_bf16(pkg, dev, M, N, K, act):
+    """LayerNorm fused as the GEMM prologue (csrc/encoder.hip) vs torch: LayerNorm in fp32, rows rounded to bf16, fp64 product
+    with the bf16 weights, bias, exact GELU.  Also the by-products backward needs: normalised rows, mean, rstd, pre-activation."""
+    Fn = pkg.functional
+    x = g(M, K, seed=1) * 1.7 + 0.3
+    gam, bet = 1.0 + 0.2 * g(K, seed=2), 0.1 * g(K, seed=3)
+    w = (g(N, K, seed=4) * 0.05).bfloat16()
+    bias = 0.1 * g(N, seed=5)
+    xn_ref = F.layer_norm(x, (K,), gam, bet, 1e-5)
+    xnb = xn_ref.bfloat16()
+    pre_ref = (xnb.double() @ w.double().t() + bias.double()).float()
+    out_ref = F.gelu(pre_ref) if act else pre_ref
+    xd = x.to(dev)
+    C = torch.empty(M, N, device=dev)
+    Cb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    pre = torch.empty(M, N, device=dev)
+    xn = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    Fn.ln_gemm_bf16(xd, gam.to(dev), bet.to(dev), w.to(dev), bias=bias.to(dev), act=act, C=C, Cb=Cb, pre=pre, xn=xn, mean=mean, rstd=rstd)
+    # the kernel's bf16 rounding of the normalised rows may differ from torch's by one ulp where fp32 LN differs in the last bit
+    assert (xn.float().cpu() - xnb.float()).abs().max() <= 2 ** -7 * xnb.float().abs().max()
+    assert relerr(mean, x.mean(1)) < 1e-5 and relerr(rstd, (x.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    pre_own = (xn.float().cpu().double() @ w.double().t() + bias.double()).float()     # product of the rows the kernel itself kept
+    assert relerr(pre, pre_own) < 2e-5
+    assert relerr(pre, pre_ref) < 5e-3
+    own = F.gelu(pre_own) if act else pre_own
+    assert relerr(C, own) < 2e-5
+    assert torch.equal(Cb.cpu(), C.cpu().bfloat16())
+    # outputs optional: bf16 only, nothing kept
+    Cb2 = torch.empty_like(Cb)
+    Fn.ln_gemm_bf16(xd, gam.to(dev), bet.to(dev), w.to(dev), bias=bias.to(dev), act=act, Cb=Cb2)
+    assert torch.equal(Cb2, Cb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["6464", "6432", "3264", "64128"])
+def test_gemm_bf16_small_m_tiles(pkg, dev, cfg, monkeypatch):
+    """every small-M tile shape of the bf16-storage GEMM (normally chosen by workgroup count) on ragged shapes, both B layouts"""
+    Fn = pkg.functional
+    monkeypatch.setenv("UNETR_GEMM_CFG", cfg)
+    for (M, N, K) in ((432, 768, 768), (100, 200, 192), (432, 3072, 768), (33, 136, 64)):
+        x, w, dy = g(M, K, seed=1).bfloat16(), g(N, K, seed=2).bfloat16(), g(M, N, seed=3).bfloat16()
+        y = torch.empty(M, N, device=dev)
+        Fn.gemm_bf16(x.to(dev), w.to(dev), M, N, K, C=y)
+        assert relerr(y, (x.double() @ w.double().t()).float()) < 2e-5, (cfg, M, N, K)
+        if N % 64 == 0 and cfg != "6432":
+            dx = torch.empty(M, K, device=dev)
+            Fn.gemm_bf16(dy.to(dev), w.to(dev), M, K, N, b_kn=True, C=dx)
+            assert relerr(dx, (dy.double() @ w.double()).float()) < 2e-5, (cfg, M, N, K, "b_kn")
