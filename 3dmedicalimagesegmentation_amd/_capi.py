@@ -68,6 +68,8 @@ _SIGNATURES = {
     "unetr_gemm_bf16": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_size_t, P],
     "unetr_cast_bf16": [P, P, c_long, P],
     "unetr_ln_gemm_bf16": [ctypes.POINTER(LnGemmDesc), P],
+    "unetr_attention_bf16_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "unetr_attention_bf16_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "unetr_gemm_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, c_int, P],
     "unetr_gemm_bf16_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, P],
     "unetr_colsum_grouped": [ctypes.POINTER(ColsumProblem), c_int, P],

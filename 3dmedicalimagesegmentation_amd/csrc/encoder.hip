@@ -85,24 +85,24 @@ ln_gemm_kernel(LnGemmArgs a) {
     {
         const int nch = K >> 3;
         const int c0 = lane, c1 = lane + 64;
-        const bool v1 = c1 < nch;                          // (K <= 1024, K % 64 == 0: chunk c0 always exists)
-        const int c1c = v1 ? c1 : c0;
+        const bool v0 = c0 < nch, v1 = c1 < nch;           // K <= 1024: at most two chunks per lane; K < 512: some lanes idle
+        const int c0c = v0 ? c0 : 0, c1c = v1 ? c1 : 0;
         f32x4 v[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float* xr = a.x + (long)min(m0 + wave * 8 + i, a.M - 1) * a.ldx;
-            v[i][0] = *(const f32x4*)(xr + c0 * 8); v[i][1] = *(const f32x4*)(xr + c0 * 8 + 4);
+            v[i][0] = *(const f32x4*)(xr + c0c * 8); v[i][1] = *(const f32x4*)(xr + c0c * 8 + 4);
             v[i][2] = *(const f32x4*)(xr + c1c * 8); v[i][3] = *(const f32x4*)(xr + c1c * 8 + 4);
         }
-        const f32x4 g0 = *(const f32x4*)(a.gamma + c0 * 8), g1 = *(const f32x4*)(a.gamma + c0 * 8 + 4);
+        const f32x4 g0 = *(const f32x4*)(a.gamma + c0c * 8), g1 = *(const f32x4*)(a.gamma + c0c * 8 + 4);
         const f32x4 g2 = *(const f32x4*)(a.gamma + c1c * 8), g3 = *(const f32x4*)(a.gamma + c1c * 8 + 4);
-        const f32x4 b0 = *(const f32x4*)(a.beta + c0 * 8), b1 = *(const f32x4*)(a.beta + c0 * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(a.beta + c0c * 8), b1 = *(const f32x4*)(a.beta + c0c * 8 + 4);
         const f32x4 b2 = *(const f32x4*)(a.beta + c1c * 8), b3 = *(const f32x4*)(a.beta + c1c * 8 + 4);
         const float invK = 1.0f / (float)K;
         float mu[8], rs[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float s = (v[i][0][0] + v[i][0][1] + v[i][0][2] + v[i][0][3]) + (v[i][1][0] + v[i][1][1] + v[i][1][2] + v[i][1][3]);
+            float s = v0 ? (v[i][0][0] + v[i][0][1] + v[i][0][2] + v[i][0][3]) + (v[i][1][0] + v[i][1][1] + v[i][1][2] + v[i][1][3]) : 0.f;
             if (v1) s += (v[i][2][0] + v[i][2][1] + v[i][2][2] + v[i][2][3]) + (v[i][3][0] + v[i][3][1] + v[i][3][2] + v[i][3][3]);
             mu[i] = wave_sum(s) * invK;
         }
@@ -112,7 +112,7 @@ ln_gemm_kernel(LnGemmArgs a) {
 #pragma unroll
             for (int h = 0; h < 4; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[i][h][e] - mu[i]; q += (h < 2 || v1) ? d * d : 0.f; }
+                for (int e = 0; e < 4; ++e) { const float d = v[i][h][e] - mu[i]; q += (h < 2 ? v0 : v1) ? d * d : 0.f; }
             rs[i] = rsqrtf(wave_sum(q) * invK + a.eps);
         }
         const bool keep = a.xn != nullptr && tn == 0;
@@ -128,10 +128,10 @@ ln_gemm_kernel(LnGemmArgs a) {
                 o[12 + e] = (v[i][3][e] - mu[i]) * rs[i] * g3[e] + b3[e];
             }
             const u32x4 p0 = PrecBF16::pack(o), p1 = PrecBF16::pack(o + 8);
-            *(u32x4*)(lds + (c0 >> 3) * (BM * 128) + lds_tile_off(r, c0 & 7)) = p0;
+            if (v0) *(u32x4*)(lds + (c0 >> 3) * (BM * 128) + lds_tile_off(r, c0 & 7)) = p0;
             if (v1) *(u32x4*)(lds + (c1 >> 3) * (BM * 128) + lds_tile_off(r, c1 & 7)) = p1;
             if (keep && gm < a.M) {
-                *(u32x4*)(a.xn + (long)gm * K + c0 * 8) = p0;
+                if (v0) *(u32x4*)(a.xn + (long)gm * K + c0 * 8) = p0;
                 if (v1) *(u32x4*)(a.xn + (long)gm * K + c1 * 8) = p1;
                 if (lane == 0) { a.mean[gm] = mu[i]; a.rstd[gm] = rs[i]; }
             }

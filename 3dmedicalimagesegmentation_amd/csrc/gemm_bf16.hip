@@ -236,7 +236,7 @@ int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t
     int splits = 1;
     // few tiles (batch-2 token counts): the kernel is latency-bound, one workgroup's time is ~ its K steps, so long K
     // ranges are cut into slabs of >= 12 steps (shorter slabs cost more in the reduce launch than they save)
-    if (tiles < 128 && ksteps >= 24) splits = std::min(ksteps / 12, (int)((512 + tiles - 1) / tiles));
+    if (tiles < 192 && ksteps >= 24) splits = std::min(ksteps / 12, (int)((512 + tiles - 1) / tiles));
     if (const char* e = getenv("UNETR_GEMM_SPLITS")) { int v = atoi(e); if (v > 0) splits = std::min(v, ksteps); }
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits < 1 || ws == nullptr) splits = 1;
@@ -392,28 +392,26 @@ extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, con
     const int env_ns = getenv("UNETR_GEMM_STAGES") ? atoi(getenv("UNETR_GEMM_STAGES")) : 0;
     const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
 #define BF16_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st)
-    // Small token counts (batch 2: M = 432): one wave of workgroups, as many of the 256 CUs as the shape allows -- the tile
-    // is picked so that cdiv(M,BM) * cdiv(N,BN) comes closest to 256 from below (64x64: 84 workgroups at N = 768, 64x32 /
-    // 32x64: 168; 64x128 at N = 3072: 168 instead of 336 in two rounds).  cfg codes: 6464, 6432, 3264, 64128.
+    // Small token counts (batch 2: M = 432).  Measured per launch on MI355X (tools/probe_encoder.py, us incl. launch boundary):
+    //   forward, K = 768:   N = 768: 64x32 5.6 < 32x64 5.7 < 64x64 7.1;  N = 2304: 64x64 6.6 < 64x96 7.5 < 64x128 9.1;
+    //                       N = 3072: 64x64 10.5 < 64x96 11.2 < 64x128 13.7
+    //   forward, K = 3072, N = 768: 64x64 + 4 split-K slabs 12.5 ~ 64x32 13.0 < 32x64 13.6 < 64x64 unsplit 16.3
+    //   [K,N]-operand data gradients: K = 768: 32x64 (N = 768: 6.4, N = 3072: 11.8) < 64x64 (7.3, 13.1) < 64x128;
+    //                                 K = 3072, N = 768: 64x64 + split-K 14.4 < 64x128 + split-K 16.6 < 32x64 24.9
+    // i.e. short reductions want the most workgroups (a CU pulls only ~70 GB/s from L2), long ones the 64x64 tile cut into
+    // K slabs.  cfg codes (UNETR_GEMM_CFG): 6464, 6432, 3264, 64128, 6496.
     int cfg = env_cfg;
     if (!big && (cfg == 0 || cfg == 64)) {
-        const int cand[4][3] = {{64, 64, 6464}, {64, 32, 6432}, {32, 64, 3264}, {64, 128, 64128}};
-        long best = -1;
         cfg = 6464;
-        for (int i = 0; i < 4; ++i) {
-            if (cand[i][2] == 6432 && d->b_kn) continue;           // (the [K,N] image needs >= 8 chunks per row)
-            if (cand[i][2] == 64128 && N < 128) continue;
-            const long t = (long)cdiv(M, cand[i][0]) * cdiv(N, cand[i][1]);
-            const long score = t <= 256 ? t : 256 - (t - 256);        // just under one wave of workgroups is best
-            if (score > best) { best = score; cfg = cand[i][2]; }
-        }
-        if (env_cfg == 64) cfg = 6464;
+        if (env_cfg == 0 && K <= 1024 && N <= 1024) cfg = d->b_kn ? 3264 : 6432;
+        if (env_cfg == 0 && K <= 1024 && d->b_kn && N > 1024 && N % 64 == 0) cfg = 3264;
     }
     if (!d->b_kn) {
         if (big) { if (env_ns == 3) BF16_GO(4, 4, false, 3); if (env_ns == 4) BF16_GO(4, 4, false, 4); BF16_GO(4, 4, false, 2); }
         if (cfg == 6432) BF16_GO(2, 1, false, 4);
         if (cfg == 3264) BF16_GO(1, 2, false, 4);
         if (cfg == 64128) BF16_GO(2, 4, false, 3);
+        if (cfg == 6496) BF16_GO(2, 3, false, 3);
         if (env_ns == 2) BF16_GO(2, 2, false, 2);
         if (env_ns == 6) BF16_GO(2, 2, false, 6);
         BF16_GO(2, 2, false, 4);

@@ -294,8 +294,16 @@ def ln_gemm_bf16(x, gamma, beta, Wb, *, bias=None, act=0, C=None, Cb=None, pre=N
     call("unetr_ln_gemm_bf16", ctypes.byref(d), _stream())
 
 
-def fused_encoder_enabled():
-    return os.environ.get("UNETR_AMD_FUSED_ENCODER", "1") != "0"
+def fused_ln_enabled():
+    """LayerNorm as the prologue of the consuming GEMM (unetr_ln_gemm_bf16).  Off by default: measured on MI355X at 432
+    rows it LOSES to LayerNorm kernel + bf16 GEMM (13.3 vs 3.1 + 6.6 us for qkv, 17.5 vs 3.1 + 10.5 us for linear1): a CU
+    pulls ~70 GB/s from L2, and the fused tile reads its 64 fp32 rows (2x the bytes of the bf16 rows the GEMM alone reads)
+    once per column tile -- 36 times per row tile."""
+    return os.environ.get("UNETR_AMD_FUSED_LN", "0") == "1"
+
+
+def bf16_attention_enabled():
+    return os.environ.get("UNETR_AMD_BF16_ATTENTION", "1") != "0"
 
 
 # ---- bf16 operand storage (bf16 precision mode) ---------------------------------------------------------------
@@ -550,6 +558,20 @@ def attention_bwd(qkv, out, dout, lse, B, L, heads, dh, prec, dqkv_bf16=None):
     return dqkv
 
 
+def attention_bf16_fwd(qkvb, B, L, heads, dh, out_bf16, out=None):
+    lse = torch.empty(B, heads, L, dtype=torch.float32, device=qkvb.device)
+    call("unetr_attention_bf16_fwd", qkvb.data_ptr(), _p(out), out_bf16.data_ptr(), lse.data_ptr(), B, L, heads, dh, float(dh) ** -0.5, _stream())
+    return lse
+
+
+def attention_bf16_bwd(qkvb, outb, doutb, lse, B, L, heads, dh, dqkv=None):
+    dqkvb = torch.empty_like(qkvb)
+    delta = torch.empty_like(lse)
+    call("unetr_attention_bf16_bwd", qkvb.data_ptr(), outb.data_ptr(), doutb.data_ptr(), lse.data_ptr(), _p(dqkv), dqkvb.data_ptr(),
+         delta.data_ptr(), B, L, heads, dh, float(dh) ** -0.5, _stream())
+    return dqkvb
+
+
 def _use_gemm_conv():
     """UNETR_AMD_CONV=gemm routes 3x3x3 convs through the generic im2col-loader GEMM family instead of the
     dedicated LDS-halo kernels (kept for cross-checking one HIP path against the other)."""
@@ -760,20 +782,25 @@ def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, h
         # bf16-stored operands: every GEMM input below is written as bf16 by its producer (fp32 copies stay for
         # the weight-gradient GEMMs and the LayerNorm / attention backward kernels)
         f32 = dict(dtype=torch.float32, device=x.device)
-        fused = fused_encoder_enabled() and hid <= 1024      # LayerNorm as the prologue of the GEMM that consumes it
+        fused = fused_ln_enabled() and hid <= 1024      # LayerNorm as the prologue of the GEMM that consumes it
         y1 = y2 = a = x.new_empty(0)         # the fp32 twins are not materialised: every consumer reads bf16
-        qkv = torch.empty(M, 3 * hid, **f32)
+        b16att = bf16_attention_enabled() and dh == 64   # q/k/v stay bf16 from the GEMM epilogue to the attention kernels' LDS-DMA
+        qkv = torch.empty(M, 3 * hid, dtype=torch.bfloat16 if b16att else torch.float32, device=x.device)
         if fused:
             y1b = bf16_like(x) if train else None
             m1 = torch.empty(M, **f32) if train else None
             r1 = torch.empty(M, **f32) if train else None
-            ln_gemm_bf16(x, n1w, n1b, weight_bf16(wqkv), C=qkv, xn=y1b, mean=m1, rstd=r1)
+            ln_gemm_bf16(x, n1w, n1b, weight_bf16(wqkv), C=None if b16att else qkv, Cb=qkv if b16att else None, xn=y1b, mean=m1, rstd=r1)
         else:
             y1b = bf16_like(x)
             _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
-            gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=qkv)
+            gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=None if b16att else qkv, Cb=qkv if b16att else None)
         attb = bf16_like(x)
-        att, lse = attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=attb)
+        if b16att:
+            att = x.new_empty(0)
+            lse = attention_bf16_fwd(qkv, B, L, heads, dh, attb)
+        else:
+            att, lse = attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=attb)
         x1 = torch.empty(M, hid, **f32)
         gemm_bf16(attb, weight_bf16(wp), M, hid, hid, C=x1, bias=bp, res=x, ldr=hid)
         u = torch.empty(M, mlp, **f32) if train else None      # pre-activation, only GELU' in backward reads it
@@ -861,15 +888,23 @@ class TransformerBlockFn(torch.autograd.Function):
             dx1b = None
         dx1, dn2w, dn2b = layernorm_bwd_params(dy2, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
         # attention
-        if fast:
+        b16att = fast and qkv.dtype == torch.bfloat16
+        if b16att:
+            dattb = bf16_like(x)
+            gemm_bf16(dx1b, weight_bf16(wp), M, hid, hid, b_kn=True, Cb=dattb)
+        elif fast:
             datt = torch.empty(M, hid, **f32)
             gemm_bf16(dx1b, weight_bf16(wp), M, hid, hid, b_kn=True, C=datt)
         else:
             datt = linear_dgrad(dx1, wp, prec)
         dwp = wgrad_or_defer(dx1, att, prec, wp, dx1b, attb)
         dbp = colsum_or_defer(dx1, M, hid, hid, bp)
-        dqkvb = torch.empty(M, 3 * hid, dtype=torch.bfloat16, device=x.device) if fast else None
-        dqkv = attention_bwd(qkv, att, datt, lse, B, L, heads, dh, prec, dqkv_bf16=dqkvb)
+        if b16att:
+            dqkv = None
+            dqkvb = attention_bf16_bwd(qkv, attb, dattb, lse, B, L, heads, dh)
+        else:
+            dqkvb = torch.empty(M, 3 * hid, dtype=torch.bfloat16, device=x.device) if fast else None
+            dqkv = attention_bwd(qkv, att, datt, lse, B, L, heads, dh, prec, dqkv_bf16=dqkvb)
         dwqkv = wgrad_or_defer(dqkv, y1, prec, wqkv, dqkvb, y1b)
         if fast:
             dy1 = torch.empty(M, hid, **f32)

@@ -117,6 +117,15 @@ int unetr_tconv2_fwd_supported(long M, int Cin, int Cout, long ldx, long ldy);
 int unetr_tconv2_wgrad_supported(long M, int Cin, int Cout, long ldx, long lddy);
 
 
+/* ---- the same attention core on bf16-STORED q/k/v (bf16 mode, head dim 64): qkv bf16 [B*L, 3*heads*64] as written by
+ * unetr_ln_gemm_bf16, out fp32 and/or bf16 [B*L, heads*64] (either may be NULL), lse [B, heads, L].  Backward: out_bf16 /
+ * dout_bf16 bf16 [B*L, heads*64], writes dqkv_bf16 (required) and dqkv fp32 (optional), delta [B, heads, L] scratch.
+ * Returns "unsupported" (3) for other head dims -- the caller then uses unetr_attention_fwd / _bwd on fp32 q/k/v. */
+int unetr_attention_bf16_fwd(const void* qkv, float* out, void* out_bf16, float* lse, int B, int L, int heads, int dh,
+                             float scale, void* stream);
+int unetr_attention_bf16_bwd(const void* qkv, const void* out_bf16, const void* dout_bf16, const float* lse, float* dqkv,
+                             void* dqkv_bf16, float* delta, int B, int L, int heads, int dh, float scale, void* stream);
+
 /* ---- LayerNorm fused into the GEMM that consumes it (bf16 mode, small token counts): y = act(LayerNorm(x) W^T + bias).
  * The two calls per transformer block it replaces in MONAI's TransformerBlock.forward (built at unetr.py:78-89):
  * attn.qkv(norm1(x)) and mlp.linear1(norm2(x)) followed by GELU.  x fp32 [M,K] (pitch ldx), gamma / beta [K], W bf16 [N,K]

@@ -536,7 +536,7 @@ def test_ln_gemm_bf16(pkg, dev, M, N, K, act):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["6464", "6432", "3264", "64128"])
+@pytest.mark.parametrize("cfg", ["6464", "6432", "3264", "64128", "6496"])
 def test_gemm_bf16_small_m_tiles(pkg, dev, cfg, monkeypatch):
     """every small-M tile shape of the bf16-storage GEMM (normally chosen by workgroup count) on ragged shapes, both B layouts"""
     Fn = pkg.functional
@@ -546,7 +546,36 @@ def test_gemm_bf16_small_m_tiles(pkg, dev, cfg, monkeypatch):
         y = torch.empty(M, N, device=dev)
         Fn.gemm_bf16(x.to(dev), w.to(dev), M, N, K, C=y)
         assert relerr(y, (x.double() @ w.double().t()).float()) < 2e-5, (cfg, M, N, K)
-        if N % 64 == 0 and cfg != "6432":
+        if N % 64 == 0 and cfg not in ("6432", "6496"):
             dx = torch.empty(M, K, device=dev)
             Fn.gemm_bf16(dy.to(dev), w.to(dev), M, K, N, b_kn=True, C=dx)
             assert relerr(dx, (dy.double() @ w.double()).float()) < 2e-5, (cfg, M, N, K, "b_kn")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,heads", [(2, 216, 12), (1, 8, 2), (1, 1000, 3), (3, 230, 1), (1, 512, 2)])
+def test_attention_bf16_storage(pkg, dev, B, L, heads):
+    """attention on bf16-stored q/k/v (csrc/attention_b16.hip: LDS-DMA staged images, one image for row and transposed
+    reads, chunk-resident softmax; L = 1000 / 230 / 512 exercise the chunk loop with a ragged last chunk) vs torch on the
+    same bf16-rounded inputs; bf16 rounding of P / dS bounds the error."""
+    Fn = pkg.functional
+    dh, Hd = 64, heads * 64
+    qkv = (g(B * L, 3 * Hd, seed=1) * 0.8).bfloat16()
+    dout = (g(B * L, Hd, seed=2)).bfloat16()
+    ref_in = qkv.float().requires_grad_(True)
+    t = ref_in.view(B, L, 3, heads, dh).permute(2, 0, 3, 1, 4)          # "b l (qkv h d) -> qkv b h l d"
+    att = torch.softmax(t[0] @ t[1].transpose(-1, -2) * dh ** -0.5, dim=-1)
+    out_ref = (att @ t[2]).permute(0, 2, 1, 3).reshape(B * L, Hd)
+    out_ref.backward(dout.float())
+    qd = qkv.to(dev)
+    outb = torch.empty(B * L, Hd, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(B * L, Hd, device=dev)
+    lse = Fn.attention_bf16_fwd(qd, B, L, heads, dh, outb, out=out)
+    assert relerr(out, out_ref) < 1e-2
+    assert torch.equal(outb.cpu(), out.cpu().bfloat16())
+    lse_ref = torch.logsumexp(t[0] @ t[1].transpose(-1, -2) * dh ** -0.5, dim=-1)
+    assert relerr(lse, lse_ref) < 1e-4
+    dq32 = torch.empty(B * L, 3 * Hd, device=dev)
+    dqb = Fn.attention_bf16_bwd(qd, outb, dout.to(dev), lse, B, L, heads, dh, dqkv=dq32)
+    assert relerr(dq32, ref_in.grad) < 2e-2
+    assert torch.equal(dqb.cpu(), dq32.cpu().bfloat16())

@@ -56,17 +56,19 @@ res = {}
 
 env()
 res["layernorm_fwd (bf16 out)"] = timeit(lambda: Fn.layernorm_fwd(x, gam, bet, bf16_out=y1b, want_fp32=False))
-for cfg in ("6464", "64128"):
+for cfg in ("6464", "64128", "6496"):
     env(UNETR_GEMM_CFG=cfg)
     res[f"gemm_bf16 qkv   N=2304 K=768  cfg {cfg}"] = timeit(lambda: Fn.gemm_bf16(xb, w["qkv"], M, 3 * H, H, C=qkv))
     res[f"gemm_bf16 mlp1  N=3072 K=768  cfg {cfg} (+gelu, bf16 out, pre)"] = timeit(
         lambda: Fn.gemm_bf16(xb, w["w1"], M, MLP, H, Cb=ab, bias=bias3, act=1, pre=u))
+    qb2_ = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)
+    res[f"gemm_bf16 qkv   N=2304 K=768  cfg {cfg} (bf16 out only)"] = timeit(lambda: Fn.gemm_bf16(xb, w["qkv"], M, 3 * H, H, Cb=qb2_))
 for bn in (64, 128):
     env(UNETR_LNGEMM_BN=bn)
     res[f"ln_gemm   qkv   N=2304 K=768  BN {bn} (fp32 out, keeps xn/mean/rstd)"] = timeit(
         lambda: Fn.ln_gemm_bf16(x, gam, bet, w["qkv"], C=qkv, xn=y1b, mean=m1, rstd=r1))
-    res[f"ln_gemm   qkv   N=2304 K=768  BN {bn} (bf16 out only)"] = timeit(
-        lambda: Fn.ln_gemm_bf16(x, gam, bet, w["qkv"], Cb=ab[:, :3 * H].contiguous() if False else torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)))
+    qb_ = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)
+    res[f"ln_gemm   qkv   N=2304 K=768  BN {bn} (bf16 out only)"] = timeit(lambda: Fn.ln_gemm_bf16(x, gam, bet, w["qkv"], Cb=qb_))
     res[f"ln_gemm   mlp1  N=3072 K=768  BN {bn} (+gelu, bf16 out, pre, keeps)"] = timeit(
         lambda: Fn.ln_gemm_bf16(x, gam, bet, w["w1"], bias=bias3, act=1, Cb=ab, pre=u, xn=y1b, mean=m1, rstd=r1))
 for cfg in ("6464", "6432", "3264"):
@@ -103,6 +105,11 @@ att, lse = Fn.attention_fwd(qkv, B, L, heads, 64, 1)
 dout = torch.randn(M, H, device=dev)
 dqb = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)
 res["attention_bwd (2 kernels)"] = timeit(lambda: Fn.attention_bwd(qkv, att, dout, lse, B, L, heads, 64, 1, dqkv_bf16=dqb))
+qkvb = qkv.bfloat16()
+res["attention_bf16_fwd (bf16 qkv -> bf16 out)"] = timeit(lambda: Fn.attention_bf16_fwd(qkvb, B, L, heads, 64, y1b))
+lse2 = Fn.attention_bf16_fwd(qkvb, B, L, heads, 64, y1b)
+doutb = dout.bfloat16()
+res["attention_bf16_bwd (2 kernels, bf16 only)"] = timeit(lambda: Fn.attention_bf16_bwd(qkvb, y1b, doutb, lse2, B, L, heads, 64))
 dxb = torch.empty(M, H, device=dev, dtype=torch.bfloat16)
 res["layernorm_bwd (+dres, partials)"] = timeit(lambda: Fn.layernorm_bwd(dout, x, gam, m1, r1, dres=x1, dx_bf16=dxb))
 for k, v in res.items():
