@@ -81,6 +81,8 @@ _SIGNATURES = {
     "unetr_tconv2_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv2_fwd_supported": [c_long, c_int, c_int, c_long, c_long],
     "unetr_tconv2_wgrad_supported": [c_long, c_int, c_int, c_long, c_long],
+    "unetr_pixel_shuffle2": [P, P, c_long, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_pixel_unshuffle2_bf16": [P, c_long, P, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_colsum": [P, c_long, c_int, c_int, P, c_int, P, c_size_t, P],
     "unetr_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     "unetr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P],

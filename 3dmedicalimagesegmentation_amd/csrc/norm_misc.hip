@@ -464,17 +464,24 @@ outconv_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restric
     }
 }
 
-// dx[vox, ci] = sum_co dl[b,co,v] * w[co,ci];  bias-grad partials per block: part[blk][Cout]
+// dx[vox, ci] = sum_co dl[b,co,v] * w[co,ci];  per-block partials part[blk][Cout (+ Cout*Cin)]: the bias gradient and, when
+// WG (Cout * Cin <= 64: 4 classes x 16 features), the weight gradient dw[co,ci] = sum_vox dl[co,vox] * x[vox,ci] from the
+// SAME pass over dl (the x row is one extra 64-byte read per voxel).  Before, dw took two exact-fp32 GEMMs of shape
+// [4 x 884736] x [884736 x 16] on 16x16 tiles with a deep split-K reduce: 224 us per step for 64 numbers.
+template <bool WG>
 __global__ void __launch_bounds__(256)
-outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, float* __restrict__ dx, long lddx,
-                   float* __restrict__ part, int B, long V, int Cin, int Cout) {
+outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, const float* __restrict__ x, long ldx,
+                   float* __restrict__ dx, long lddx, float* __restrict__ part, int B, long V, int Cin, int Cout) {
     __shared__ float sw[OC_MAXCO * OC_MAXCI];
-    __shared__ float red[4][OC_MAXCO];
+    __shared__ float red[4][OC_MAXCO + 64];
     for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) sw[i] = w[i];
     __syncthreads();
     float bsum[OC_MAXCO];
 #pragma unroll
     for (int co = 0; co < OC_MAXCO; ++co) bsum[co] = 0.f;
+    float wsum[WG ? 64 : 1];
+#pragma unroll
+    for (int i = 0; i < (WG ? 64 : 1); ++i) wsum[i] = 0.f;
     const long total = (long)B * V;
     for (long vox = (long)blockIdx.x * blockDim.x + threadIdx.x; vox < total; vox += (long)gridDim.x * blockDim.x) {
         int b = (int)(vox / V); long v = vox - (long)b * V;
@@ -494,6 +501,19 @@ outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, fl
                 }
             *(f32x4*)(dx + vox * lddx + c4) = o;
         }
+        if constexpr (WG) {
+            // (WG: Cout <= 4, Cin <= 16, Cin % 4 == 0 -- checked by the launcher; slot co*16 + ci)
+#pragma unroll
+            for (int c4 = 0; c4 < 16; c4 += 4) {
+                if (c4 < Cin) {
+                    const f32x4 xv = *(const f32x4*)(x + vox * ldx + c4);
+#pragma unroll
+                    for (int co = 0; co < 4; ++co)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) wsum[co * 16 + c4 + e] += g[co] * xv[e];
+                }
+            }
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -501,9 +521,29 @@ outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, fl
         float s = wave_sum(bsum[co]);
         if (lane == 0) red[wave][co] = s;
     }
+    if constexpr (WG) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            float s = wave_sum(wsum[i]);
+            if (lane == 0) red[wave][OC_MAXCO + i] = s;
+        }
+    }
     __syncthreads();
-    if (threadIdx.x < Cout)
-        part[(long)blockIdx.x * Cout + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int np = Cout + (WG ? Cout * Cin : 0);
+    if ((int)threadIdx.x < np) {
+        int src = threadIdx.x;
+        if (WG && (int)threadIdx.x >= Cout) { const int k = threadIdx.x - Cout, co = k / Cin, ci = k - co * Cin; src = OC_MAXCO + co * 16 + ci; }
+        part[(long)blockIdx.x * np + threadIdx.x] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    }
+}
+
+// out0[n] = sum_r part[r][n] for n < n0, out1[n - n0] for the rest (bias gradient, then weight gradient)
+__global__ void outconv_final_kernel(const float* __restrict__ part, int R, int N, int n0, float* __restrict__ out0, float* __restrict__ out1) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += part[(long)r * N + n];
+    if (n < n0) out0[n] = s; else out1[n - n0] = s;
 }
 
 // -------------------------------------------------------------------------------------------- AdamW
@@ -735,21 +775,25 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx,
     if (Cout > OC_MAXCO || Cin > OC_MAXCI || (Cin & 3) || (ldx & 3) || (lddx & 3)) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     int nblk = grid_for((long)B * V, 256, 1024);
-    size_t part_bytes = (size_t)nblk * Cout * sizeof(float);
+    const bool wg = Cout <= 4 && Cin <= 16 && ((uintptr_t)x & 15) == 0;      // weight gradient from the same pass
+    const int np = Cout + (wg ? Cout * Cin : 0);
+    size_t part_bytes = (size_t)nblk * np * sizeof(float);
     size_t part_al = (part_bytes + 255) & ~(size_t)255;
     if (!ws || part_al + 4096 > ws_bytes) return UNETR_ERR_WORKSPACE;
-    hipLaunchKernelGGL(outconv_bwd_kernel, dim3(nblk), dim3(256), 0, st, dlogits, w, dx, lddx, ws, B, V, Cin, Cout);
+    if (wg) hipLaunchKernelGGL(outconv_bwd_kernel<true>, dim3(nblk), dim3(256), 0, st, dlogits, w, x, ldx, dx, lddx, ws, B, V, Cin, Cout);
+    else hipLaunchKernelGGL(outconv_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, dlogits, w, x, ldx, dx, lddx, ws, B, V, Cin, Cout);
     if (int e = unetr_check_launch()) return e;
     float* ws2 = (float*)((char*)ws + part_al);
     size_t ws2_bytes = ws_bytes - part_al;
-    // dbias = column sums of the [nblk, Cout] partials (ws2 holds the colsum's own partials)
+    // dbias (and dw) = column sums of the [nblk, np] partials (ws2 holds the colsum's own partials)
     {
         int RB = std::max(1, std::min(cdiv(nblk, 64), 256));
-        if ((size_t)RB * Cout * sizeof(float) > ws2_bytes) return UNETR_ERR_WORKSPACE;
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(Cout, 64), RB), dim3(256), 0, st, ws, (long)Cout, nblk, Cout, ws2, RB);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, st, ws2, RB, Cout, dbias, 0);
+        if ((size_t)RB * np * sizeof(float) > ws2_bytes) return UNETR_ERR_WORKSPACE;
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(np, 64), RB), dim3(256), 0, st, ws, (long)np, nblk, np, ws2, RB);
+        hipLaunchKernelGGL(outconv_final_kernel, dim3(cdiv(np, 256)), dim3(256), 0, st, ws2, RB, np, Cout, dbias, dw);
     }
-    // dw[Cout, Cin] = sum_b dl_b[Cout, V] * x_b[V, Cin]   (exact-fp32 MFMA, split-K over voxels)
+    if (wg) return unetr_check_launch();
+    // larger heads: dw[Cout, Cin] = sum_b dl_b[Cout, V] * x_b[V, Cin]   (exact-fp32 MFMA, split-K over voxels)
     for (int b = 0; b < B; ++b) {
         unetr_gemm_desc d{};
         d.M = Cout; d.N = Cin; d.K = (int)V; d.batch = 1; d.a_trans = 0; d.b_trans = 1;

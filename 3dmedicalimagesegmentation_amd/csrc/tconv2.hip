@@ -501,3 +501,60 @@ extern "C" int unetr_tconv2_dgrad(const float* dy, long lddy, const float* w, fl
     if (prec == UNETR_PREC_F32) return dgrad2<PrecF32>(dy, lddy, w, dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
+
+// ---- the SMALL transposed convs (768 channels at 6^3, 64 / 128 channels at 12^3) as plain bf16-storage GEMMs ---------------
+// out[m, co*8 + tap] = sum_ci x[m, ci] * w[ci, co, tap] is x[M, Cin] . W with torch's own weight [Cin, Cout*8] read as the
+// [K, N] operand of unetr_gemm_bf16 (b_kn = 1); the data gradient is dyg[M, Cout*8] . W^T with the same matrix as the
+// [N, K] operand; the weight gradient x^T . dyg lands in torch's layout as it is (grouped bf16 weight-gradient launch).
+// What is left of the "transposed conv" is a pixel shuffle: these two kernels move between the voxel-major output
+// y[outvox(m, tap), co] (pitch ldy: possibly the first half of a concatenation buffer) and the GEMM-side matrix.
+namespace {
+__device__ __forceinline__ long tc_outvox(int m, int tap, int D, int H, int W) {
+    int x = m % W; int t = m / W; int y = t % H; t /= H; int z = t % D; int b = t / D;
+    return (((long)b * 2 * D + 2 * z + (tap >> 2)) * 2 * H + 2 * y + ((tap >> 1) & 1)) * 2 * W + 2 * x + (tap & 1);
+}
+// thread (m, co): reads the 8 taps of one output channel (32 contiguous bytes), writes one float into each of the 8 output rows
+__global__ void __launch_bounds__(256)
+pixel_shuffle2_kernel(const float* __restrict__ t, float* __restrict__ y, long ldy, long M, int D, int H, int W, int Cout) {
+    const long total = M * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / Cout), co = (int)(i - (long)m * Cout);
+        const f32x4 a = *(const f32x4*)(t + i * 8), b = *(const f32x4*)(t + i * 8 + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) y[tc_outvox(m, tap, D, H, W) * ldy + co] = v[tap];
+    }
+}
+// thread (m, co): gathers dy at the 8 output voxels of input voxel m, writes 8 bf16 (16 bytes) of dyg[m, co*8 .. co*8+7]
+__global__ void __launch_bounds__(256)
+pixel_unshuffle2_bf16_kernel(const float* __restrict__ dy, long lddy, uint16_t* __restrict__ g, long M, int D, int H, int W, int Cout) {
+    const long total = M * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / Cout), co = (int)(i - (long)m * Cout);
+        float v[8];
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) v[tap] = dy[tc_outvox(m, tap, D, H, W) * lddy + co];
+        *(u32x4*)(g + i * 8) = PrecBF16::pack(v);
+    }
+}
+}  // namespace
+
+extern "C" int unetr_pixel_shuffle2(const float* t, float* y, long ldy, int B, int D, int H, int W, int Cout, void* stream) {
+    if (!t || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || ldy < Cout) return UNETR_ERR_ARG;
+    if ((uintptr_t)t & 15) return UNETR_ERR_UNSUPPORTED;
+    const long M = (long)B * D * H * W;
+    if (M >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3((unsigned)std::min<long>(cdiv(M * Cout, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
+                       t, y, ldy, M, D, H, W, Cout);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_pixel_unshuffle2_bf16(const float* dy, long lddy, void* g, int B, int D, int H, int W, int Cout, void* stream) {
+    if (!dy || !g || B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || lddy < Cout) return UNETR_ERR_ARG;
+    if ((uintptr_t)g & 15) return UNETR_ERR_UNSUPPORTED;
+    const long M = (long)B * D * H * W;
+    if (M >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pixel_unshuffle2_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(M * Cout, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
+                       dy, lddy, (uint16_t*)g, M, D, H, W, Cout);
+    return unetr_check_launch();
+}

@@ -705,16 +705,51 @@ def instnorm_bwd(dy, lddy, x, sa, B, V, C, lrelu, x2=None, sb=None):
     return dx, dx2
 
 
+def _tconv_as_gemm(prec, M, cin, cout, ld_in):
+    """the small transposed convs (768 channels at 6^3, 64 / 128 at 12^3) go through the bf16-storage GEMM: few voxels, many
+    channels -- exactly where the dedicated voxel-tile kernels decline and the gather-loader GEMM family was 3-6x slower"""
+    return (prec == _capi.PREC_BF16 and bf16_storage_enabled() and os.environ.get("UNETR_AMD_TCONV_GEMM", "1") != "0"
+            and cin % 64 == 0 and M % 8 == 0 and ld_in == cin and M < 8192)
+
+
 def tconv_fwd(x, ldx, w, dims, cin, cout, prec, out=None, ldo=None):
     B, D, H, W = dims
     if out is None:
         out = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, dtype=torch.float32, device=x.device)
         ldo = cout
+    M = B * D * H * W
+    if _tconv_as_gemm(prec, M, cin, cout, ldx):
+        xb = _twin(x).view(M, cin)
+        tmp = torch.empty(M, 8 * cout, dtype=torch.float32, device=x.device)
+        gemm_bf16(xb, weight_bf16(w).view(cin, 8 * cout), M, 8 * cout, cin, b_kn=True, C=tmp)
+        call("unetr_pixel_shuffle2", tmp.data_ptr(), out.data_ptr(), ldo, B, D, H, W, cout, _stream())
+        return out, xb
     ws = workspace(x.device)
     args = (x.data_ptr(), ldx, w.data_ptr(), out.data_ptr(), ldo, B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
     if call_rc("unetr_tconv2_fwd", *args) != 0:       # dedicated kernel declines the shape -> generic GEMM family
         call("unetr_tconv_fwd", *args)
-    return out
+    return out, None
+
+
+def tconv_bwd(x, ldx, xb, dy, lddy, w, dims, cin, cout, prec, need_dx):
+    """(dx or None, dw as autograd wants it) of the transposed conv; xb: the bf16 input the GEMM form of forward kept"""
+    B, D, H, W = dims
+    M = B * D * H * W
+    if xb is not None:
+        dyg = torch.empty(M, 8 * cout, dtype=torch.bfloat16, device=dy.device)
+        call("unetr_pixel_unshuffle2_bf16", dy.data_ptr(), lddy, dyg.data_ptr(), B, D, H, W, cout, _stream())
+        dx = None
+        if need_dx:
+            dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=dy.device)
+            gemm_bf16(dyg, weight_bf16(w).view(cin, 8 * cout), M, cin, 8 * cout, C=dx.view(M, cin))
+        # dw[Cin, Cout*8] = x^T dyg is torch's [Cin, Cout, 2, 2, 2] as it stands: joins the grouped end-of-backward launch
+        dw = wgrad_or_defer(None, None, prec, w, xb, dyg)
+        if dw is not None:
+            dw = dw.view_as(w)
+        return dx, dw
+    dx = tconv_dgrad(dy, lddy, w, dims, cin, cout, prec) if need_dx else None
+    dw = tconv_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=_gout(w))
+    return dx, _ret(w, dw)
 
 
 def tconv_dgrad(dy, lddy, w, dims, cin, cout, prec):
@@ -1022,8 +1057,9 @@ class TconvFn(torch.autograd.Function):
         x, ldx = _rows(x)
         B, D, H, W, cin = x.shape
         cout = w.shape[1]
-        y = tconv_fwd(x, ldx, w, (B, D, H, W), cin, cout, prec)
+        y, xb = tconv_fwd(x, ldx, w, (B, D, H, W), cin, cout, prec)
         ctx.save_for_backward(x, w)
+        ctx.xb = xb
         ctx.meta = (ldx, (B, D, H, W), cin, cout, prec)
         return y
 
@@ -1032,9 +1068,8 @@ class TconvFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         ldx, dims, cin, cout, prec = ctx.meta
         dy, lddy = _rows(dy)
-        dx = tconv_dgrad(dy, lddy, w, dims, cin, cout, prec) if ctx.needs_input_grad[0] else None
-        dw = tconv_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=_gout(w))
-        return dx, _ret(w, dw), None
+        dx, dw = tconv_bwd(x, ldx, ctx.xb, dy, lddy, w, dims, cin, cout, prec, ctx.needs_input_grad[0])
+        return dx, dw, None
 
 
 class UpBlockFn(torch.autograd.Function):
@@ -1051,7 +1086,7 @@ class UpBlockFn(torch.autograd.Function):
         dims2 = (B, 2 * D, 2 * H, 2 * W)
         rows2 = B * 8 * D * H * W
         cat = torch.empty(*dims2, 2 * C, dtype=torch.float32, device=inp.device)
-        tconv_fwd(inp, ldi, wt, (B, D, H, W), cin, C, prec, out=cat, ldo=2 * C)
+        _, ctx.xb = tconv_fwd(inp, ldi, wt, (B, D, H, W), cin, C, prec, out=cat, ldo=2 * C)
         call("unetr_copy_rows", cat.data_ptr() + 4 * C, 2 * C, skip.data_ptr(), lds, rows2, C, 0, _stream())
         out, saved = _resblock_fwd(cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, prec)
         ctx.save_for_backward(inp, wt, w1, w2, w3, cat, *saved)
@@ -1065,10 +1100,9 @@ class UpBlockFn(torch.autograd.Function):
         B, D, H, W = dims
         dims2 = (B, 2 * D, 2 * H, 2 * W)
         dcat, dw1, dw2, dw3 = _resblock_bwd(dout, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True)
-        dinp = tconv_dgrad(dcat, 2 * C, wt, dims, cin, C, prec) if ctx.needs_input_grad[0] else None
-        dwt = tconv_wgrad(inp, ldi, dcat, 2 * C, dims, cin, C, prec, out=_gout(wt))
+        dinp, dwt = tconv_bwd(inp, ldi, ctx.xb, dcat, 2 * C, wt, dims, cin, C, prec, ctx.needs_input_grad[0])
         dskip = dcat[..., C:] if ctx.needs_input_grad[1] else None
-        return dinp, dskip, _ret(wt, dwt), _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None
+        return dinp, dskip, dwt, _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None
 
 
 class OutConvFn(torch.autograd.Function):

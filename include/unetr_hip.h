@@ -145,6 +145,12 @@ typedef struct {
 } unetr_ln_gemm_desc;
 int unetr_ln_gemm_bf16(const unetr_ln_gemm_desc* d, void* stream);
 
+/* The small transposed convs (Cin a multiple of 64, bf16 mode) run as plain unetr_gemm_bf16 calls on torch's own weight
+ * matrix [Cin, Cout*8]; these two move between the GEMM-side matrix t / g [M, Cout*8] (column = co*8 + tap) and the
+ * voxel-major tensor y / dy [B, 2D, 2H, 2W, Cout] (pitch ldy): the pixel shuffle that is left of the "transposed conv". */
+int unetr_pixel_shuffle2(const float* t, float* y, long ldy, int B, int D, int H, int W, int Cout, void* stream);
+int unetr_pixel_unshuffle2_bf16(const float* dy, long lddy, void* g_bf16, int B, int D, int H, int W, int Cout, void* stream);
+
 /* ---- column sums: out[n] (+)= sum_m x[m*ld+n]  (bias / position-embedding gradients) ---------------- */
 int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate,
                  float* ws, size_t ws_bytes, void* stream);

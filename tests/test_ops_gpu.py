@@ -175,7 +175,7 @@ def ncdhw(x):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("B,S,cin,cout", [(2, 6, 768, 32), (1, 5, 32, 16), (2, 12, 64, 64),
+@pytest.mark.parametrize("B,S,cin,cout", [(2, 6, 768, 32), (1, 5, 32, 16), (2, 12, 64, 64), (2, 6, 768, 128), (2, 12, 128, 64),
                                           # shapes the dedicated tconv2 kernels take (>= 2048 input voxels, small channel counts):
                                           (2, 16, 32, 16), (1, 17, 16, 8), (1, 13, 64, 32), (1, 16, 48, 24), (2, 12, 32, 32), (1, 14, 16, 64)])
 def test_tconv(pkg, dev, prec, B, S, cin, cout):
@@ -186,8 +186,14 @@ def test_tconv(pkg, dev, prec, B, S, cin, cout):
     yr.backward(dy)
     dims = (B, S, S, S)
     xd, wd, dyd = cl(x).to(dev), w.to(dev), cl(dy).to(dev)
-    assert relerr(ncdhw(Fn.tconv_fwd(xd, cin, wd, dims, cin, cout, prec).cpu()), yr) < TOL[prec]
-    assert relerr(ncdhw(Fn.tconv_dgrad(dyd, cout, wd, dims, cin, cout, prec).cpu()), xr.grad) < TOL[prec]
+    y, xb = Fn.tconv_fwd(xd, cin, wd, dims, cin, cout, prec)
+    # (bf16 mode, Cin % 64 == 0, few voxels: the bf16-storage GEMM + pixel-shuffle form; xb is the bf16 input it kept)
+    assert (xb is not None) == (prec == 1 and cin % 64 == 0 and B * S ** 3 < 8192 and (B * S ** 3) % 8 == 0)
+    assert relerr(ncdhw(y.cpu()), yr) < TOL[prec]
+    dx, dw = Fn.tconv_bwd(xd, cin, xb, dyd, cout, wd, dims, cin, cout, prec, True)
+    assert relerr(ncdhw(dx.cpu()), xr.grad) < TOL[prec]
+    assert dw.shape == wr.grad.shape and relerr(dw, wr.grad) < TOL[prec]
+    assert relerr(ncdhw(Fn.tconv_dgrad(dyd, cout, wd, dims, cin, cout, prec).cpu()), xr.grad) < TOL[prec]      # the direct kernels
     assert relerr(Fn.tconv_wgrad(xd, cin, dyd, cout, dims, cin, cout, prec), wr.grad) < TOL[prec]
     # write into / read from one half of a concat buffer
     cat = torch.zeros(B, 2 * S, 2 * S, 2 * S, 2 * cout, device=dev)

@@ -80,7 +80,7 @@ def main():
         dims = (B, S, S, S)
         flops = 2.0 * v * a.cin * a.cout * 8
         nbytes = 4.0 * v * (a.cin + 8 * a.cout)
-        fn = {"tconv_fwd": lambda: Fn.tconv_fwd(x, a.cin, w, dims, a.cin, a.cout, prec),
+        fn = {"tconv_fwd": lambda: Fn.tconv_fwd(x, a.cin, w, dims, a.cin, a.cout, prec)[0],
               "tconv_dgrad": lambda: Fn.tconv_dgrad(dy, a.cout, w, dims, a.cin, a.cout, prec),
               "tconv_wgrad": lambda: Fn.tconv_wgrad(x, a.cin, dy, a.cout, dims, a.cin, a.cout, prec)}[a.kernel]
         label = f"{a.kernel} {a.cin}->{a.cout} @ {S}^3 B={B} {a.prec}"
