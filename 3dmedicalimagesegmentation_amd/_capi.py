@@ -81,8 +81,8 @@ _SIGNATURES = {
     "unetr_tconv2_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv2_fwd_supported": [c_long, c_int, c_int, c_long, c_long],
     "unetr_tconv2_wgrad_supported": [c_long, c_int, c_int, c_long, c_long],
-    "unetr_pixel_shuffle2": [P, P, c_long, c_int, c_int, c_int, c_int, c_int, P],
-    "unetr_pixel_unshuffle2_bf16": [P, c_long, P, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_pixel_shuffle2": [P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_pixel_unshuffle2_bf16": [P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_colsum": [P, c_long, c_int, c_int, P, c_int, P, c_size_t, P],
     "unetr_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     "unetr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_size_t, P],
@@ -93,22 +93,22 @@ _SIGNATURES = {
     "unetr_conv_gemm_wgrad": [P, c_long, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
-    "unetr_conv3_fwd_fused": [P, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_fwd_fused": [P, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_dgrad_fused": [P, c_long, P, P, c_long, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_pack_grouped": [ctypes.POINTER(PackProblem), c_int, c_int, P],
     "unetr_conv3_pack_1x1": [P, P, c_int, c_int, c_int, P],
     "unetr_instnorm_stats_finalize": [P, c_int, c_int, c_long, c_int, c_float, P, P],
-    "unetr_conv3_wgrad": [P, c_long, P, c_long, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_wgrad": [P, c_long, P, c_long, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_debug_tr16": [P, P, P],
-    "unetr_instnorm_stats": [P, c_long, c_int, c_long, c_int, c_float, P, P, c_size_t, P],
-    "unetr_instnorm_apply": [P, c_long, P, P, c_long, P, P, c_long, c_int, c_long, c_int, c_int, P],
-    "unetr_instnorm_bwd": [P, c_long, P, c_long, P, P, c_long, P, P, c_long, P, c_long, c_int, c_long, c_int, c_int, P, c_size_t, P],
-    "unetr_nchw_to_nhwc": [P, P, c_long, c_int, c_int, c_long, P],
-    "unetr_nhwc_to_nchw": [P, c_long, P, c_int, c_int, c_long, c_int, P],
+    "unetr_instnorm_stats": [P, c_long, c_int, c_long, c_int, c_float, P, P, c_size_t, c_int, P],
+    "unetr_instnorm_apply": [P, c_long, P, P, c_long, P, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
+    "unetr_instnorm_bwd": [P, c_long, P, c_long, P, P, c_long, P, P, c_long, P, c_long, c_int, c_long, c_int, c_int, P, c_size_t, c_int, P],
+    "unetr_nchw_to_nhwc": [P, P, c_long, c_int, c_int, c_long, c_int, P],
+    "unetr_nhwc_to_nchw": [P, c_long, P, c_int, c_int, c_long, c_int, c_int, P],
     "unetr_patch_gather": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
-    "unetr_copy_rows": [P, c_long, P, c_long, c_long, c_int, c_int, P],
-    "unetr_outconv_fwd": [P, c_long, P, P, P, c_int, c_long, c_int, c_int, P],
-    "unetr_outconv_bwd": [P, P, c_long, P, P, c_long, P, P, c_int, c_long, c_int, c_int, P, c_size_t, P],
+    "unetr_copy_rows": [P, c_long, P, c_long, c_long, c_int, c_int, c_int, P],
+    "unetr_outconv_fwd": [P, c_long, P, P, P, c_int, c_long, c_int, c_int, c_int, P],
+    "unetr_outconv_bwd": [P, P, c_long, P, P, c_long, P, P, c_int, c_long, c_int, c_int, P, c_size_t, c_int, P],
     "unetr_dicece_fwd": [P, P, c_int, c_int, c_long, c_int, c_float, c_float, P, P, P, c_size_t, P],
     "unetr_dicece_bwd": [P, P, P, P, P, c_int, c_int, c_long, c_int, P],
     "unetr_sw_accumulate": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

@@ -87,3 +87,34 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- activation storage type of the conv side: fp32 (fp32 precision mode) or bf16 (bf16 precision mode: every feature map
+// and feature-map gradient between the kernels is stored as bf16 -- half the HBM bytes of passes that are bandwidth-bound;
+// statistics, weights, accumulators and reductions stay fp32).  Io<T> = the 4-element / 1-element access of such a tensor.
+template <class T> struct Io;
+template <> struct Io<float> {
+    static constexpr int B16 = 0;
+    static __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+    static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+    static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
+template <> struct Io<uint16_t> {
+    static constexpr int B16 = 1;
+    static __device__ __forceinline__ f32x4 ld4(const uint16_t* p) { return __builtin_convertvector(*(const bf16x4*)p, f32x4); }
+    static __device__ __forceinline__ void st4(uint16_t* p, f32x4 v) { *(bf16x4*)p = __builtin_convertvector(v, bf16x4); }
+    static __device__ __forceinline__ float ld1(const uint16_t* p) { return __builtin_bit_cast(float, (uint32_t)*p << 16); }
+    static __device__ __forceinline__ void st1(uint16_t* p, float v) { __bf16 h = (__bf16)v; *p = __builtin_bit_cast(uint16_t, h); }
+};
+// bf16 precision mode <=> bf16 activation storage: the element type of the feature maps a kernel instantiated for P reads and writes
+template <class P> struct ActOf { typedef float type; };
+template <> struct ActOf<PrecBF16> { typedef uint16_t type; };
+// P::CH consecutive elements at p (16 bytes either way) as one packed MFMA operand chunk; zero when !ok (p must be a valid
+// address even then: callers clamp it)
+template <class P>
+__device__ __forceinline__ u32x4 act_chunk(const typename ActOf<P>::type* p, bool ok) {
+    const u32x4 w = *(const u32x4*)p;
+    return ok ? w : (u32x4){0u, 0u, 0u, 0u};
+}
+// run CALL with `AT` bound to the activation storage type selected by the run-time flag act16
+#define ACT_DISPATCH(act16, ...) do { if (act16) { typedef uint16_t AT; __VA_ARGS__; } else { typedef float AT; __VA_ARGS__; } } while (0)

@@ -66,10 +66,40 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 // batches of SB chunks per thread with no dependent instruction in between, so a batch costs ONE memory
 // round trip instead of SB (the first version looped load -> convert -> ds_write per chunk and ran the
 // 96^3 convs at 1.1 TB/s).  vec: 16-byte loads (aligned, Cin % 4 == 0); otherwise predicated scalar loads.
-template <class P, int NCH, bool VEC>
-__device__ __forceinline__ void stage_halo(const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0, int D, int H, int W,
+// XM = how the input tensor is stored: 0 fp32, predicated scalar loads (single-channel image); 1 fp32, 16-byte loads of four
+// channels; 2 bf16 (bf16 precision mode: feature maps are stored as bf16), one 16-byte load = the 8 channels of a piece.
+template <class P, int NCH, int XM>
+__device__ __forceinline__ void stage_halo(const void* __restrict__ xv, long ldx, int b, int z0, int y0, int x0, int D, int H, int W,
                                            int c0, int Cin, int pitch, char* halo) {
     constexpr int CH = P::CH, TOTAL = NHALO * NCH, ITERS = (TOTAL + 255) / 256, SB = 6, NQ = CH / 4;
+    constexpr bool VEC = XM == 1;
+    if constexpr (XM == 2) {
+        const uint16_t* __restrict__ xh = (const uint16_t*)xv;
+        for (int it0 = 0; it0 < ITERS; it0 += SB) {
+            u32x4 buf[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int id = threadIdx.x + (it0 + j) * 256;
+                const int hv = id / NCH, ch = id - hv * NCH;
+                const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+                const int c = c0 + ch * CH;
+                const bool ok = (it0 + j < ITERS) && id < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
+                                (unsigned)gx < (unsigned)W && c < Cin;
+                buf[j] = act_chunk<P>((const typename ActOf<P>::type*)(ok ? xh + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + c : xh), ok);
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int id = threadIdx.x + (it0 + j) * 256;
+                if (it0 + j < ITERS && id < TOTAL) {
+                    const int hv = id / NCH, ch = id - hv * NCH;
+                    *(u32x4*)(halo + hv * pitch + ch * 16) = buf[j];
+                }
+            }
+        }
+        return;
+    }
+    const float* __restrict__ x = (const float*)xv;
     for (int it0 = 0; it0 < ITERS; it0 += SB) {
         f32x4 buf[SB][NQ];
 #pragma unroll
@@ -135,10 +165,11 @@ __device__ __forceinline__ void tile_coords(int id, int total, int ntx, int nty,
 
 constexpr int FPITCH = 80;  // 64 B of channels (one k-block) + 16 B pad per halo voxel
 
-template <class P, int NTB, bool VEC>
+template <class P, int NTB, int XM>
 __global__ void __launch_bounds__(256)
-conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
+conv3_fwd_kernel(const void* __restrict__ x, long ldx, const char* __restrict__ wp, typename ActOf<P>::type* __restrict__ y, long ldy, int accumulate,
                  int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz) {
+    typedef typename ActOf<P>::type YT;
     constexpr int CH = P::CH, SL = 4 * CH;
     __shared__ __attribute__((aligned(16))) char halo[NHALO * FPITCH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -155,7 +186,7 @@ conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__
 
     for (int slab = 0; slab < nslab; ++slab) {
         __syncthreads();
-        stage_halo<P, 4, VEC>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, FPITCH, halo);
+        stage_halo<P, 4, XM>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, FPITCH, halo);
         __syncthreads();
         // B fragment of (tap, slab, n-tile j): 16 bytes at wp[((tap*nslab+slab)*Cout + n)*64 + g*16].
         // Fragments are prefetched one GROUP of GT taps ahead (L1/L2 latency ~ a few hundred cycles must hide
@@ -203,16 +234,16 @@ conv3_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__
             for (int rr = 0; rr < 4; ++rr) {
                 const int xo = x0 + 4 * g + rr;
                 if (xo >= W) continue;
-                float* yp = y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r;
+                YT* yp = y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r;
                 if (accumulate) {
                     float old[NTB];
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) old[j] = yp[j * 16];
+                    for (int j = 0; j < NTB; ++j) old[j] = Io<YT>::ld1(yp + j * 16);
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr] + old[j];
+                    for (int j = 0; j < NTB; ++j) Io<YT>::st1(yp + j * 16, acc[i][j][rr] + old[j]);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) yp[j * 16] = acc[i][j][rr];
+                    for (int j = 0; j < NTB; ++j) Io<YT>::st1(yp + j * 16, acc[i][j][rr]);
                 }
             }
         }
@@ -242,11 +273,34 @@ struct HaloRegs {
 // and are zeroed in halo_store from the okbits mask.  Nothing here depends on the loaded values, so the loads stay in
 // flight across the MFMA phase that follows (a select / multiply right after the load is either turned back into a
 // conditional load behind an exec-mask branch with 64-bit address arithmetic, or waits for the data before the MFMAs).
-template <class P, int NCH, bool VEC>
-__device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const float* __restrict__ x, long ldx, int b, int z0, int y0, int x0,
+template <class P, int NCH, int XM>
+__device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const void* __restrict__ xv, long ldx, int b, int z0, int y0, int x0,
                                           int D, int H, int W, int c0, int Cin) {
     constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
+    constexpr bool VEC = XM == 1;
     static_assert(HaloRegs<P, NCH>::ITERS * NQ <= 32, "okbits is one 32-bit mask");
+    if constexpr (XM == 2) {
+        // bf16-stored input: the 8 channels of a piece are ONE 16-byte load, already in MFMA operand form; it travels in
+        // v[j][0] (bit pattern) and halo_store writes it to the window as it is (both okbits of the piece carry its mask)
+        const uint16_t* __restrict__ xh = (const uint16_t*)xv + (long)b * D * H * W * ldx;
+        const int ld32 = (int)ldx;
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < HaloRegs<P, NCH>::ITERS; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int hv = id / NCH, ch = id - hv * NCH;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const int c = c0 + ch * CH;
+            const bool ok = id < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin;
+            const int off = ok ? ((gz * H + gy) * W + gx) * ld32 + c : 0;
+            R.v[j][0] = __builtin_bit_cast(f32x4, *(const u32x4*)(xh + off));
+            bits |= ok ? (((1u << NQ) - 1u) << (j * NQ)) : 0u;
+        }
+        R.okbits = bits;
+        return;
+    }
+    const float* __restrict__ x = (const float*)xv;
     const float* __restrict__ xb = x + (long)b * D * H * W * ldx;
     const int ld32 = (int)ldx;
     unsigned bits = 0;
@@ -286,7 +340,7 @@ __device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const float* __re
     R.okbits = bits;
 }
 
-template <class P, int NCH>
+template <class P, int NCH, int XM = 1>
 __device__ __forceinline__ void halo_store(const HaloRegs<P, NCH>& R, int pitch, char* halo) {
     constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
 #pragma unroll
@@ -294,10 +348,15 @@ __device__ __forceinline__ void halo_store(const HaloRegs<P, NCH>& R, int pitch,
         const int id = threadIdx.x + j * 256;
         if (id < TOTAL) {
             const int hv = id / NCH, ch = id - hv * NCH;
-            float v[CH];
+            u32x4 w;
+            if constexpr (XM == 2) {
+                w = __builtin_bit_cast(u32x4, R.v[j][0]);
+            } else {
+                float v[CH];
 #pragma unroll
-            for (int c4 = 0; c4 < NQ; ++c4) { v[4 * c4] = R.v[j][c4][0]; v[4 * c4 + 1] = R.v[j][c4][1]; v[4 * c4 + 2] = R.v[j][c4][2]; v[4 * c4 + 3] = R.v[j][c4][3]; }
-            u32x4 w = P::pack(v);
+                for (int c4 = 0; c4 < NQ; ++c4) { v[4 * c4] = R.v[j][c4][0]; v[4 * c4 + 1] = R.v[j][c4][1]; v[4 * c4 + 2] = R.v[j][c4][2]; v[4 * c4 + 3] = R.v[j][c4][3]; }
+                w = P::pack(v);
+            }
             // zero the out-of-window pieces on the PACKED words (dword d holds elements of piece d * NQ / 4)
 #pragma unroll
             for (int d = 0; d < 4; ++d) w[d] = ((R.okbits >> (j * NQ + d * NQ / 4)) & 1u) ? w[d] : 0u;
@@ -359,12 +418,13 @@ __device__ __forceinline__ void stats_flush(float (&s1)[NTB], float (&s2)[NTB], 
 //   the 1x1x1 branch) multiplied by a 1x1x1 weight matrix in the tile epilogue: dx = conv3x3x3^T(dc1) + conv1x1x1^T(dc3) in
 //   one pass, instead of a GEMM writing dx followed by an accumulating conv that re-reads it.  x3 fragments are loaded
 //   straight from global memory in MFMA operand shape (16 voxels x one 16-byte chunk per lane group).
-template <class P, int NTB, bool PAIR, bool VEC, int FUSE>
+template <class P, int NTB, bool PAIR, int XM, int FUSE>
 __global__ void __launch_bounds__(256, (FUSE == 2 ? (PAIR && NTB == 1) : (FUSE == 3 ? NTB == 1 : (FUSE == 1 && (NTB == 1 || (!PAIR && NTB == 2))))) ? 2 : 1)
-conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wp, float* __restrict__ y, long ldy, int accumulate,
+conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restrict__ wp, typename ActOf<P>::type* __restrict__ y, long ldy, int accumulate,
                       int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles,
-                      float* __restrict__ part, const char* __restrict__ wp3, float* __restrict__ y3, long ldy3,
+                      float* __restrict__ part, const char* __restrict__ wp3, typename ActOf<P>::type* __restrict__ y3, long ldy3,
                       float* __restrict__ part3, int K3) {
+    typedef typename ActOf<P>::type YT;
     constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16 + 16;
     __shared__ __attribute__((aligned(16))) char halo[NHALO * PITCH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -419,7 +479,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
     if (tile < ntiles) {
         int tx, ty, tz, b;
         tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
-        halo_load<P, NCH, VEC>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, 0, Cin);
+        halo_load<P, NCH, XM>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, 0, Cin);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         int tx, ty, tz, b;
@@ -446,7 +506,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
 
         for (int slab = 0; slab < nslab; ++slab) {
             __syncthreads();                       // everyone is done reading the previous window
-            halo_store<P, NCH>(R, PITCH, halo);    // (waits for the prefetched loads)
+            halo_store<P, NCH, XM>(R, PITCH, halo);    // (waits for the prefetched loads)
             __syncthreads();
             {   // prefetch the next (tile, slab) window; it lands while the MFMAs below run
                 int ntile = tile, nslb = slab + 1;
@@ -454,7 +514,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                 if (ntile < ntiles) {
                     int ax, ay, az, ab;
                     tile_coords(ntile, ntiles, ntx, nty, ntz, ax, ay, az, ab);
-                    halo_load<P, NCH, VEC>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, nslb * SL, Cin);
+                    halo_load<P, NCH, XM>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, nslb * SL, Cin);
                 }
             }
             if constexpr (PAIR) {
@@ -528,7 +588,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
         {
             // 16 voxel rows x NTB channel tiles per lane; out-of-volume voxels are clamped to voxel 0 of the tile row
             // for the (batched, unconditional) read of the accumulate path and skipped on store
-            float* yrow[4][4];
+            YT* yrow[4][4];
             bool okv[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -540,30 +600,24 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                 }
             if constexpr (FUSE == 4) {
                 // acc += x3[voxel, :] . w3: A rows = the 16 x-positions of output row i (lane r), chunk g of each 64-byte k-block
-                const float* x3 = y3;
+                const YT* x3 = y3;
                 const int n3 = (K3 + 4 * CH - 1) / (4 * CH);
                 for (int kb = 0; kb < n3; ++kb) {
                     u32x4 w3f[NTB];
 #pragma unroll
                     for (int j = 0; j < NTB; ++j) w3f[j] = *(const u32x4*)(wp3 + ((long)kb * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
                     const int c3 = kb * 4 * CH + g * CH;
-                    float av[4][CH];
+                    u32x4 av[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int yo = y0 + i, xo = x0 + r;
                         const bool ok = zo < D && yo < H && xo < W && c3 + CH <= K3;
-                        const float* q = x3 + (ok ? ((((long)b * D + zo) * H + yo) * W + xo) * ldy3 + c3 : 0);
-#pragma unroll
-                        for (int e = 0; e < CH / 4; ++e) {
-                            const f32x4 t = *(const f32x4*)(q + 4 * e);
-                            av[i][4 * e] = ok ? t[0] : 0.f; av[i][4 * e + 1] = ok ? t[1] : 0.f; av[i][4 * e + 2] = ok ? t[2] : 0.f; av[i][4 * e + 3] = ok ? t[3] : 0.f;
-                        }
+                        av[i] = act_chunk<P>(x3 + (ok ? ((((long)b * D + zo) * H + yo) * W + xo) * ldy3 + c3 : 0), ok);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const u32x4 a = P::pack(av[i]);
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, w3f[j]);
+                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], av[i], w3f[j]);
                     }
                 }
             }
@@ -574,12 +628,12 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) old[rr][j] = yrow[i][rr][j * 16];
+                        for (int j = 0; j < NTB; ++j) old[rr][j] = Io<YT>::ld1(yrow[i][rr] + j * 16);
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                         for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) yrow[i][rr][j * 16] = acc[i][j][rr] + old[rr][j];
+                            if (okv[i][rr]) Io<YT>::st1(yrow[i][rr] + j * 16, acc[i][j][rr] + old[rr][j]);
                 }
             } else {
 #pragma unroll
@@ -588,7 +642,7 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                         for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) yrow[i][rr][j * 16] = acc[i][j][rr];
+                            if (okv[i][rr]) Io<YT>::st1(yrow[i][rr] + j * 16, acc[i][j][rr]);
             }
             if constexpr (STATS) stats_add<NTB>(acc, okv, rs1, rs2);
             if constexpr (has3) {
@@ -596,10 +650,10 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        float* q = y3 + (yrow[i][rr] - y);          // same pitch as y (checked by the host)
+                        YT* q = y3 + (yrow[i][rr] - y);          // same pitch as y (checked by the host)
 #pragma unroll
                         for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) q[j * 16] = acc3[i][j][rr];
+                            if (okv[i][rr]) Io<YT>::st1(q + j * 16, acc3[i][j][rr]);
                     }
                 stats_add<NTB>(acc3, okv, rt1, rt2);
             }
@@ -620,10 +674,10 @@ conv3_fwd_pipe_kernel(const float* __restrict__ x, long ldx, const char* __restr
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        float* q = y3 + (yrow[i][rr] - y);
+                        YT* q = y3 + (yrow[i][rr] - y);
 #pragma unroll
                         for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) q[j * 16] = a3[i][j][rr];
+                            if (okv[i][rr]) Io<YT>::st1(q + j * 16, a3[i][j][rr]);
                     }
                 stats_add<NTB>(a3, okv, rt1, rt2);
             }
@@ -670,11 +724,14 @@ template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
     static constexpr int UPW = (NUX + 3) / 4;                 // units per wave
 };
 
-template <class P, bool VECX, bool VECY, bool HAS3, int CIS, bool PIPE_OK>
+// XMX: storage of x (see stage_halo); dy / dy3 are feature-map gradients: ActOf<P> (bf16 in bf16 mode -- VECY is then moot:
+// a 16-channel dy row is two 16-byte pieces)
+template <class P, int XMX, bool VECY, bool HAS3, int CIS, bool PIPE_OK>
 __global__ void __launch_bounds__(256, CIS == 1 ? (HAS3 ? 2 : 3) : 1)   // CIS = 1: 41-43 KB of LDS -> three workgroups per CU (two with the second dy image: 168 registers would spill)
-conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
-                   const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
+conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>::type* __restrict__ dy, long lddy, float* __restrict__ part,
+                   const typename ActOf<P>::type* __restrict__ dy3, long lddy3, float* __restrict__ part3,
                    int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
+    typedef typename ActOf<P>::type GT;
     using C = WgCfg<P, HAS3, CIS>;
     typedef typename C::T T;
     constexpr int CH = P::CH, WG_UNITS = C::NU, WG_UPW = C::UPW;
@@ -702,7 +759,7 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
 
     // dy tile(s): 256 voxels x 16 channels
     constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
-    auto load_dy = [&](const float* __restrict__ src, long ld, int b, int z0, int y0, int x0, f32x4 (&buf)[YIT][NQ]) {
+    auto load_dy = [&](const GT* __restrict__ src, long ld, int b, int z0, int y0, int x0, f32x4 (&buf)[YIT][NQ]) {
 #pragma unroll
         for (int j = 0; j < YIT; ++j) {
             const int id = threadIdx.x + j * 256;
@@ -710,19 +767,24 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
             const int gz = z0 + (v >> 6), gy = y0 + ((v >> 4) & 3), gx = x0 + (v & 15);
             const int cc = co0 + ch * CH;
             const bool ok = gz < D && gy < H && gx < W && cc < Cout;
-            const float* q = ok ? src + ((((long)b * D + gz) * H + gy) * W + gx) * ld + cc : src;   // branch-free
+            const GT* q = ok ? src + ((((long)b * D + gz) * H + gy) * W + gx) * ld + cc : src;   // branch-free
+            if constexpr (CH == 8) {
+                // bf16-stored gradient: one 16-byte load = the packed piece (bit pattern kept in buf[j][0])
+                buf[j][0] = __builtin_bit_cast(f32x4, act_chunk<P>(q, ok));
+            } else {
 #pragma unroll
-            for (int c4 = 0; c4 < NQ; ++c4) {
-                if constexpr (VECY) {
-                    const bool okc = ok && cc + 4 * c4 + 4 <= Cout;
-                    f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : src);
-                    buf[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else {
+                for (int c4 = 0; c4 < NQ; ++c4) {
+                    if constexpr (VECY) {
+                        const bool okc = ok && cc + 4 * c4 + 4 <= Cout;
+                        f32x4 t = *(const f32x4*)(okc ? q + 4 * c4 : src);
+                        buf[j][c4] = okc ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool oke = ok && cc + 4 * c4 + e < Cout;
-                        float t = *(oke ? q + 4 * c4 + e : src);
-                        buf[j][c4][e] = oke ? t : 0.f;
+                        for (int e = 0; e < 4; ++e) {
+                            const bool oke = ok && cc + 4 * c4 + e < Cout;
+                            float t = *(oke ? q + 4 * c4 + e : src);
+                            buf[j][c4][e] = oke ? t : 0.f;
+                        }
                     }
                 }
             }
@@ -733,10 +795,14 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
         for (int j = 0; j < YIT; ++j) {
             const int id = threadIdx.x + j * 256;
             const int v = id / YCH, ch = id - v * YCH;
-            float vals[CH];
+            if constexpr (CH == 8) {
+                *(u32x4*)(img + v * C::PY + ch * 16) = __builtin_bit_cast(u32x4, buf[j][0]);
+            } else {
+                float vals[CH];
 #pragma unroll
-            for (int c4 = 0; c4 < NQ; ++c4) { vals[4 * c4] = buf[j][c4][0]; vals[4 * c4 + 1] = buf[j][c4][1]; vals[4 * c4 + 2] = buf[j][c4][2]; vals[4 * c4 + 3] = buf[j][c4][3]; }
-            *(u32x4*)(img + v * C::PY + ch * 16) = P::pack(vals);
+                for (int c4 = 0; c4 < NQ; ++c4) { vals[4 * c4] = buf[j][c4][0]; vals[4 * c4 + 1] = buf[j][c4][1]; vals[4 * c4 + 2] = buf[j][c4][2]; vals[4 * c4 + 3] = buf[j][c4][3]; }
+                *(u32x4*)(img + v * C::PY + ch * 16) = P::pack(vals);
+            }
         }
     };
     // PIPE (16-channel slab only: the prefetch registers fit next to two resident workgroups per CU): the window and dy
@@ -748,7 +814,7 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
         if ((int)blockIdx.x < ntiles) {
             int tx, ty, tz, b;
             tile_coords(blockIdx.x, ntiles, ntx, nty, ntz, tx, ty, tz, b);
-            halo_load<P, 16 / CH, VECX>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, ci0, Cin);
+            halo_load<P, 16 / CH, XMX>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, ci0, Cin);
             load_dy(dy, lddy, b, tz * TZ, ty * TY, tx * TX, ybuf);
             if constexpr (HAS3) load_dy(dy3, lddy3, b, tz * TZ, ty * TY, tx * TX, y3buf);
         }
@@ -759,7 +825,7 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
         if constexpr (PIPE) {
-            halo_store<P, 16 / CH>(R, C::PX, ximg);
+            halo_store<P, 16 / CH, XMX>(R, C::PX, ximg);
             store_dy(ybuf, yimg);
             if constexpr (HAS3) store_dy(y3buf, y3img);
             __syncthreads();
@@ -767,12 +833,12 @@ conv3_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restric
             if (nt < ntiles) {
                 int ax, ay, az, ab;
                 tile_coords(nt, ntiles, ntx, nty, ntz, ax, ay, az, ab);
-                halo_load<P, 16 / CH, VECX>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, ci0, Cin);
+                halo_load<P, 16 / CH, XMX>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, ci0, Cin);
                 load_dy(dy, lddy, ab, az * TZ, ay * TY, ax * TX, ybuf);
                 if constexpr (HAS3) load_dy(dy3, lddy3, ab, az * TZ, ay * TY, ax * TX, y3buf);
             }
         } else {
-            stage_halo<P, 16 * CIS / CH, VECX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
+            stage_halo<P, 16 * CIS / CH, XMX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
             load_dy(dy, lddy, b, z0, y0, x0, ybuf);
             store_dy(ybuf, yimg);
             if constexpr (HAS3) { load_dy(dy3, lddy3, b, z0, y0, x0, y3buf); store_dy(y3buf, y3img); }
@@ -960,11 +1026,15 @@ int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st
     return unetr_check_launch();
 }
 
-struct FuseArgs { float* part; const void* wp3; float* y3; long ldy3; float* part3; int rows; int k3; };   // k3 > 0: FUSE 4 (y3 = second input)
+struct FuseArgs { float* part; const void* wp3; void* y3; long ldy3; float* part3; int rows; int k3; };   // k3 > 0: FUSE 4 (y3 = second input)
 
+// x_f32: the input tensor is fp32 even in bf16 mode (the image in front of encoder1: <= 16 channels, pair layout only)
 template <class P>
-int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accumulate, int B, int D, int H, int W, int Cin, int Cout,
-          hipStream_t st, FuseArgs* fz = nullptr) {
+int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accumulate, int B, int D, int H, int W, int Cin, int Cout,
+          hipStream_t st, FuseArgs* fz = nullptr, int x_f32 = 0) {
+    typedef typename ActOf<P>::type YT;
+    YT* y = (YT*)yv;
+    constexpr bool B16 = P::CH == 8;
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long spatial = (long)B * ntx * nty * ntz;
     const int ntn = Cout / 16;
@@ -973,21 +1043,34 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
         ntb = std::min(ntn, 8);
         while (ntb > 1 && spatial * (ntn / ntb) < 512) ntb >>= 1;
     }
-    const int vec = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
+    int xm = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
+    if (B16 && !x_f32) {
+        if (((uintptr_t)x & 15) || (ldx & 7) || (Cin & 7)) return UNETR_ERR_UNSUPPORTED;     // bf16 rows: whole 16-byte pieces
+        xm = 2;
+    }
+    if (B16 && fz && fz->k3 > 0 && ((fz->ldy3 & 7) || ((uintptr_t)fz->y3 & 15) || (fz->k3 & 7))) return UNETR_ERR_UNSUPPORTED;
     if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
     if (conv_pipe_enabled() && ntb <= 4) {
         // persistent, software-pipelined kernel: a few resident workgroups per CU walk the tiles
         const bool pair = use_pair<P>(Cin);
+        if (B16 && xm != 2 && !pair) return UNETR_ERR_UNSUPPORTED;   // fp32 input in bf16 mode = the image: pair layout only
         if (pair && ntb > 2) ntb = 2;
         const long cap = 512;   // 2 resident workgroups per CU (VGPR-limited); more would queue behind them
         dim3 pgrid((unsigned)std::min<long>(spatial, cap), ntn / ntb);
-#define LAUNCH_PIPE_F(NTB_, PAIR_, VEC_, FUSE_)                                                                                   \
-    hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, VEC_, FUSE_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
+#define LAUNCH_PIPE_F(NTB_, PAIR_, XM_, FUSE_)                                                                                    \
+    hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, XM_, FUSE_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
                        accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial, fz ? fz->part : nullptr,                       \
-                       fz ? (const char*)fz->wp3 : nullptr, fz ? fz->y3 : nullptr, fz ? fz->ldy3 : 0, fz ? fz->part3 : nullptr,            \
+                       fz ? (const char*)fz->wp3 : nullptr, fz ? (YT*)fz->y3 : nullptr, fz ? fz->ldy3 : 0, fz ? fz->part3 : nullptr,       \
                        fz ? fz->k3 : 0)
 #define LAUNCH_PIPE_V(NTB_, PAIR_, FUSE_)                                                                                         \
-    do { if (vec) LAUNCH_PIPE_F(NTB_, PAIR_, true, FUSE_); else LAUNCH_PIPE_F(NTB_, PAIR_, false, FUSE_); } while (0)
+    do {                                                                                                                          \
+        if constexpr (B16) {                                                                                                      \
+            if (xm == 2) { LAUNCH_PIPE_F(NTB_, PAIR_, 2, FUSE_); break; }                                                         \
+            if constexpr (PAIR_) { if (xm == 1) LAUNCH_PIPE_F(NTB_, true, 1, FUSE_); else LAUNCH_PIPE_F(NTB_, true, 0, FUSE_); }  \
+        } else {                                                                                                                  \
+            if (xm == 1) LAUNCH_PIPE_F(NTB_, PAIR_, 1, FUSE_); else LAUNCH_PIPE_F(NTB_, PAIR_, 0, FUSE_);                         \
+        }                                                                                                                         \
+    } while (0)
 #define LAUNCH_PIPE(NTB_, PAIR_)                                                                                                  \
     do {                                                                                                                          \
         if (fz && fz->k3 > 0) { LAUNCH_PIPE_V(NTB_, PAIR_, 4); break; }                                                           \
@@ -1015,12 +1098,13 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
     }
     if (fz) return UNETR_ERR_UNSUPPORTED;       // fused statistics / 1x1 need the persistent kernel
     dim3 grid((unsigned)spatial, ntn / ntb);
+    if (B16 && xm != 2) return UNETR_ERR_UNSUPPORTED;
+#define LAUNCH_FWD_X(NTB_, XM_) hipLaunchKernelGGL((conv3_fwd_kernel<P, NTB_, XM_>), grid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
+                                                   accumulate, D, H, W, Cin, Cout, ntx, nty, ntz)
 #define LAUNCH_FWD(NTB_)                                                                                                          \
     do {                                                                                                                          \
-        if (vec) hipLaunchKernelGGL((conv3_fwd_kernel<P, NTB_, true>), grid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy,     \
-                                    accumulate, D, H, W, Cin, Cout, ntx, nty, ntz);                                               \
-        else hipLaunchKernelGGL((conv3_fwd_kernel<P, NTB_, false>), grid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy,       \
-                                accumulate, D, H, W, Cin, Cout, ntx, nty, ntz);                                                   \
+        if constexpr (B16) LAUNCH_FWD_X(NTB_, 2);                                                                                 \
+        else { if (xm == 1) LAUNCH_FWD_X(NTB_, 1); else LAUNCH_FWD_X(NTB_, 0); }                                                  \
     } while (0)
     switch (ntb) {
         case 1: LAUNCH_FWD(1); break;
@@ -1033,8 +1117,12 @@ int fwd_t(const float* x, long ldx, const void* wp, float* y, long ldy, int accu
 }
 
 template <class P>
-int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, const float* dy3, long lddy3, float* dw3,
-            int B, int D, int H, int W, int Cin, int Cout, float* ws, size_t ws_bytes, hipStream_t st) {
+int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, const void* dy3v, long lddy3, float* dw3,
+            int B, int D, int H, int W, int Cin, int Cout, float* ws, size_t ws_bytes, hipStream_t st, int x_f32 = 0) {
+    typedef typename ActOf<P>::type GT;
+    const GT* dy = (const GT*)dyv;
+    const GT* dy3 = (const GT*)dy3v;
+    constexpr bool B16 = P::CH == 8;
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long ntiles = (long)B * ntx * nty * ntz;
     if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
@@ -1053,9 +1141,17 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
     float* ws3 = ws + (size_t)G * n;
     const int vecy3 = (dy3 && ((uintptr_t)dy3 & 15) == 0 && (lddy3 & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
     if (nci > 65535 || nco > 65535) return UNETR_ERR_ARG;
-    const int vecx = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;
+    int vecx = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0) ? 1 : 0;      // XMX
     const int vecy = (((uintptr_t)dy & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
     const bool vy = vecy && (!dy3 || vecy3);
+    if (B16) {
+        // bf16-stored gradients (and input, unless it is the fp32 image): whole 16-byte pieces of 8 channels
+        if (((uintptr_t)dy & 15) || (lddy & 7) || (Cout & 7) || (dy3 && (((uintptr_t)dy3 & 15) || (lddy3 & 7)))) return UNETR_ERR_UNSUPPORTED;
+        if (!x_f32) {
+            if (((uintptr_t)x & 15) || (ldx & 7) || (Cin & 7)) return UNETR_ERR_UNSUPPORTED;
+            vecx = 2;
+        }
+    }
 #define LAUNCH_WG_C(VX_, VY_, H3_, CIS_)                                                                                          \
     hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, H3_, CIS_, (CIS_ == 1)>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, \
                        ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles)
@@ -1064,10 +1160,16 @@ int wgrad_t(const float* x, long ldx, const float* dy, long lddy, float* dw, con
         if (dy3) { if (cis == 1) LAUNCH_WG_C(VX_, VY_, true, 1); else LAUNCH_WG_C(VX_, VY_, true, 2); }                            \
         else { if (cis == 1) LAUNCH_WG_C(VX_, VY_, false, 1); else LAUNCH_WG_C(VX_, VY_, false, 2); }                              \
     } while (0)
-    if (vecx && vy) LAUNCH_WG(true, true);
-    else if (vecx) LAUNCH_WG(true, false);
-    else if (vy) LAUNCH_WG(false, true);
-    else LAUNCH_WG(false, false);
+    if constexpr (B16) {
+        if (vecx == 2) LAUNCH_WG(2, true);
+        else if (vecx == 1) LAUNCH_WG(1, true);
+        else LAUNCH_WG(0, true);
+    } else {
+        if (vecx && vy) LAUNCH_WG(1, true);
+        else if (vecx) LAUNCH_WG(1, false);
+        else if (vy) LAUNCH_WG(0, true);
+        else LAUNCH_WG(0, false);
+    }
     int blocks = (int)std::min<long>((n + 31) / 32, 16384);
     hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, (int)G, n, dw);
     if (dy3) hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((int)std::min<long>((n3 + 31) / 32, 16384)), dim3(256), 0, st, ws3, (int)G, n3, dw3);
@@ -1089,7 +1191,7 @@ extern "C" int unetr_conv3_pack_weight(const float* w, void* wpack, int Cin, int
     return UNETR_ERR_ARG;
 }
 
-extern "C" int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, float* y, long ldy, int accumulate,
+extern "C" int unetr_conv3_fwd(const void* x, long ldx, const void* wpack, void* y, long ldy, int accumulate,
                                int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream) {
     if (!x || !wpack || !y || B <= 0) return UNETR_ERR_ARG;
     if (Cout % 16) return UNETR_ERR_UNSUPPORTED;
@@ -1100,9 +1202,9 @@ extern "C" int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, floa
 
 // Forward of the first half of MONAI's UnetResBlock in one launch (unetr.py:90-98 and the decoder blocks :135-174):
 // y = conv3x3x3(x), its InstanceNorm statistics, and optionally y3 = conv1x1x1(x) with its statistics.
-extern "C" int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack, float* y, long ldy, float* stats,
-                                     const void* w3pack, float* y3, long ldy3, float* stats3, float eps,
-                                     int B, int D, int H, int W, int Cin, int Cout, int prec,
+extern "C" int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack, void* y, long ldy, float* stats,
+                                     const void* w3pack, void* y3, long ldy3, float* stats3, float eps,
+                                     int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32,
                                      float* ws, size_t ws_bytes, void* stream) {
     if (!x || !wpack || !y || !stats || B <= 0) return UNETR_ERR_ARG;
     if ((w3pack != nullptr) != (y3 != nullptr) || (w3pack != nullptr) != (stats3 != nullptr)) return UNETR_ERR_ARG;
@@ -1113,7 +1215,7 @@ extern "C" int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack
     if (!ws || per * (w3pack ? 2 : 1) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
     FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr, 0, 0};
     int rc;
-    if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
+    if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz, x_f32);
     else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
     else return UNETR_ERR_ARG;
     if (rc) return rc;
@@ -1173,8 +1275,8 @@ extern "C" int unetr_conv3_pack_1x1(const float* w3, void* w3pack, int Cin, int 
 
 // Data gradient of MONAI's UnetResBlock input in one launch: dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3).
 // wpack_dgrad from unetr_conv3_pack_weight(mode 1); w3 is the 1x1x1 weight [Cout, Cin] itself (packed here into ws).
-extern "C" int unetr_conv3_dgrad_fused(const float* dc1, long ld1, const void* wpack_dgrad, const float* dc3, long ld3, const float* w3,
-                                       const void* w3pack_t, float* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout,
+extern "C" int unetr_conv3_dgrad_fused(const void* dc1, long ld1, const void* wpack_dgrad, const void* dc3, long ld3, const float* w3,
+                                       const void* w3pack_t, void* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout,
                                        int prec, float* ws, size_t ws_bytes, void* stream) {
     if (!dc1 || !wpack_dgrad || !dc3 || (!w3 && !w3pack_t) || !dx || B <= 0) return UNETR_ERR_ARG;
     if (Cin % 16 || Cout % 4 || (ld3 & 3) || ((uintptr_t)dc3 & 15)) return UNETR_ERR_UNSUPPORTED;
@@ -1187,19 +1289,19 @@ extern "C" int unetr_conv3_dgrad_fused(const float* dc1, long ld1, const void* w
         if (rc) return rc;
         w3t = ws;
     }
-    FuseArgs fz{nullptr, w3t, const_cast<float*>(dc3), ld3, nullptr, 0, Cout};
+    FuseArgs fz{nullptr, w3t, const_cast<void*>(dc3), ld3, nullptr, 0, Cout};
     // the data gradient is the same kernel with contraction over the block's Cout channels and Cin outputs
     if (prec == UNETR_PREC_BF16) return fwd_t<PrecBF16>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
     if (prec == UNETR_PREC_F32) return fwd_t<PrecF32>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
     return UNETR_ERR_ARG;
 }
 
-extern "C" int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
-                                 const float* dy3, long ldy3, float* dw3,
-                                 int B, int D, int H, int W, int Cin, int Cout, int prec,
+extern "C" int unetr_conv3_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw,
+                                 const void* dy3, long ldy3, float* dw3,
+                                 int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32,
                                  float* ws, size_t ws_bytes, void* stream) {
     if (!x || !dy || !dw || B <= 0 || ((dy3 != nullptr) != (dw3 != nullptr))) return UNETR_ERR_ARG;
-    if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, x_f32);
     if (prec == UNETR_PREC_F32) return wgrad_t<PrecF32>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }

@@ -210,8 +210,9 @@ __device__ __forceinline__ void in_block_reduce(f32x4 (&acc)[NS], int cvn, int n
     }
 }
 
+template <class T>
 __global__ void __launch_bounds__(256)
-in_stats_kernel(const float* __restrict__ x, long ld, long V, int C, float* __restrict__ part) {
+in_stats_kernel(const T* __restrict__ x, long ld, long V, int C, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cvn = C >> 2, nphase = 256 / cvn;
     const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
@@ -220,7 +221,7 @@ in_stats_kernel(const float* __restrict__ x, long ld, long V, int C, float* __re
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     if (ph < nphase)
         for (long v = v0 + ph; v < v1; v += nphase) {
-            f32x4 t = *(const f32x4*)(x + ((long)b * V + v) * ld + 4 * cv);
+            f32x4 t = Io<T>::ld4(x + ((long)b * V + v) * ld + 4 * cv);
             acc[0] += t;
             acc[1] += t * t;
         }
@@ -251,19 +252,20 @@ __global__ void in_stats_final_kernel(const float* __restrict__ part, int nchunk
 
 __device__ __forceinline__ float lrelu_f(float v) { return v > 0.f ? v : 0.01f * v; }
 
+template <class T>
 __global__ void __launch_bounds__(256)
-in_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ sa, const float* __restrict__ x2, long ldx2,
-                const float* __restrict__ sb, float* __restrict__ y, long ldy, int B, long V, int C, int lrelu) {
+in_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ sa, const T* __restrict__ x2, long ldx2,
+                const float* __restrict__ sb, T* __restrict__ y, long ldy, int B, long V, int C, int lrelu) {
     const int cvn = C >> 2;
     const long total = (long)B * V * cvn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int cv = (int)(i % cvn); long vox = i / cvn; int b = (int)(vox / V);
-        f32x4 t = *(const f32x4*)(x + vox * ldx + 4 * cv), o;
+        f32x4 t = Io<T>::ld4(x + vox * ldx + 4 * cv), o;
         const float* s = sa + ((long)b * C + 4 * cv) * 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (t[e] - s[2 * e]) * s[2 * e + 1];
         if (x2) {
-            f32x4 t2 = *(const f32x4*)(x2 + vox * ldx2 + 4 * cv);
+            f32x4 t2 = Io<T>::ld4(x2 + vox * ldx2 + 4 * cv);
             const float* s2 = sb + ((long)b * C + 4 * cv) * 2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += (t2[e] - s2[2 * e]) * s2[2 * e + 1];
@@ -272,14 +274,15 @@ in_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = lrelu_f(o[e]);
         }
-        *(f32x4*)(y + vox * ldy + 4 * cv) = o;
+        Io<T>::st4(y + vox * ldy + 4 * cv, o);
     }
 }
 
 // backward stage 1: per (b,c) sums of g, g*n1, g*n2 with g = dy * lrelu'(n1+n2)
+template <class T>
 __global__ void __launch_bounds__(256)
-in_bwd_reduce_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, const float* __restrict__ sa,
-                     const float* __restrict__ x2, long ldx2, const float* __restrict__ sb, long V, int C, int lrelu,
+in_bwd_reduce_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
+                     const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, long V, int C, int lrelu,
                      float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cvn = C >> 2, nphase = 256 / cvn;
@@ -308,9 +311,9 @@ in_bwd_reduce_kernel(const float* __restrict__ dy, long lddy, const float* __res
             for (int u = 0; u < U; ++u) {
                 const long vv = v + (long)u * nphase;
                 const long vox = (long)b * V + (vv < v1 ? vv : v);      // clamped: re-reads voxel v, masked below
-                g[u] = *(const f32x4*)(dy + vox * lddy + 4 * cv);
-                t[u] = *(const f32x4*)(x + vox * ldx + 4 * cv);
-                t2[u] = x2 ? *(const f32x4*)(x2 + vox * ldx2 + 4 * cv) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                g[u] = Io<T>::ld4(dy + vox * lddy + 4 * cv);
+                t[u] = Io<T>::ld4(x + vox * ldx + 4 * cv);
+                t2[u] = x2 ? Io<T>::ld4(x2 + vox * ldx2 + 4 * cv) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -348,24 +351,25 @@ __global__ void in_bwd_final_kernel(const float* __restrict__ part, int nchunk, 
     }
 }
 
+template <class T>
 __global__ void __launch_bounds__(256)
-in_bwd_apply_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, const float* __restrict__ sa,
-                    const float* __restrict__ x2, long ldx2, const float* __restrict__ sb, const float* __restrict__ sums,
-                    float* __restrict__ dx, long lddx, float* __restrict__ dx2, long lddx2, int B, long V, int C, int lrelu) {
+in_bwd_apply_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
+                    const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, const float* __restrict__ sums,
+                    T* __restrict__ dx, long lddx, T* __restrict__ dx2, long lddx2, int B, long V, int C, int lrelu) {
     const int cvn = C >> 2;
     const long total = (long)B * V * cvn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int cv = (int)(i % cvn); long vox = i / cvn; int b = (int)(vox / V);
         const float* s1 = sa + ((long)b * C + 4 * cv) * 2;
         const float* sm = sums + ((long)b * C + 4 * cv) * 3;
-        f32x4 g = *(const f32x4*)(dy + vox * lddy + 4 * cv);
-        f32x4 t = *(const f32x4*)(x + vox * ldx + 4 * cv), n1, n2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 g = Io<T>::ld4(dy + vox * lddy + 4 * cv);
+        f32x4 t = Io<T>::ld4(x + vox * ldx + 4 * cv), n1, n2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) n1[e] = (t[e] - s1[2 * e]) * s1[2 * e + 1];
         const float* s2 = nullptr;
         if (x2) {
             s2 = sb + ((long)b * C + 4 * cv) * 2;
-            f32x4 t2 = *(const f32x4*)(x2 + vox * ldx2 + 4 * cv);
+            f32x4 t2 = Io<T>::ld4(x2 + vox * ldx2 + 4 * cv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) n2[e] = (t2[e] - s2[2 * e]) * s2[2 * e + 1];
         }
@@ -376,36 +380,37 @@ in_bwd_apply_kernel(const float* __restrict__ dy, long lddy, const float* __rest
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = s1[2 * e + 1] * (g[e] - sm[3 * e] - n1[e] * sm[3 * e + 1]);
-        *(f32x4*)(dx + vox * lddx + 4 * cv) = o;
+        Io<T>::st4(dx + vox * lddx + 4 * cv, o);
         if (x2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = s2[2 * e + 1] * (g[e] - sm[3 * e] - n2[e] * sm[3 * e + 2]);
-            *(f32x4*)(dx2 + vox * lddx2 + 4 * cv) = o;
+            Io<T>::st4(dx2 + vox * lddx2 + 4 * cv, o);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------ layout moves
 // per batch: src [R, Ccols] (pitch lds_) -> dst [Ccols, R] (pitch ldd)
+template <class TS, class TD>
 __global__ void __launch_bounds__(256)
-transpose_kernel(const float* __restrict__ src, long ld_s, long bs_s, float* __restrict__ dst, long ld_d, long bs_d,
+transpose_kernel(const TS* __restrict__ src, long ld_s, long bs_s, TD* __restrict__ dst, long ld_d, long bs_d,
                  long R, long Cc, int accumulate) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
-    const float* s = src + (long)blockIdx.z * bs_s;
-    float* d = dst + (long)blockIdx.z * bs_d;
+    const TS* s = src + (long)blockIdx.z * bs_s;
+    TD* d = dst + (long)blockIdx.z * bs_d;
     for (int j = ty; j < 32; j += 8) {
         long r = r0 + j, c = c0 + tx;
-        tile[j][tx] = (r < R && c < Cc) ? s[r * ld_s + c] : 0.f;
+        tile[j][tx] = (r < R && c < Cc) ? Io<TS>::ld1(s + r * ld_s + c) : 0.f;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         long c = c0 + j, r = r0 + tx;
         if (r < R && c < Cc) {
             float v = tile[tx][j];
-            if (accumulate) v += d[c * ld_d + r];
-            d[c * ld_d + r] = v;
+            if (accumulate) v += Io<TD>::ld1(d + c * ld_d + r);
+            Io<TD>::st1(d + c * ld_d + r, v);
         }
     }
 }
@@ -422,22 +427,24 @@ __global__ void patch_gather_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
-__global__ void add_rows_kernel(float* __restrict__ y, long ldy, const float* __restrict__ a, long lda, long rows, int cols, int accumulate) {
+template <class T>
+__global__ void add_rows_kernel(T* __restrict__ y, long ldy, const T* __restrict__ a, long lda, long rows, int cols, int accumulate) {
     const int cvn = cols >> 2;
     const long total = rows * cvn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int cv = (int)(i % cvn); long r = i / cvn;
-        f32x4* yp = (f32x4*)(y + r * ldy + 4 * cv);
-        f32x4 v = *(const f32x4*)(a + r * lda + 4 * cv);
-        if (accumulate) v += *yp;
-        *yp = v;
+        T* yp = y + r * ldy + 4 * cv;
+        f32x4 v = Io<T>::ld4(a + r * lda + 4 * cv);
+        if (accumulate) v += Io<T>::ld4(yp);
+        Io<T>::st4(yp, v);
     }
 }
 
 // ------------------------------------------------------------------------- out conv (1x1x1 + bias)
 constexpr int OC_MAXCO = 16, OC_MAXCI = 64;
+template <class T>
 __global__ void __launch_bounds__(256)
-outconv_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ bias,
+outconv_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ bias,
                    float* __restrict__ logits, int B, long V, int Cin, int Cout) {
     __shared__ float sw[OC_MAXCO * OC_MAXCI + OC_MAXCO];
     for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) sw[i] = w[i];
@@ -450,7 +457,7 @@ outconv_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restric
 #pragma unroll
         for (int co = 0; co < OC_MAXCO; ++co) acc[co] = sw[OC_MAXCO * OC_MAXCI + co];
         for (int c4 = 0; c4 < Cin; c4 += 4) {
-            f32x4 t = *(const f32x4*)(x + vox * ldx + c4);
+            f32x4 t = Io<T>::ld4(x + vox * ldx + c4);
 #pragma unroll
             for (int co = 0; co < OC_MAXCO; ++co)
                 if (co < Cout) {
@@ -468,10 +475,10 @@ outconv_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restric
 // WG (Cout * Cin <= 64: 4 classes x 16 features), the weight gradient dw[co,ci] = sum_vox dl[co,vox] * x[vox,ci] from the
 // SAME pass over dl (the x row is one extra 64-byte read per voxel).  Before, dw took two exact-fp32 GEMMs of shape
 // [4 x 884736] x [884736 x 16] on 16x16 tiles with a deep split-K reduce: 224 us per step for 64 numbers.
-template <bool WG>
+template <bool WG, class T>
 __global__ void __launch_bounds__(256)
-outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, const float* __restrict__ x, long ldx,
-                   float* __restrict__ dx, long lddx, float* __restrict__ part, int B, long V, int Cin, int Cout) {
+outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, const T* __restrict__ x, long ldx,
+                   T* __restrict__ dx, long lddx, float* __restrict__ part, int B, long V, int Cin, int Cout) {
     __shared__ float sw[OC_MAXCO * OC_MAXCI];
     __shared__ float red[4][OC_MAXCO + 64];
     for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) sw[i] = w[i];
@@ -499,14 +506,14 @@ outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, co
                     const float* ww = sw + co * Cin + c4;
                     o[0] += g[co] * ww[0]; o[1] += g[co] * ww[1]; o[2] += g[co] * ww[2]; o[3] += g[co] * ww[3];
                 }
-            *(f32x4*)(dx + vox * lddx + c4) = o;
+            Io<T>::st4(dx + vox * lddx + c4, o);
         }
         if constexpr (WG) {
             // (WG: Cout <= 4, Cin <= 16, Cin % 4 == 0 -- checked by the launcher; slot co*16 + ci)
 #pragma unroll
             for (int c4 = 0; c4 < 16; c4 += 4) {
                 if (c4 < Cin) {
-                    const f32x4 xv = *(const f32x4*)(x + vox * ldx + c4);
+                    const f32x4 xv = Io<T>::ld4(x + vox * ldx + c4);
 #pragma unroll
                     for (int co = 0; co < 4; ++co)
 #pragma unroll
@@ -656,15 +663,15 @@ static int in_check(int C, long ld) {
     return UNETR_OK;
 }
 
-extern "C" int unetr_instnorm_stats(const float* x, long ld, int B, long V, int C, float eps, float* stats,
-                                    float* ws, size_t ws_bytes, void* stream) {
+extern "C" int unetr_instnorm_stats(const void* x, long ld, int B, long V, int C, float eps, float* stats,
+                                    float* ws, size_t ws_bytes, int act16, void* stream) {
     if (!x || !stats || B <= 0 || V <= 0) return UNETR_ERR_ARG;
     if (int e = in_check(C, ld)) return e;
     int nchunk = cdiv(V, IN_VPB);
     if (!ws || (size_t)B * nchunk * 2 * C * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int cvn = C >> 2, nphase = 256 / cvn;
-    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), (size_t)2 * nphase * cvn * 16, st, x, ld, V, C, ws);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_stats_kernel<AT>, dim3(nchunk, B), dim3(256), (size_t)2 * nphase * cvn * 16, st, (const AT*)x, ld, V, C, ws));
     hipLaunchKernelGGL(in_stats_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, eps, stats, B);
     return unetr_check_launch();
 }
@@ -701,18 +708,19 @@ extern "C" int unetr_instnorm_stats_finalize(const float* part, int nchunk, int 
     return unetr_check_launch();
 }
 
-extern "C" int unetr_instnorm_apply(const float* x, long ldx, const float* sa, const float* x2, long ldx2, const float* sb,
-                                    float* y, long ldy, int B, long V, int C, int lrelu, void* stream) {
+extern "C" int unetr_instnorm_apply(const void* x, long ldx, const float* sa, const void* x2, long ldx2, const float* sb,
+                                    void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream) {
     if (!x || !sa || !y || (x2 && !sb)) return UNETR_ERR_ARG;
     if ((C & 3) || (ldx & 3) || (ldy & 3) || (x2 && (ldx2 & 3))) return UNETR_ERR_UNSUPPORTED;
     long total = (long)B * V * (C >> 2);
-    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, sa, x2, ldx2, sb, y, ldy, B, V, C, lrelu);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_apply_kernel<AT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const AT*)x, ldx, sa,
+                                           (const AT*)x2, ldx2, sb, (AT*)y, ldy, B, V, C, lrelu));
     return unetr_check_launch();
 }
 
-extern "C" int unetr_instnorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* sa,
-                                  const float* x2, long ldx2, const float* sb, float* dx, long lddx, float* dx2, long lddx2,
-                                  int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, void* stream) {
+extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const float* sa,
+                                  const void* x2, long ldx2, const float* sb, void* dx, long lddx, void* dx2, long lddx2,
+                                  int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, int act16, void* stream) {
     if (!dy || !x || !sa || !dx || (x2 && (!sb || !dx2))) return UNETR_ERR_ARG;
     if (int e = in_check(C, ldx)) return e;
     if ((lddy & 3) || (lddx & 3) || (x2 && ((ldx2 & 3) || (lddx2 & 3)))) return UNETR_ERR_UNSUPPORTED;
@@ -722,28 +730,28 @@ extern "C" int unetr_instnorm_bwd(const float* dy, long lddy, const float* x, lo
     float* sums = ws + (size_t)B * nchunk * 3 * C;
     hipStream_t st = (hipStream_t)stream;
     int cvn = C >> 2, nphase = 256 / cvn;
-    hipLaunchKernelGGL(in_bwd_reduce_kernel, dim3(nchunk, B), dim3(256), (size_t)3 * nphase * cvn * 16, st, dy, lddy, x, ldx, sa,
-                       x2, ldx2, sb, V, C, lrelu, ws);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_reduce_kernel<AT>, dim3(nchunk, B), dim3(256), (size_t)3 * nphase * cvn * 16, st, (const AT*)dy, lddy,
+                                           (const AT*)x, ldx, sa, (const AT*)x2, ldx2, sb, V, C, lrelu, ws));
     hipLaunchKernelGGL(in_bwd_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, B, sums);
     long total = (long)B * V * (C >> 2);
-    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, dy, lddy, x, ldx, sa, x2, ldx2, sb, sums,
-                       dx, lddx, dx2, lddx2, B, V, C, lrelu);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_apply_kernel<AT>, dim3(grid_for(total)), dim3(256), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
+                                           (const AT*)x2, ldx2, sb, sums, (AT*)dx, lddx, (AT*)dx2, lddx2, B, V, C, lrelu));
     return unetr_check_launch();
 }
 
-extern "C" int unetr_nchw_to_nhwc(const float* x, float* y, long ldy, int B, int C, long V, void* stream) {
+extern "C" int unetr_nchw_to_nhwc(const float* x, void* y, long ldy, int B, int C, long V, int act16, void* stream) {
     if (!x || !y) return UNETR_ERR_ARG;
     // per batch: src [C rows, V cols] -> dst [V, C]
     if (cdiv(C, 32) > 65535 || B > 65535) return UNETR_ERR_ARG;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(V, 32), B), dim3(256), 0, (hipStream_t)stream,
-                       x, V, (long)C * V, y, ldy, V * ldy, (long)C, V, 0);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL((transpose_kernel<float, AT>), dim3(cdiv(C, 32), cdiv(V, 32), B), dim3(256), 0, (hipStream_t)stream,
+                                           x, V, (long)C * V, (AT*)y, ldy, V * ldy, (long)C, V, 0));
     return unetr_check_launch();
 }
-extern "C" int unetr_nhwc_to_nchw(const float* x, long ldx, float* y, int B, int C, long V, int accumulate, void* stream) {
+extern "C" int unetr_nhwc_to_nchw(const void* x, long ldx, float* y, int B, int C, long V, int accumulate, int act16, void* stream) {
     if (!x || !y) return UNETR_ERR_ARG;
     if (cdiv(C, 32) > 65535 || B > 65535) return UNETR_ERR_ARG;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(V, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream,
-                       x, ldx, V * ldx, y, V, (long)C * V, V, (long)C, accumulate);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL((transpose_kernel<AT, float>), dim3(cdiv(V, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream,
+                                           (const AT*)x, ldx, V * ldx, y, V, (long)C * V, V, (long)C, accumulate));
     return unetr_check_launch();
 }
 
@@ -754,34 +762,37 @@ extern "C" int unetr_patch_gather(const float* x, float* patches, int B, int C, 
     return unetr_check_launch();
 }
 
-extern "C" int unetr_copy_rows(float* y, long ldy, const float* a, long lda, long rows, int cols, int accumulate, void* stream) {
+extern "C" int unetr_copy_rows(void* y, long ldy, const void* a, long lda, long rows, int cols, int accumulate, int act16, void* stream) {
     if (!y || !a || (cols & 3) || (ldy & 3) || (lda & 3)) return UNETR_ERR_ARG;
-    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (cols >> 2))), dim3(256), 0, (hipStream_t)stream, y, ldy, a, lda, rows, cols, accumulate);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(add_rows_kernel<AT>, dim3(grid_for(rows * (cols >> 2))), dim3(256), 0, (hipStream_t)stream, (AT*)y, ldy,
+                                           (const AT*)a, lda, rows, cols, accumulate));
     return unetr_check_launch();
 }
 
-extern "C" int unetr_outconv_fwd(const float* x, long ldx, const float* w, const float* bias, float* logits,
-                                 int B, long V, int Cin, int Cout, void* stream) {
+extern "C" int unetr_outconv_fwd(const void* x, long ldx, const float* w, const float* bias, float* logits,
+                                 int B, long V, int Cin, int Cout, int act16, void* stream) {
     if (!x || !w || !logits) return UNETR_ERR_ARG;
     if (Cout > OC_MAXCO || Cin > OC_MAXCI || (Cin & 3) || (ldx & 3)) return UNETR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(outconv_fwd_kernel, dim3(grid_for((long)B * V)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, logits, B, V, Cin, Cout);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(outconv_fwd_kernel<AT>, dim3(grid_for((long)B * V)), dim3(256), 0, (hipStream_t)stream, (const AT*)x, ldx, w, bias,
+                                           logits, B, V, Cin, Cout));
     return unetr_check_launch();
 }
 
-extern "C" int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx, const float* w, float* dx, long lddx,
+extern "C" int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, const float* w, void* dx, long lddx,
                                  float* dw, float* dbias, int B, long V, int Cin, int Cout,
-                                 float* ws, size_t ws_bytes, void* stream) {
+                                 float* ws, size_t ws_bytes, int act16, void* stream) {
     if (!dlogits || !x || !w || !dx || !dw || !dbias) return UNETR_ERR_ARG;
     if (Cout > OC_MAXCO || Cin > OC_MAXCI || (Cin & 3) || (ldx & 3) || (lddx & 3)) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     int nblk = grid_for((long)B * V, 256, 1024);
     const bool wg = Cout <= 4 && Cin <= 16 && ((uintptr_t)x & 15) == 0;      // weight gradient from the same pass
+    if (!wg && act16) return UNETR_ERR_UNSUPPORTED;                          // (the generic GEMM below reads fp32 x)
     const int np = Cout + (wg ? Cout * Cin : 0);
     size_t part_bytes = (size_t)nblk * np * sizeof(float);
     size_t part_al = (part_bytes + 255) & ~(size_t)255;
     if (!ws || part_al + 4096 > ws_bytes) return UNETR_ERR_WORKSPACE;
-    if (wg) hipLaunchKernelGGL(outconv_bwd_kernel<true>, dim3(nblk), dim3(256), 0, st, dlogits, w, x, ldx, dx, lddx, ws, B, V, Cin, Cout);
-    else hipLaunchKernelGGL(outconv_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, dlogits, w, x, ldx, dx, lddx, ws, B, V, Cin, Cout);
+    if (wg) ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_bwd_kernel<true, AT>), dim3(nblk), dim3(256), 0, st, dlogits, w, (const AT*)x, ldx, (AT*)dx, lddx, ws, B, V, Cin, Cout));
+    else ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_bwd_kernel<false, AT>), dim3(nblk), dim3(256), 0, st, dlogits, w, (const AT*)x, ldx, (AT*)dx, lddx, ws, B, V, Cin, Cout));
     if (int e = unetr_check_launch()) return e;
     float* ws2 = (float*)((char*)ws + part_al);
     size_t ws2_bytes = ws_bytes - part_al;
@@ -798,7 +809,7 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx,
         unetr_gemm_desc d{};
         d.M = Cout; d.N = Cin; d.K = (int)V; d.batch = 1; d.a_trans = 0; d.b_trans = 1;
         d.lda = V; d.ldb = ldx; d.ldc = Cin; d.res_mod = Cout; d.alpha = 1.f; d.accumulate = b > 0; d.prec = UNETR_PREC_F32;
-        int e = unetr_gemm(&d, dlogits + (long)b * Cout * V, x + (long)b * V * ldx, dw, ws2, ws2_bytes, stream);
+        int e = unetr_gemm(&d, dlogits + (long)b * Cout * V, (const float*)x + (long)b * V * ldx, dw, ws2, ws2_bytes, stream);
         if (e) return e;
     }
     return UNETR_OK;

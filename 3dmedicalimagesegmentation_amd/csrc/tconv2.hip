@@ -44,8 +44,8 @@ __device__ __forceinline__ int out_base(int m, int D, int H, int W) {
 // over voxel tiles g, g+G, ...   RT = Cin/16 row tiles, CTW = column tiles per wave (NC = 64*CTW).
 template <class P, int RT, int CTW>
 __global__ void __launch_bounds__(256)
-tconv2_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
-                    int M, int D, int H, int W, int Cin, int Cout, int ntiles) {
+tconv2_wgrad_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const typename Elem<P>::type* __restrict__ dy, long lddy,
+                    float* __restrict__ part, int M, int D, int H, int W, int Cin, int Cout, int ntiles) {
     typedef typename Elem<P>::type T;
     constexpr int ES = sizeof(T), CH = P::CH, NC = 64 * CTW;
     constexpr int PXI = RT * 16 * ES + 16, PYI = NC * ES + 16;          // image pitches (bytes), padded
@@ -80,14 +80,7 @@ tconv2_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restri
                 if (id < TV * QX) {
                     const int v = id / QX, q = id - v * QX;
                     const bool ok = m0 + v < M;
-                    const float* src = x + (long)(ok ? m0 + v : 0) * ldx + q * CH;
-                    float vals[CH];
-#pragma unroll
-                    for (int e = 0; e < CH / 4; ++e) {
-                        const f32x4 t = *(const f32x4*)(src + 4 * e);
-                        vals[4 * e] = ok ? t[0] : 0.f; vals[4 * e + 1] = ok ? t[1] : 0.f; vals[4 * e + 2] = ok ? t[2] : 0.f; vals[4 * e + 3] = ok ? t[3] : 0.f;
-                    }
-                    *(u32x4*)(ximg + v * PXI + q * 16) = P::pack(vals);
+                    *(u32x4*)(ximg + v * PXI + q * 16) = act_chunk<P>(x + (long)(ok ? m0 + v : 0) * ldx + q * CH, ok);
                 }
             }
         }
@@ -96,7 +89,7 @@ tconv2_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restri
         {
             constexpr int QY = NC / CH;
             constexpr int IT = TV * QY / 256;
-            float buf[IT][CH];
+            u32x4 buf[IT];
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
                 const int id = threadIdx.x + j * 256;
@@ -105,18 +98,13 @@ tconv2_wgrad_kernel(const float* __restrict__ x, long ldx, const float* __restri
                 const int ob = tab[v];
                 const bool ok = ob >= 0 && tap < 8;
                 const int ov = ob + ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
-                const float* src = dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0);
-#pragma unroll
-                for (int e = 0; e < CH / 4; ++e) {
-                    const f32x4 t = *(const f32x4*)(src + 4 * e);
-                    buf[j][4 * e] = ok ? t[0] : 0.f; buf[j][4 * e + 1] = ok ? t[1] : 0.f; buf[j][4 * e + 2] = ok ? t[2] : 0.f; buf[j][4 * e + 3] = ok ? t[3] : 0.f;
-                }
+                buf[j] = act_chunk<P>(dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0), ok);
             }
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
                 const int id = threadIdx.x + j * 256;
                 const int v = id / QY, q = id - v * QY;
-                *(u32x4*)(yimg + v * PYI + q * 16) = P::pack(buf[j]);
+                *(u32x4*)(yimg + v * PYI + q * 16) = buf[j];
             }
         }
         __syncthreads();
@@ -225,8 +213,9 @@ __global__ void tconv2_pack_kernel(const float* __restrict__ w, T* __restrict__ 
 // KB = k-blocks of 4 chunks (64 bytes) per row; NT = 16-column tiles (= 8*Cout/16).  Each wave: 16 voxels x all columns.
 template <class P, int KB, int NT>
 __global__ void __launch_bounds__(256)
-tconv2_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict__ wr, float* __restrict__ y, long ldy,
+tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const char* __restrict__ wr, typename Elem<P>::type* __restrict__ y, long ldy,
                   int M, int D, int H, int W, int Cin, int Cout, int ntiles) {
+    typedef typename Elem<P>::type T;
     constexpr int CH = P::CH, RB = KB * 64;              // bytes per operand row
     constexpr int PA = RB + 16;                          // padded pitches
     __shared__ __attribute__((aligned(16))) char lds[NT * 16 * PA + TV * PA + TV * 4];
@@ -256,14 +245,7 @@ tconv2_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict_
                 if (id < TV * QX) {
                     const int v = id / QX, q = id - v * QX;
                     const bool ok = m0 + v < M && q * CH < Cin;
-                    const float* src = x + (long)(ok ? m0 + v : 0) * ldx + (ok ? q * CH : 0);
-                    float vals[CH];
-#pragma unroll
-                    for (int e = 0; e < CH / 4; ++e) {
-                        const f32x4 t = *(const f32x4*)(src + 4 * e);
-                        vals[4 * e] = ok ? t[0] : 0.f; vals[4 * e + 1] = ok ? t[1] : 0.f; vals[4 * e + 2] = ok ? t[2] : 0.f; vals[4 * e + 3] = ok ? t[3] : 0.f;
-                    }
-                    *(u32x4*)(ximg + v * PA + q * 16) = P::pack(vals);
+                    *(u32x4*)(ximg + v * PA + q * 16) = act_chunk<P>(x + (long)(ok ? m0 + v : 0) * ldx + (ok ? q * CH : 0), ok);
                 }
             }
         }
@@ -290,7 +272,7 @@ tconv2_fwd_kernel(const float* __restrict__ x, long ldx, const char* __restrict_
             const int toff = ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
-                if (ob[rr] >= 0) y[(long)(ob[rr] + toff) * ldy + co] = acc[j][rr];
+                if (ob[rr] >= 0) Io<T>::st1(y + (long)(ob[rr] + toff) * ldy + co, acc[j][rr]);
         }
     }
 }
@@ -310,7 +292,7 @@ __global__ void tconv2_pack_d_kernel(const float* __restrict__ w, T* __restrict_
 
 template <class P, int NT>
 __global__ void __launch_bounds__(256)
-tconv2_dgrad_kernel(const float* __restrict__ dy, long lddy, const char* __restrict__ wd, float* __restrict__ dx, long ldx,
+tconv2_dgrad_kernel(const typename Elem<P>::type* __restrict__ dy, long lddy, const char* __restrict__ wd, typename Elem<P>::type* __restrict__ dx, long ldx,
                     int M, int D, int H, int W, int Cin, int Cout, int ntiles) {
     typedef typename Elem<P>::type T;
     constexpr int ES = sizeof(T), CH = P::CH;
@@ -334,7 +316,7 @@ tconv2_dgrad_kernel(const float* __restrict__ dy, long lddy, const char* __restr
         }
         __syncthreads();
         for (int id0 = 0; id0 < TV * QY; id0 += 1024) {          // 4 pieces per thread in flight
-            float buf[4][CH];
+            u32x4 buf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int id = id0 + threadIdx.x + j * 256;
@@ -343,19 +325,14 @@ tconv2_dgrad_kernel(const float* __restrict__ dy, long lddy, const char* __restr
                 const int ob = tab[v];
                 const bool ok = id < TV * QY && ob >= 0;
                 const int ov = ob + ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
-                const float* src = dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0);
-#pragma unroll
-                for (int e = 0; e < CH / 4; ++e) {
-                    const f32x4 t = *(const f32x4*)(src + 4 * e);
-                    buf[j][4 * e] = ok ? t[0] : 0.f; buf[j][4 * e + 1] = ok ? t[1] : 0.f; buf[j][4 * e + 2] = ok ? t[2] : 0.f; buf[j][4 * e + 3] = ok ? t[3] : 0.f;
-                }
+                buf[j] = act_chunk<P>(dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0), ok);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int id = id0 + threadIdx.x + j * 256;
                 if (id < TV * QY) {
                     const int v = id / QY, q = id - v * QY;
-                    *(u32x4*)(yimg + v * PA + q * 16) = P::pack(buf[j]);
+                    *(u32x4*)(yimg + v * PA + q * 16) = buf[j];
                 }
             }
         }
@@ -377,7 +354,7 @@ tconv2_dgrad_kernel(const float* __restrict__ dy, long lddy, const char* __restr
             if (m < M) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    if (j * 16 + r < Cin) dx[(long)m * ldx + j * 16 + r] = acc[j][rr];
+                    if (j * 16 + r < Cin) Io<T>::st1(dx + (long)m * ldx + j * 16 + r, acc[j][rr]);
             }
         }
     }
@@ -389,13 +366,13 @@ inline bool tconv2_enabled() {
 }
 
 template <class P, int RT, int CTW>
-void launch_wgrad(int G, int NG, const float* x, long ldx, const float* dy, long lddy, float* ws, int M, int D, int H, int W,
+void launch_wgrad(int G, int NG, const typename Elem<P>::type* x, long ldx, const typename Elem<P>::type* dy, long lddy, float* ws, int M, int D, int H, int W,
                   int Cin, int Cout, int ntiles, hipStream_t st) {
     hipLaunchKernelGGL((tconv2_wgrad_kernel<P, RT, CTW>), dim3(G, NG), dim3(256), 0, st, x, ldx, dy, lddy, ws, M, D, H, W, Cin, Cout, ntiles);
 }
 
 template <class P>
-int wgrad2(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int D, int H, int W, int Cin, int Cout,
+int wgrad2(const typename Elem<P>::type* x, long ldx, const typename Elem<P>::type* dy, long lddy, float* dw, int B, int D, int H, int W, int Cin, int Cout,
            float* ws, size_t ws_bytes, hipStream_t st) {
     const long Ml = (long)B * D * H * W;
     const int M = (int)Ml, ntiles = cdiv(M, TV), N = 8 * Cout, RT = Cin / 16;
@@ -414,13 +391,13 @@ int wgrad2(const float* x, long ldx, const float* dy, long lddy, float* dw, int 
 }
 
 template <class P, int KB, int NT>
-void launch_fwd(int G, const float* x, long ldx, const char* wr, float* y, long ldy, int M, int D, int H, int W, int Cin, int Cout,
+void launch_fwd(int G, const typename Elem<P>::type* x, long ldx, const char* wr, typename Elem<P>::type* y, long ldy, int M, int D, int H, int W, int Cin, int Cout,
                 int ntiles, hipStream_t st) {
     hipLaunchKernelGGL((tconv2_fwd_kernel<P, KB, NT>), dim3(G), dim3(256), 0, st, x, ldx, wr, y, ldy, M, D, H, W, Cin, Cout, ntiles);
 }
 
 template <class P>
-int fwd2(const float* x, long ldx, const float* w, float* y, long ldy, int B, int D, int H, int W, int Cin, int Cout,
+int fwd2(const typename Elem<P>::type* x, long ldx, const float* w, typename Elem<P>::type* y, long ldy, int B, int D, int H, int W, int Cin, int Cout,
          float* ws, size_t ws_bytes, hipStream_t st) {
     typedef typename Elem<P>::type T;
     const int M = (int)((long)B * D * H * W), ntiles = cdiv(M, TV), N = 8 * Cout, NT = N / 16;
@@ -437,7 +414,7 @@ int fwd2(const float* x, long ldx, const float* w, float* y, long ldy, int B, in
 }
 
 template <class P>
-int dgrad2(const float* dy, long lddy, const float* w, float* dx, long ldx, int B, int D, int H, int W, int Cin, int Cout,
+int dgrad2(const typename Elem<P>::type* dy, long lddy, const float* w, typename Elem<P>::type* dx, long ldx, int B, int D, int H, int W, int Cin, int Cout,
            float* ws, size_t ws_bytes, hipStream_t st) {
     typedef typename Elem<P>::type T;
     const int M = (int)((long)B * D * H * W), ntiles = cdiv(M, TV), K = 8 * Cout, NT = cdiv(Cin, 16);
@@ -471,34 +448,43 @@ extern "C" int unetr_tconv2_fwd_supported(long M, int Cin, int Cout, long ldx, l
            ldx % 4 == 0 && ldy % 4 == 0;
 }
 
-extern "C" int unetr_tconv2_wgrad(const float* x, long ldx, const float* dy, long lddy, float* dw, int B, int D, int H, int W,
+extern "C" int unetr_tconv2_wgrad(const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int D, int H, int W,
                                   int Cin, int Cout, int prec, float* ws, size_t ws_bytes, void* stream) {
     if (!x || !dy || !dw) return UNETR_ERR_ARG;
     if (!unetr_tconv2_wgrad_supported((long)B * D * H * W, Cin, Cout, ldx, lddy) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15))
         return UNETR_ERR_UNSUPPORTED;
-    if (prec == UNETR_PREC_BF16) return wgrad2<PrecBF16>(x, ldx, dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
-    if (prec == UNETR_PREC_F32) return wgrad2<PrecF32>(x, ldx, dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16) {
+        if ((ldx & 7) || (lddy & 7)) return UNETR_ERR_UNSUPPORTED;       // bf16 rows: 16-byte chunks
+        return wgrad2<PrecBF16>((const uint16_t*)x, ldx, (const uint16_t*)dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    }
+    if (prec == UNETR_PREC_F32) return wgrad2<PrecF32>((const float*)x, ldx, (const float*)dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 
-extern "C" int unetr_tconv2_fwd(const float* x, long ldx, const float* w, float* y, long ldy, int B, int D, int H, int W,
+extern "C" int unetr_tconv2_fwd(const void* x, long ldx, const float* w, void* y, long ldy, int B, int D, int H, int W,
                                 int Cin, int Cout, int prec, float* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !y) return UNETR_ERR_ARG;
     if (!unetr_tconv2_fwd_supported((long)B * D * H * W, Cin, Cout, ldx, ldy) || ((uintptr_t)x & 15)) return UNETR_ERR_UNSUPPORTED;
-    if (prec == UNETR_PREC_BF16) return fwd2<PrecBF16>(x, ldx, w, y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
-    if (prec == UNETR_PREC_F32) return fwd2<PrecF32>(x, ldx, w, y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16) {
+        if (ldx & 7) return UNETR_ERR_UNSUPPORTED;
+        return fwd2<PrecBF16>((const uint16_t*)x, ldx, w, (uint16_t*)y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    }
+    if (prec == UNETR_PREC_F32) return fwd2<PrecF32>((const float*)x, ldx, w, (float*)y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 
-extern "C" int unetr_tconv2_dgrad(const float* dy, long lddy, const float* w, float* dx, long ldx, int accumulate,
+extern "C" int unetr_tconv2_dgrad(const void* dy, long lddy, const float* w, void* dx, long ldx, int accumulate,
                                   int B, int D, int H, int W, int Cin, int Cout, int prec, float* ws, size_t ws_bytes, void* stream) {
     if (!dy || !w || !dx) return UNETR_ERR_ARG;
     const long M = (long)B * D * H * W;
     if (accumulate || !tconv2_enabled() || M < 2048 || M >= (1L << 27) || Cin < 8 || Cin > 64 || Cout % 8 || Cout < 8 || Cout > 32 ||
         (lddy & 3) || ((uintptr_t)dy & 15))
         return UNETR_ERR_UNSUPPORTED;
-    if (prec == UNETR_PREC_BF16) return dgrad2<PrecBF16>(dy, lddy, w, dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
-    if (prec == UNETR_PREC_F32) return dgrad2<PrecF32>(dy, lddy, w, dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16) {
+        if (lddy & 7) return UNETR_ERR_UNSUPPORTED;
+        return dgrad2<PrecBF16>((const uint16_t*)dy, lddy, w, (uint16_t*)dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    }
+    if (prec == UNETR_PREC_F32) return dgrad2<PrecF32>((const float*)dy, lddy, w, (float*)dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 
@@ -514,47 +500,49 @@ __device__ __forceinline__ long tc_outvox(int m, int tap, int D, int H, int W) {
     return (((long)b * 2 * D + 2 * z + (tap >> 2)) * 2 * H + 2 * y + ((tap >> 1) & 1)) * 2 * W + 2 * x + (tap & 1);
 }
 // thread (m, co): reads the 8 taps of one output channel (32 contiguous bytes), writes one float into each of the 8 output rows
+template <class T>
 __global__ void __launch_bounds__(256)
-pixel_shuffle2_kernel(const float* __restrict__ t, float* __restrict__ y, long ldy, long M, int D, int H, int W, int Cout) {
+pixel_shuffle2_kernel(const float* __restrict__ t, T* __restrict__ y, long ldy, long M, int D, int H, int W, int Cout) {
     const long total = M * Cout;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int m = (int)(i / Cout), co = (int)(i - (long)m * Cout);
         const f32x4 a = *(const f32x4*)(t + i * 8), b = *(const f32x4*)(t + i * 8 + 4);
         const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
-        for (int tap = 0; tap < 8; ++tap) y[tc_outvox(m, tap, D, H, W) * ldy + co] = v[tap];
+        for (int tap = 0; tap < 8; ++tap) Io<T>::st1(y + tc_outvox(m, tap, D, H, W) * ldy + co, v[tap]);
     }
 }
 // thread (m, co): gathers dy at the 8 output voxels of input voxel m, writes 8 bf16 (16 bytes) of dyg[m, co*8 .. co*8+7]
+template <class T>
 __global__ void __launch_bounds__(256)
-pixel_unshuffle2_bf16_kernel(const float* __restrict__ dy, long lddy, uint16_t* __restrict__ g, long M, int D, int H, int W, int Cout) {
+pixel_unshuffle2_bf16_kernel(const T* __restrict__ dy, long lddy, uint16_t* __restrict__ g, long M, int D, int H, int W, int Cout) {
     const long total = M * Cout;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int m = (int)(i / Cout), co = (int)(i - (long)m * Cout);
         float v[8];
 #pragma unroll
-        for (int tap = 0; tap < 8; ++tap) v[tap] = dy[tc_outvox(m, tap, D, H, W) * lddy + co];
+        for (int tap = 0; tap < 8; ++tap) v[tap] = Io<T>::ld1(dy + tc_outvox(m, tap, D, H, W) * lddy + co);
         *(u32x4*)(g + i * 8) = PrecBF16::pack(v);
     }
 }
 }  // namespace
 
-extern "C" int unetr_pixel_shuffle2(const float* t, float* y, long ldy, int B, int D, int H, int W, int Cout, void* stream) {
+extern "C" int unetr_pixel_shuffle2(const float* t, void* y, long ldy, int B, int D, int H, int W, int Cout, int act16, void* stream) {
     if (!t || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || ldy < Cout) return UNETR_ERR_ARG;
     if ((uintptr_t)t & 15) return UNETR_ERR_UNSUPPORTED;
     const long M = (long)B * D * H * W;
     if (M >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3((unsigned)std::min<long>(cdiv(M * Cout, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
-                       t, y, ldy, M, D, H, W, Cout);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(pixel_shuffle2_kernel<AT>, dim3((unsigned)std::min<long>(cdiv(M * Cout, 256), 4096)), dim3(256), 0,
+                                           (hipStream_t)stream, t, (AT*)y, ldy, M, D, H, W, Cout));
     return unetr_check_launch();
 }
 
-extern "C" int unetr_pixel_unshuffle2_bf16(const float* dy, long lddy, void* g, int B, int D, int H, int W, int Cout, void* stream) {
+extern "C" int unetr_pixel_unshuffle2_bf16(const void* dy, long lddy, void* g, int B, int D, int H, int W, int Cout, int act16, void* stream) {
     if (!dy || !g || B <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || lddy < Cout) return UNETR_ERR_ARG;
     if ((uintptr_t)g & 15) return UNETR_ERR_UNSUPPORTED;
     const long M = (long)B * D * H * W;
     if (M >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pixel_unshuffle2_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(M * Cout, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
-                       dy, lddy, (uint16_t*)g, M, D, H, W, Cout);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(pixel_unshuffle2_bf16_kernel<AT>, dim3((unsigned)std::min<long>(cdiv(M * Cout, 256), 4096)), dim3(256), 0,
+                                           (hipStream_t)stream, (const AT*)dy, lddy, (uint16_t*)g, M, D, H, W, Cout));
     return unetr_check_launch();
 }

@@ -200,11 +200,31 @@ def flush_deferred(st=None):
             cb(p)
 
 
-def _require_gpu(t):
+def act_dtype(prec):
+    """storage type of the conv side's feature maps and their gradients: bf16 in bf16 precision mode (half the HBM bytes of
+    the bandwidth-bound InstanceNorm / conv passes), fp32 in fp32 mode.  The C ABI infers it from `prec` (csrc/common.hpp)."""
+    return torch.bfloat16 if prec == _capi.PREC_BF16 else torch.float32
+
+
+def _a16(t):
+    return int(t.dtype == torch.bfloat16)
+
+
+def _prec_of(t):
+    return _capi.PREC_BF16 if t.dtype == torch.bfloat16 else _capi.PREC_F32
+
+
+def _as_act(t, prec):
+    """tensor in the activation storage type of `prec` (a torch cast: only on the rare generic-fallback boundaries)"""
+    dt = act_dtype(prec)
+    return t if t.dtype == dt else t.to(dt)
+
+
+def _require_gpu(t, act=False):
     if not t.is_cuda:
         raise RuntimeError("3dmedicalimagesegmentation_amd: the HIP backend needs tensors on a ROCm device "
                            "(got a CPU tensor); there is no CPU fallback.")
-    if t.dtype != torch.float32:
+    if t.dtype != torch.float32 and not (act and t.dtype == torch.bfloat16):
         raise RuntimeError(f"3dmedicalimagesegmentation_amd: fp32 storage expected, got {t.dtype}")
     if t.device.index != torch.cuda.current_device():
         # kernels are launched on the CURRENT device's stream with raw pointers: a tensor of another GPU would fault
@@ -218,7 +238,8 @@ def _rows(t):
     c = t.shape[-1]
     if t.stride(-1) == 1 and t.dim() >= 2:
         ld = t.stride(-2)
-        ok = ld >= c and (ld % 4 == 0 or ld == c) and t.data_ptr() % 16 == 0
+        al = 16 // t.element_size()            # elements per 16 bytes
+        ok = ld >= c and (ld % al == 0 or (ld == c and t.dtype == torch.float32)) and t.data_ptr() % 16 == 0
         exp = ld
         for d in range(t.dim() - 2, -1, -1):
             if t.shape[d] != 1 and t.stride(d) != exp:
@@ -447,6 +468,8 @@ def _bf16_path(prec, *kdims):
 
 def _twin(t):
     """bf16 copy of an fp32 activation / gradient: the twin its producer attached, else a cast"""
+    if t.dtype == torch.bfloat16:
+        return t
     tw = getattr(t, "_unetr_bf16", None)
     if tw is not None and tw[0].shape == t.shape and tw[1] == t._version:   # autograd may accumulate into t in place
         return tw[0]
@@ -589,7 +612,7 @@ def conv3(x, ldx, w, dims, prec, mode=0, out=None, ldo=None, accumulate=False):
         return conv_fwd(x, ldx, conv_pack(w, mode), dims, cin, cout, 3, prec, out=out, ldo=ldo, accumulate=accumulate)
     wp = conv_pack_get(w, mode, prec)
     if out is None:
-        out = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, D, H, W, cout, dtype=act_dtype(prec), device=x.device)
         ldo = cout
     call("unetr_conv3_fwd", x.data_ptr(), ldx, wp.data_ptr(), out.data_ptr(), ldo, int(accumulate), B, D, H, W, cin, cout, prec, _stream())
     return out
@@ -606,16 +629,18 @@ def conv3_fused(x, ldx, w, w3, dims, prec):
         return None
     dev = x.device
     wp = conv_pack_get(w, 0, prec)
-    c = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=dev)
+    adt = act_dtype(prec)
+    x_f32 = int(prec == _capi.PREC_BF16 and x.dtype == torch.float32)      # the image in front of encoder1
+    c = torch.empty(B, D, H, W, cout, dtype=adt, device=dev)
     st = torch.empty(B, cout, 2, dtype=torch.float32, device=dev)
     wp3 = c3 = st3 = None
     if w3 is not None:
         wp3 = conv_pack_get(w3, 2, prec)
-        c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=dev)
+        c3 = torch.empty(B, D, H, W, cout, dtype=adt, device=dev)
         st3 = torch.empty(B, cout, 2, dtype=torch.float32, device=dev)
     ws = workspace(dev)
     rc = call_rc("unetr_conv3_fwd_fused", x.data_ptr(), ldx, wp.data_ptr(), c.data_ptr(), cout, st.data_ptr(), _p(wp3), _p(c3), cout,
-                 _p(st3), IN_EPS, B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
+                 _p(st3), IN_EPS, B, D, H, W, cin, cout, prec, x_f32, ws.data_ptr(), ws.numel() * 4, _stream())
     if rc != 0:
         return None
     return c, st, c3, st3
@@ -640,15 +665,17 @@ def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out
     """dw of the 3x3x3 conv; with dy3/out3 also the weight gradient of the 1x1x1 conv sharing the input x."""
     if _use_gemm_conv():
         if dy3 is not None:
-            gemm(dy3, x, out3, cout, cin, dims[0] * dims[1] * dims[2] * dims[3], lda=cout, ldb=ldx, ldc=cin, prec=_capi.PREC_F32,
-                 a_trans=True, b_trans=True)
+            x32 = x if x.dtype == torch.float32 else x.float().contiguous()
+            gemm(dy3.float() if dy3.dtype != torch.float32 else dy3, x32, out3, cout, cin, dims[0] * dims[1] * dims[2] * dims[3], lda=cout,
+                 ldb=x32.stride(-2), ldc=cin, prec=_capi.PREC_F32, a_trans=True, b_trans=True)
         return conv_wgrad(x, ldx, dy, lddy, dims, cin, cout, 3, prec, out=out)
     B, D, H, W = dims
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, 3, dtype=torch.float32, device=x.device)
     ws = workspace(x.device)
+    x_f32 = int(prec == _capi.PREC_BF16 and x.dtype == torch.float32)
     call("unetr_conv3_wgrad", x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(),
          dy3.data_ptr() if dy3 is not None else None, cout, out3.data_ptr() if out3 is not None else None,
-         B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
+         B, D, H, W, cin, cout, prec, x_f32, ws.data_ptr(), ws.numel() * 4, _stream())
     return dw
 
 
@@ -663,6 +690,20 @@ def conv_pack(w, mode):
 def conv_fwd(x, ldx, wpack, dims, cin, cout, ks, prec, out=None, ldo=None, accumulate=False):
     """x: rows [B*D*H*W, cin] pitch ldx -> y rows [.., cout]"""
     B, D, H, W = dims
+    if prec == _capi.PREC_BF16:
+        # generic im2col-loader GEMM family: fp32 storage only -- cast at the boundary (shapes the dedicated kernels decline)
+        x32 = x.float().contiguous() if x.dtype != torch.float32 else x
+        l32 = x32.stride(-2) if x32.dim() >= 2 else ldx
+        o32 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
+        if accumulate and out is not None:
+            o32.copy_(out)
+        ws = workspace(x.device)
+        call("unetr_conv_gemm_fwd", x32.data_ptr(), l32, wpack.data_ptr(), o32.data_ptr(), cout, int(accumulate), B, D, H, W, cin, cout, ks,
+             prec, ws.data_ptr(), ws.numel() * 4, _stream())
+        if out is None:
+            return o32.to(act_dtype(prec))
+        out.copy_(o32)
+        return out
     if out is None:
         out = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
         ldo = cout
@@ -676,6 +717,10 @@ def conv_wgrad(x, ldx, dy, lddy, dims, cin, cout, ks, prec, out=None):
     B, D, H, W = dims
     dw = out if out is not None else torch.empty(cout, cin, ks, ks, ks, dtype=torch.float32, device=x.device)
     ws = workspace(x.device)
+    if x.dtype != torch.float32:
+        x = x.float().contiguous(); ldx = x.stride(-2)
+    if dy.dtype != torch.float32:
+        dy = dy.float().contiguous(); lddy = dy.stride(-2)
     call("unetr_conv_gemm_wgrad", x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), B, D, H, W, cin, cout, ks, prec,
          ws.data_ptr(), ws.numel() * 4, _stream())
     return dw
@@ -684,24 +729,26 @@ def conv_wgrad(x, ldx, dy, lddy, dims, cin, cout, ks, prec, out=None):
 def instnorm_stats(x, ld, B, V, C):
     stats = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
     ws = workspace(x.device)
-    call("unetr_instnorm_stats", x.data_ptr(), ld, B, V, C, IN_EPS, stats.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
+    call("unetr_instnorm_stats", x.data_ptr(), ld, B, V, C, IN_EPS, stats.data_ptr(), ws.data_ptr(), ws.numel() * 4, _a16(x), _stream())
     return stats
 
 
 def instnorm_apply(x, sa, B, V, C, lrelu, x2=None, sb=None):
     y = torch.empty_like(x)
     call("unetr_instnorm_apply", x.data_ptr(), C, sa.data_ptr(), x2.data_ptr() if x2 is not None else None, C,
-         sb.data_ptr() if sb is not None else None, y.data_ptr(), C, B, V, C, int(lrelu), _stream())
+         sb.data_ptr() if sb is not None else None, y.data_ptr(), C, B, V, C, int(lrelu), _a16(x), _stream())
     return y
 
 
 def instnorm_bwd(dy, lddy, x, sa, B, V, C, lrelu, x2=None, sb=None):
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype).contiguous(); lddy = dy.stride(-2)
     dx = torch.empty_like(x)
     dx2 = torch.empty_like(x2) if x2 is not None else None
     ws = workspace(x.device)
     call("unetr_instnorm_bwd", dy.data_ptr(), lddy, x.data_ptr(), C, sa.data_ptr(), x2.data_ptr() if x2 is not None else None, C,
          sb.data_ptr() if sb is not None else None, dx.data_ptr(), C, dx2.data_ptr() if dx2 is not None else None, C,
-         B, V, C, int(lrelu), ws.data_ptr(), ws.numel() * 4, _stream())
+         B, V, C, int(lrelu), ws.data_ptr(), ws.numel() * 4, _a16(x), _stream())
     return dx, dx2
 
 
@@ -714,20 +761,30 @@ def _tconv_as_gemm(prec, M, cin, cout, ld_in):
 
 def tconv_fwd(x, ldx, w, dims, cin, cout, prec, out=None, ldo=None):
     B, D, H, W = dims
+    adt = act_dtype(prec)
     if out is None:
-        out = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, dtype=adt, device=x.device)
         ldo = cout
     M = B * D * H * W
     if _tconv_as_gemm(prec, M, cin, cout, ldx):
-        xb = _twin(x).view(M, cin)
+        xb = _twin(x).view(M, cin)             # (a bf16 feature map is its own operand; tokens bring their bf16 twin)
         tmp = torch.empty(M, 8 * cout, dtype=torch.float32, device=x.device)
         gemm_bf16(xb, weight_bf16(w).view(cin, 8 * cout), M, 8 * cout, cin, b_kn=True, C=tmp)
-        call("unetr_pixel_shuffle2", tmp.data_ptr(), out.data_ptr(), ldo, B, D, H, W, cout, _stream())
+        call("unetr_pixel_shuffle2", tmp.data_ptr(), out.data_ptr(), ldo, B, D, H, W, cout, _a16(out), _stream())
         return out, xb
     ws = workspace(x.device)
+    if prec == _capi.PREC_BF16 and x.dtype != adt:
+        x = x.to(adt).contiguous(); ldx = cin      # (fp32 tokens in front of a shape the GEMM form does not take)
     args = (x.data_ptr(), ldx, w.data_ptr(), out.data_ptr(), ldo, B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
-    if call_rc("unetr_tconv2_fwd", *args) != 0:       # dedicated kernel declines the shape -> generic GEMM family
-        call("unetr_tconv_fwd", *args)
+    if call_rc("unetr_tconv2_fwd", *args) != 0:       # dedicated kernel declines the shape -> generic GEMM family (fp32 storage)
+        if prec == _capi.PREC_BF16:
+            x32 = x.float().contiguous()
+            o32 = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, dtype=torch.float32, device=x.device)
+            call("unetr_tconv_fwd", x32.data_ptr(), cin, w.data_ptr(), o32.data_ptr(), cout, B, D, H, W, cin, cout, prec,
+                 ws.data_ptr(), ws.numel() * 4, _stream())
+            out[..., :cout].copy_(o32) if out.shape[-1] != cout else out.copy_(o32)
+        else:
+            call("unetr_tconv_fwd", *args)
     return out, None
 
 
@@ -737,16 +794,24 @@ def tconv_bwd(x, ldx, xb, dy, lddy, w, dims, cin, cout, prec, need_dx):
     M = B * D * H * W
     if xb is not None:
         dyg = torch.empty(M, 8 * cout, dtype=torch.bfloat16, device=dy.device)
-        call("unetr_pixel_unshuffle2_bf16", dy.data_ptr(), lddy, dyg.data_ptr(), B, D, H, W, cout, _stream())
+        call("unetr_pixel_unshuffle2_bf16", dy.data_ptr(), lddy, dyg.data_ptr(), B, D, H, W, cout, _a16(dy), _stream())
         dx = None
         if need_dx:
-            dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=dy.device)
-            gemm_bf16(dyg, weight_bf16(w).view(cin, 8 * cout), M, cin, 8 * cout, C=dx.view(M, cin))
+            dx = torch.empty(B, D, H, W, cin, dtype=x.dtype, device=dy.device)        # fp32 for tokens, bf16 for feature maps
+            wb = weight_bf16(w).view(cin, 8 * cout)
+            if dx.dtype == torch.bfloat16:
+                gemm_bf16(dyg, wb, M, cin, 8 * cout, Cb=dx.view(M, cin))
+            else:
+                gemm_bf16(dyg, wb, M, cin, 8 * cout, C=dx.view(M, cin))
         # dw[Cin, Cout*8] = x^T dyg is torch's [Cin, Cout, 2, 2, 2] as it stands: joins the grouped end-of-backward launch
         dw = wgrad_or_defer(None, None, prec, w, xb, dyg)
         if dw is not None:
             dw = dw.view_as(w)
         return dx, dw
+    if prec == _capi.PREC_BF16 and x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16).contiguous(); ldx = cin
+    if prec == _capi.PREC_BF16 and dy.dtype != torch.bfloat16:
+        dy = dy.to(torch.bfloat16).contiguous(); lddy = cout
     dx = tconv_dgrad(dy, lddy, w, dims, cin, cout, prec) if need_dx else None
     dw = tconv_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=_gout(w))
     return dx, _ret(w, dw)
@@ -754,11 +819,18 @@ def tconv_bwd(x, ldx, xb, dy, lddy, w, dims, cin, cout, prec, need_dx):
 
 def tconv_dgrad(dy, lddy, w, dims, cin, cout, prec):
     B, D, H, W = dims
-    dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(B, D, H, W, cin, dtype=act_dtype(prec), device=dy.device)
     ws = workspace(dy.device)
     args = (dy.data_ptr(), lddy, w.data_ptr(), dx.data_ptr(), cin, 0, B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
     if call_rc("unetr_tconv2_dgrad", *args) != 0:
-        call("unetr_tconv_dgrad", *args)
+        if prec == _capi.PREC_BF16:                   # generic GEMM family: fp32 storage
+            d32 = dy.float().contiguous() if lddy == cout else dy[..., :cout].float().contiguous()
+            x32 = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=dy.device)
+            call("unetr_tconv_dgrad", d32.data_ptr(), cout, w.data_ptr(), x32.data_ptr(), cin, 0, B, D, H, W, cin, cout, prec,
+                 ws.data_ptr(), ws.numel() * 4, _stream())
+            dx.copy_(x32)
+        else:
+            call("unetr_tconv_dgrad", *args)
     return dx
 
 
@@ -768,7 +840,13 @@ def tconv_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None):
     ws = workspace(x.device)
     args = (x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), B, D, H, W, cin, cout, prec, ws.data_ptr(), ws.numel() * 4, _stream())
     if call_rc("unetr_tconv2_wgrad", *args) != 0:
-        call("unetr_tconv_wgrad", *args)
+        if prec == _capi.PREC_BF16:
+            x32 = x.float().contiguous() if ldx == cin else x[..., :cin].float().contiguous()
+            d32 = dy.float().contiguous() if lddy == cout else dy[..., :cout].float().contiguous()
+            call("unetr_tconv_wgrad", x32.data_ptr(), cin, d32.data_ptr(), cout, dw.data_ptr(), B, D, H, W, cin, cout, prec,
+                 ws.data_ptr(), ws.numel() * 4, _stream())
+        else:
+            call("unetr_tconv_wgrad", *args)
     return dw
 
 
@@ -989,8 +1067,11 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec):
         else:
             c1 = conv3(x, ldx, w1, dims, prec)
             s1 = instnorm_stats(c1, cout, B, V, cout)
+        # 1x1x1 conv on the generic GEMM family (fp32 storage: cast at the boundary in bf16 mode)
+        x32 = x if x.dtype == torch.float32 else x.float()
         c3 = torch.empty(B, D, H, W, cout, dtype=torch.float32, device=x.device)
-        gemm(x, w3, c3, B * V, cout, cin, lda=ldx, ldb=cin, ldc=cout, prec=prec)
+        gemm(x32, w3, c3, B * V, cout, cin, lda=x32.stride(-2), ldb=cin, ldc=cout, prec=prec)
+        c3 = _as_act(c3, prec)
         s3 = instnorm_stats(c3, cout, B, V, cout)
     a1 = instnorm_apply(c1, s1, B, V, cout, True)
     f2 = conv3_fused(a1, cout, w2, None, dims, prec)
@@ -1019,9 +1100,11 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=_gout(w1), dy3=dc3, out3=dw3)
     dx = None
     if need_dx:
-        dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=x.device)
+        dx = torch.empty(B, D, H, W, cin, dtype=act_dtype(prec), device=x.device)
         if not conv3_dgrad_fused(dc1, dc3, w1, w3, dx, dims, prec):
-            gemm(dc3, w3, dx, B * V, cin, cout, lda=cout, ldb=cin, ldc=cin, prec=prec, b_trans=True)
+            d32 = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=x.device)
+            gemm(dc3.float() if dc3.dtype != torch.float32 else dc3, w3, d32, B * V, cin, cout, lda=cout, ldb=cin, ldc=cin, prec=prec, b_trans=True)
+            dx.copy_(d32)
             conv3(dc1, cout, w1, dims, prec, mode=1, out=dx, ldo=cin, accumulate=True)
     return dx, dw1, dw2, dw3
 
@@ -1031,7 +1114,7 @@ class ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2, w3, prec):
-        _require_gpu(x)
+        _require_gpu(x, act=True)
         x, ldx = _rows(x)
         B, D, H, W, cin = x.shape
         cout = w1.shape[0]
@@ -1053,7 +1136,7 @@ class TconvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, prec):
-        _require_gpu(x)
+        _require_gpu(x, act=True)
         x, ldx = _rows(x)
         B, D, H, W, cin = x.shape
         cout = w.shape[1]
@@ -1078,16 +1161,16 @@ class UpBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inp, skip, wt, w1, w2, w3, prec):
-        _require_gpu(inp)
+        _require_gpu(inp, act=True)
         inp, ldi = _rows(inp)
-        skip, lds = _rows(skip)
         B, D, H, W, cin = inp.shape
         C = wt.shape[1]
         dims2 = (B, 2 * D, 2 * H, 2 * W)
         rows2 = B * 8 * D * H * W
-        cat = torch.empty(*dims2, 2 * C, dtype=torch.float32, device=inp.device)
+        cat = torch.empty(*dims2, 2 * C, dtype=act_dtype(prec), device=inp.device)
+        skip, lds = _rows(_as_act(skip, prec))
         _, ctx.xb = tconv_fwd(inp, ldi, wt, (B, D, H, W), cin, C, prec, out=cat, ldo=2 * C)
-        call("unetr_copy_rows", cat.data_ptr() + 4 * C, 2 * C, skip.data_ptr(), lds, rows2, C, 0, _stream())
+        call("unetr_copy_rows", cat.data_ptr() + cat.element_size() * C, 2 * C, skip.data_ptr(), lds, rows2, C, 0, _a16(cat), _stream())
         out, saved = _resblock_fwd(cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, prec)
         ctx.save_for_backward(inp, wt, w1, w2, w3, cat, *saved)
         ctx.meta = (ldi, (B, D, H, W), cin, C, prec)
@@ -1110,12 +1193,12 @@ class OutConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        _require_gpu(x)
+        _require_gpu(x, act=True)
         x, ldx = _rows(x)
         B, D, H, W, cin = x.shape
         cout = w.shape[0]
         logits = torch.empty(B, cout, D, H, W, dtype=torch.float32, device=x.device)
-        call("unetr_outconv_fwd", x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), logits.data_ptr(), B, D * H * W, cin, cout, _stream())
+        call("unetr_outconv_fwd", x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), logits.data_ptr(), B, D * H * W, cin, cout, _a16(x), _stream())
         ctx.save_for_backward(x, w, b)
         ctx.meta = (ldx, (B, D, H, W), cin, cout)
         return logits
@@ -1125,13 +1208,13 @@ class OutConvFn(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         ldx, (B, D, H, W), cin, cout = ctx.meta
         dl = dl.contiguous()
-        dx = torch.empty(B, D, H, W, cin, dtype=torch.float32, device=x.device)
+        dx = torch.empty(B, D, H, W, cin, dtype=x.dtype, device=x.device)
         gw, gb = _gout(w), _gout(b)
         dw = gw if gw is not None else torch.empty_like(w)
         db = gb if gb is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
         ws = workspace(x.device)
         call("unetr_outconv_bwd", dl.data_ptr(), x.data_ptr(), ldx, w.data_ptr(), dx.data_ptr(), cin, dw.data_ptr(), db.data_ptr(),
-             B, D * H * W, cin, cout, ws.data_ptr(), ws.numel() * 4, _stream())
+             B, D * H * W, cin, cout, ws.data_ptr(), ws.numel() * 4, _a16(x), _stream())
         return dx, _ret(w, dw), _ret(b, db)
 
 
@@ -1140,19 +1223,20 @@ class ToNCDHWFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        _require_gpu(x)
+        _require_gpu(x, act=True)
         x, ldx = _rows(x)
         B, D, H, W, C = x.shape
         y = torch.empty(B, C, D, H, W, dtype=torch.float32, device=x.device)
-        call("unetr_nhwc_to_nchw", x.data_ptr(), ldx, y.data_ptr(), B, C, D * H * W, 0, _stream())
+        call("unetr_nhwc_to_nchw", x.data_ptr(), ldx, y.data_ptr(), B, C, D * H * W, 0, _a16(x), _stream())
+        ctx.adt = x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
         B, C, D, H, W = dy.shape
-        dx = torch.empty(B, D, H, W, C, dtype=torch.float32, device=dy.device)
-        call("unetr_nchw_to_nhwc", dy.data_ptr(), dx.data_ptr(), C, B, C, D * H * W, _stream())
+        dx = torch.empty(B, D, H, W, C, dtype=ctx.adt, device=dy.device)
+        call("unetr_nchw_to_nhwc", dy.data_ptr(), dx.data_ptr(), C, B, C, D * H * W, _a16(dx), _stream())
         return dx
 
 
@@ -1163,8 +1247,8 @@ def to_channels_last(x_in):
     x_in = x_in.contiguous()
     if C == 1:
         return x_in.view(B, D, H, W, 1)
-    y = torch.empty(B, D, H, W, C, dtype=torch.float32, device=x_in.device)
-    call("unetr_nchw_to_nhwc", x_in.data_ptr(), y.data_ptr(), C, B, C, D * H * W, _stream())
+    y = torch.empty(B, D, H, W, C, dtype=torch.float32, device=x_in.device)      # (the image stays fp32 in every mode)
+    call("unetr_nchw_to_nhwc", x_in.data_ptr(), y.data_ptr(), C, B, C, D * H * W, 0, _stream())
     return y
 
 

@@ -11,7 +11,13 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no host synchronisation;
  *   - return value 0 = ok, non-zero = UNETR_ERR_* (the Python shim raises RuntimeError);
  *   - `prec`: 0 = fp32 (v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chains), 1 = bf16 operands with fp32
- *     accumulation (v_mfma_f32_16x16x32_bf16).  Storage is fp32 in both modes;
+ *     accumulation (v_mfma_f32_16x16x32_bf16);
+ *   - ACTIVATION STORAGE: on the conv side (3x3x3 / 1x1x1 / transposed convs, InstanceNorm, concat copies, out conv)
+ *     every feature map and feature-map gradient is stored in the precision mode's activation type: fp32 with prec 0,
+ *     **bf16 with prec 1** (half the HBM bytes of passes that are bandwidth-bound; statistics, weights, partial sums,
+ *     logits and the input image stay fp32).  Entry points that take `prec` infer the type from it (`const void*`
+ *     operands); entry points without one take `act16` (1 = bf16 feature maps).  Rows of a bf16 feature map are 16-byte
+ *     aligned (pitch % 8 == 0).  The token side (ViT) keeps an fp32 residual stream plus bf16 operand copies;
  *   - feature maps are channels-last: [B, D, H, W, C] with a row pitch `ld` (floats between voxels), so a
  *     producer can write straight into one half of a concatenation buffer (torch.cat at MONAI
  *     UnetrUpBlock.forward, used by unetr.py:203-206, becomes free);
@@ -104,13 +110,13 @@ int unetr_tconv_wgrad(const float* x, long ldx, const float* dy, long ldy, float
  * 64-voxel tiles, LDS table of output-voxel bases, dy gathered voxel-major and read through transposing LDS loads).
  * Same arguments and results as unetr_tconv_fwd / unetr_tconv_wgrad; return "unsupported" (3) for shapes outside their
  * range (M = B*D*H*W < 2048, channel counts, alignment) -- the caller then uses the generic entry points above. */
-int unetr_tconv2_fwd(const float* x, long ldx, const float* w, float* y, long ldy,
+int unetr_tconv2_fwd(const void* x, long ldx, const float* w, void* y, long ldy,
                      int B, int D, int H, int W, int Cin, int Cout, int prec,
                      float* ws, size_t ws_bytes, void* stream);
-int unetr_tconv2_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
+int unetr_tconv2_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw,
                        int B, int D, int H, int W, int Cin, int Cout, int prec,
                        float* ws, size_t ws_bytes, void* stream);
-int unetr_tconv2_dgrad(const float* dy, long ldy, const float* w, float* dx, long ldx, int accumulate,
+int unetr_tconv2_dgrad(const void* dy, long ldy, const float* w, void* dx, long ldx, int accumulate,
                        int B, int D, int H, int W, int Cin, int Cout, int prec,
                        float* ws, size_t ws_bytes, void* stream);
 int unetr_tconv2_fwd_supported(long M, int Cin, int Cout, long ldx, long ldy);
@@ -148,8 +154,8 @@ int unetr_ln_gemm_bf16(const unetr_ln_gemm_desc* d, void* stream);
 /* The small transposed convs (Cin a multiple of 64, bf16 mode) run as plain unetr_gemm_bf16 calls on torch's own weight
  * matrix [Cin, Cout*8]; these two move between the GEMM-side matrix t / g [M, Cout*8] (column = co*8 + tap) and the
  * voxel-major tensor y / dy [B, 2D, 2H, 2W, Cout] (pitch ldy): the pixel shuffle that is left of the "transposed conv". */
-int unetr_pixel_shuffle2(const float* t, float* y, long ldy, int B, int D, int H, int W, int Cout, void* stream);
-int unetr_pixel_unshuffle2_bf16(const float* dy, long lddy, void* g_bf16, int B, int D, int H, int W, int Cout, void* stream);
+int unetr_pixel_shuffle2(const float* t, void* y, long ldy, int B, int D, int H, int W, int Cout, int act16, void* stream);
+int unetr_pixel_unshuffle2_bf16(const void* dy, long lddy, void* g_bf16, int B, int D, int H, int W, int Cout, int act16, void* stream);
 
 /* ---- column sums: out[n] (+)= sum_m x[m*ld+n]  (bias / position-embedding gradients) ---------------- */
 int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate,
@@ -192,7 +198,7 @@ int unetr_conv_gemm_wgrad(const float* x, long ldx, const float* dy, long ldy, f
  * mode 0 = forward, mode 1 = data gradient (then call unetr_conv3_fwd with Cin/Cout swapped).  Cout % 16 == 0. */
 size_t unetr_conv3_packed_bytes(int Cin, int Cout, int mode, int prec);
 int unetr_conv3_pack_weight(const float* w, void* wpack, int Cin, int Cout, int mode, int prec, void* stream);
-int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, float* y, long ldy, int accumulate,
+int unetr_conv3_fwd(const void* x, long ldx, const void* wpack, void* y, long ldy, int accumulate,
                     int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream);
 /* dy3/dw3 (both or neither): also produce the weight gradient dw3[Cout,Cin] of the 1x1x1 conv that shares the
  * input x (MONAI UnetResBlock.conv3 next to conv1) from its own output gradient dy3, inside the same pass. */
@@ -201,18 +207,19 @@ int unetr_conv3_fwd(const float* x, long ldx, const void* wpack, float* y, long 
  * block's conv3, which reads the same input) with stats3.  wpack from unetr_conv3_pack_weight(mode 0), w3pack from
  * unetr_conv3_pack_1x1.  Returns "unsupported" for shapes that do not run on the persistent kernel (caller then uses
  * unetr_conv3_fwd + unetr_gemm + unetr_instnorm_stats). */
-int unetr_conv3_fwd_fused(const float* x, long ldx, const void* wpack, float* y, long ldy, float* stats,
-                          const void* w3pack, float* y3, long ldy3, float* stats3, float eps,
+int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack, void* y, long ldy, float* stats,
+                          const void* w3pack, void* y3, long ldy3, float* stats3, float eps,
                           int B, int D, int H, int W, int Cin, int Cout, int prec,
+                          int x_f32 /* bf16 mode: x is the fp32 image (<= 16 channels), not a bf16 feature map */,
                           float* ws, size_t ws_bytes, void* stream);
 size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec);
 int unetr_conv3_pack_1x1(const float* w3 /* [Cout,Cin] */, void* w3pack, int Cin, int Cout, int prec, void* stream);
 /* Data gradient of the residual block's input in one launch: dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3)
  * (autograd of UnetResBlock.conv1 + conv3, both fed by the block input).  wpack_dgrad from unetr_conv3_pack_weight(mode 1)
  * of conv1's weight; w3 = conv3's weight [Cout, Cin] as stored; dc1 / dc3 [B,D,H,W,Cout] channels-last with pitches. */
-int unetr_conv3_dgrad_fused(const float* dc1, long ld1, const void* wpack_dgrad, const float* dc3, long ld3, const float* w3,
+int unetr_conv3_dgrad_fused(const void* dc1, long ld1, const void* wpack_dgrad, const void* dc3, long ld3, const float* w3,
                             const void* w3pack_t /* optional: kind-3 pack of w3 (unetr_conv3_pack_grouped); NULL = packed here from w3 */,
-                            float* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout, int prec,
+                            void* dx, long lddx, int B, int D, int H, int W, int Cin, int Cout, int prec,
                             float* ws, size_t ws_bytes, void* stream);
 /* All weight re-packs of a step in one launch (descriptors in the kernel arguments, <= 64 per launch).  kind 0 / 1: what
  * unetr_conv3_pack_weight(mode 0 / 1) writes; kind 2: unetr_conv3_pack_1x1; kind 3: the transposed 1x1x1 layout that
@@ -221,40 +228,40 @@ typedef struct { const float* w; void* out; int Cin, Cout, kind; } unetr_pack_pr
 int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, int prec, void* stream);
 /* (mean, rstd) from InstanceNorm partial sums part[B][nchunk][2][C] (sum, sum of squares) */
 int unetr_instnorm_stats_finalize(const float* part, int nchunk, int B, long V, int C, float eps, float* stats, void* stream);
-int unetr_conv3_wgrad(const float* x, long ldx, const float* dy, long ldy, float* dw,
-                      const float* dy3, long ldy3, float* dw3,
-                      int B, int D, int H, int W, int Cin, int Cout, int prec,
+int unetr_conv3_wgrad(const void* x, long ldx, const void* dy, long ldy, float* dw,
+                      const void* dy3, long ldy3, float* dw3,
+                      int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32 /* as in unetr_conv3_fwd_fused */,
                       float* ws, size_t ws_bytes, void* stream);
 /* probe of the ds_read_b64_tr_b16 lane map used by the bf16 weight-gradient kernel (test hook) */
 int unetr_debug_tr16(const void* in_u16_64x64, void* out_u16_64x4, void* stream);
 
 /* ---- InstanceNorm3d(affine=False, eps 1e-5) + LeakyReLU(0.01) + residual add -------------------------
  * stats: [B, C, 2] = (mean, rstd). */
-int unetr_instnorm_stats(const float* x, long ld, int B, long V, int C, float eps, float* stats,
-                         float* ws, size_t ws_bytes, void* stream);
+int unetr_instnorm_stats(const void* x, long ld, int B, long V, int C, float eps, float* stats,
+                         float* ws, size_t ws_bytes, int act16, void* stream);
 /* y = lrelu?(norm(x;sa) [+ norm(x2;sb)]) */
-int unetr_instnorm_apply(const float* x, long ldx, const float* sa, const float* x2, long ldx2, const float* sb,
-                         float* y, long ldy, int B, long V, int C, int lrelu, void* stream);
+int unetr_instnorm_apply(const void* x, long ldx, const float* sa, const void* x2, long ldx2, const float* sb,
+                         void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream);
 /* backward of y = lrelu?(norm(x) [+ norm(x2)]): writes dx (and dx2). */
-int unetr_instnorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* sa,
-                       const float* x2, long ldx2, const float* sb, float* dx, long lddx, float* dx2, long lddx2,
-                       int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, void* stream);
+int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const float* sa,
+                       const void* x2, long ldx2, const float* sb, void* dx, long lddx, void* dx2, long lddx2,
+                       int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, int act16, void* stream);
 
 /* ---- layout moves --------------------------------------------------------------------------------- */
 /* NCDHW [B,C,V] <-> channels-last [B,V,C] (pitch ld) */
-int unetr_nchw_to_nhwc(const float* x, float* y, long ldy, int B, int C, long V, void* stream);
-int unetr_nhwc_to_nchw(const float* x, long ldx, float* y, int B, int C, long V, int accumulate, void* stream);
+int unetr_nchw_to_nhwc(const float* x /* fp32 NCDHW */, void* y /* feature map */, long ldy, int B, int C, long V, int act16, void* stream);
+int unetr_nhwc_to_nchw(const void* x /* feature map */, long ldx, float* y /* fp32 NCDHW */, int B, int C, long V, int accumulate, int act16, void* stream);
 /* einops "b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)" (MONAI PatchEmbeddingBlock, perceptron) */
 int unetr_patch_gather(const float* x, float* patches, int B, int C, int D, int H, int W, int P, void* stream);
 /* y[r, 0:cols] (+)= a[r, 0:cols] for row-pitched matrices (skip -> concat buffer, gradient sums) */
-int unetr_copy_rows(float* y, long ldy, const float* a, long lda, long rows, int cols, int accumulate, void* stream);
+int unetr_copy_rows(void* y, long ldy, const void* a, long lda, long rows, int cols, int accumulate, int act16, void* stream);
 
 /* ---- 1x1x1 out conv with bias, NCDHW logits (MONAI UnetOutBlock; unetr.py:175,207) ------------------ */
-int unetr_outconv_fwd(const float* x, long ldx, const float* w, const float* bias, float* logits,
-                      int B, long V, int Cin, int Cout, void* stream);
-int unetr_outconv_bwd(const float* dlogits, const float* x, long ldx, const float* w, float* dx, long lddx,
+int unetr_outconv_fwd(const void* x, long ldx, const float* w, const float* bias, float* logits,
+                      int B, long V, int Cin, int Cout, int act16, void* stream);
+int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, const float* w, void* dx, long lddx,
                       float* dw, float* dbias, int B, long V, int Cin, int Cout,
-                      float* ws, size_t ws_bytes, void* stream);
+                      float* ws, size_t ws_bytes, int act16, void* stream);
 
 /* ---- DiceCELoss (unetr_segmentation_3d.py:404 and :477-482) -------------------------------------------
  * sigmoid_multilabel = 0: DiceCELoss(to_onehot_y=True, softmax=True); label [B,V] float-valued class ids.
