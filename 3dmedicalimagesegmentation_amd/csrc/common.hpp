@@ -94,6 +94,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 template <class T> struct Io;
 template <> struct Io<float> {
     static constexpr int B16 = 0;
+    static constexpr int W = 4;       // elements per 16-byte access
+    static __device__ __forceinline__ void ldw(const float* p, float (&v)[4]) { const f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    static __device__ __forceinline__ void stw(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
     static __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
     static __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
     static __device__ __forceinline__ float ld1(const float* p) { return *p; }
@@ -101,6 +104,16 @@ template <> struct Io<float> {
 };
 template <> struct Io<uint16_t> {
     static constexpr int B16 = 1;
+    static constexpr int W = 8;
+    static __device__ __forceinline__ void ldw(const uint16_t* p, float (&v)[8]) {
+        const f32x8 t = __builtin_convertvector(*(const bf16x8*)p, f32x8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t[e];
+    }
+    static __device__ __forceinline__ void stw(uint16_t* p, const float (&v)[8]) {
+        const f32x8 t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        *(bf16x8*)p = __builtin_convertvector(t, bf16x8);
+    }
     static __device__ __forceinline__ f32x4 ld4(const uint16_t* p) { return __builtin_convertvector(*(const bf16x4*)p, f32x4); }
     static __device__ __forceinline__ void st4(uint16_t* p, f32x4 v) { *(bf16x4*)p = __builtin_convertvector(v, bf16x4); }
     static __device__ __forceinline__ float ld1(const uint16_t* p) { return __builtin_bit_cast(float, (uint32_t)*p << 16); }

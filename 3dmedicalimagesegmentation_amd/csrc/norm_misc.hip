@@ -192,21 +192,23 @@ colsum_grouped_kernel(ColsumArgs a) {
 // x: [B, V, C] pitch ld.  thread -> (channel vec cv, voxel phase); block covers VPB voxels of one batch item.
 constexpr int IN_VPB = 1024;
 
-template <int NS>  // NS sums per channel
-__device__ __forceinline__ void in_block_reduce(f32x4 (&acc)[NS], int cvn, int nphase, float* lds, float* part_out, int C) {
-    // lds: [NS][nphase][cvn] float4
-    f32x4* l4 = (f32x4*)lds;
+// Thread -> (channel group cv of W channels, voxel phase); W = Io<T>::W = one 16-byte access (4 fp32 / 8 bf16 channels): with
+// bf16 storage a 4-channel granule would be an 8-byte access and the passes turn issue-bound instead of bandwidth-bound.
+template <int NS, int W>  // NS sums per channel
+__device__ __forceinline__ void in_block_reduce(float (&acc)[NS][W], int cvn, int nphase, float* lds, float* part_out, int C) {
+    // lds: [NS][nphase][cvn][W] floats
     const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
     if (ph < nphase)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) l4[(s * nphase + ph) * cvn + cv] = acc[s];
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int e = 0; e < W; ++e) lds[((s * nphase + ph) * cvn + cv) * W + e] = acc[s][e];
     __syncthreads();
-    for (int i = threadIdx.x; i < NS * cvn; i += blockDim.x) {
-        int s = i / cvn, c = i - s * cvn;
-        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int p = 0; p < nphase; ++p) t += l4[(s * nphase + p) * cvn + c];
-        // part_out: [NS][C]
-        *(f32x4*)(part_out + (long)s * C + 4 * c) = t;
+    for (int i = threadIdx.x; i < NS * C; i += blockDim.x) {
+        const int s = i / C, c = i - s * C;
+        float t = 0.f;
+        for (int p = 0; p < nphase; ++p) t += lds[(s * nphase + p) * C + c];
+        part_out[(long)s * C + c] = t;       // part_out: [NS][C]
     }
 }
 
@@ -214,18 +216,22 @@ template <class T>
 __global__ void __launch_bounds__(256)
 in_stats_kernel(const T* __restrict__ x, long ld, long V, int C, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int cvn = C >> 2, nphase = 256 / cvn;
+    constexpr int W = Io<T>::W;
+    const int cvn = C / W, nphase = 256 / cvn;
     const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
     const int b = blockIdx.y;
     const long v0 = (long)blockIdx.x * IN_VPB, v1 = std::min<long>(V, v0 + IN_VPB);
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    float acc[2][W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
     if (ph < nphase)
         for (long v = v0 + ph; v < v1; v += nphase) {
-            f32x4 t = Io<T>::ld4(x + ((long)b * V + v) * ld + 4 * cv);
-            acc[0] += t;
-            acc[1] += t * t;
+            float t[W];
+            Io<T>::ldw(x + ((long)b * V + v) * ld + W * cv, t);
+#pragma unroll
+            for (int e = 0; e < W; ++e) { acc[0][e] += t[e]; acc[1][e] += t[e] * t[e]; }
         }
-    in_block_reduce<2>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 2 * C, C);
+    in_block_reduce<2, W>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 2 * C, C);
 }
 
 __global__ void in_stats_final_kernel(const float* __restrict__ part, int nchunk, long V, int C, float eps,
@@ -256,25 +262,27 @@ template <class T>
 __global__ void __launch_bounds__(256)
 in_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ sa, const T* __restrict__ x2, long ldx2,
                 const float* __restrict__ sb, T* __restrict__ y, long ldy, int B, long V, int C, int lrelu) {
-    const int cvn = C >> 2;
+    constexpr int W = Io<T>::W;
+    const int cvn = C / W;
     const long total = (long)B * V * cvn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int cv = (int)(i % cvn); long vox = i / cvn; int b = (int)(vox / V);
-        f32x4 t = Io<T>::ld4(x + vox * ldx + 4 * cv), o;
-        const float* s = sa + ((long)b * C + 4 * cv) * 2;
+        float t[W], t2[W], o[W];
+        Io<T>::ldw(x + vox * ldx + W * cv, t);
+        if (x2) Io<T>::ldw(x2 + vox * ldx2 + W * cv, t2);
+        const float* s = sa + ((long)b * C + W * cv) * 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (t[e] - s[2 * e]) * s[2 * e + 1];
+        for (int e = 0; e < W; ++e) o[e] = (t[e] - s[2 * e]) * s[2 * e + 1];
         if (x2) {
-            f32x4 t2 = Io<T>::ld4(x2 + vox * ldx2 + 4 * cv);
-            const float* s2 = sb + ((long)b * C + 4 * cv) * 2;
+            const float* s2 = sb + ((long)b * C + W * cv) * 2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += (t2[e] - s2[2 * e]) * s2[2 * e + 1];
+            for (int e = 0; e < W; ++e) o[e] += (t2[e] - s2[2 * e]) * s2[2 * e + 1];
         }
         if (lrelu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = lrelu_f(o[e]);
+            for (int e = 0; e < W; ++e) o[e] = lrelu_f(o[e]);
         }
-        Io<T>::st4(y + vox * ldy + 4 * cv, o);
+        Io<T>::stw(y + vox * ldy + W * cv, o);
     }
 }
 
@@ -285,55 +293,56 @@ in_bwd_reduce_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ 
                      const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, long V, int C, int lrelu,
                      float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int cvn = C >> 2, nphase = 256 / cvn;
+    constexpr int W = Io<T>::W;
+    const int cvn = C / W, nphase = 256 / cvn;
     const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
     const int b = blockIdx.y;
     const long v0 = (long)blockIdx.x * IN_VPB, v1 = std::min<long>(V, v0 + IN_VPB);
-    f32x4 acc[3];
+    float acc[3][W];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[s][e] = 0.f;
     if (ph < nphase) {
-        const float* s1 = sa + ((long)b * C + 4 * cv) * 2;
-        const float* s2 = x2 ? sb + ((long)b * C + 4 * cv) * 2 : nullptr;
-        // statistics of this thread's four channels, loaded once
-        float mu1[4], rs1[4], mu2[4], rs2[4];
+        const float* s1 = sa + ((long)b * C + W * cv) * 2;
+        const float* s2 = x2 ? sb + ((long)b * C + W * cv) * 2 : nullptr;
+        // statistics of this thread's channels, loaded once
+        float mu1[W], rs1[W], mu2[W], rs2[W];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < W; ++e) {
             mu1[e] = s1[2 * e]; rs1[e] = s1[2 * e + 1];
             mu2[e] = x2 ? s2[2 * e] : 0.f; rs2[e] = x2 ? s2[2 * e + 1] : 0.f;
         }
-        // four voxels per iteration: all their loads are issued before the first use (a pure-read pass with one voxel in
+        // several voxels per iteration: all their loads are issued before the first use (a pure-read pass with one voxel in
         // flight per thread ran at 4.2 TB/s against 6.8 TB/s for the read+write passes)
-        constexpr int U = 4;
+        constexpr int U = 32 / W;
         for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
-            f32x4 g[U], t[U], t2[U];
+            float g[U][W], t[U][W], t2[U][W];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const long vv = v + (long)u * nphase;
                 const long vox = (long)b * V + (vv < v1 ? vv : v);      // clamped: re-reads voxel v, masked below
-                g[u] = Io<T>::ld4(dy + vox * lddy + 4 * cv);
-                t[u] = Io<T>::ld4(x + vox * ldx + 4 * cv);
-                t2[u] = x2 ? Io<T>::ld4(x2 + vox * ldx2 + 4 * cv) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                Io<T>::ldw(dy + vox * lddy + W * cv, g[u]);
+                Io<T>::ldw(x + vox * ldx + W * cv, t[u]);
+                if (x2) Io<T>::ldw(x2 + vox * ldx2 + W * cv, t2[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float live = (v + (long)u * nphase < v1) ? 1.f : 0.f;
-                f32x4 n1, n2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    n1[e] = (t[u][e] - mu1[e]) * rs1[e];
-                    n2[e] = (t2[u][e] - mu2[e]) * rs2[e];
+                for (int e = 0; e < W; ++e) {
+                    const float n1 = (t[u][e] - mu1[e]) * rs1[e];
+                    const float n2 = x2 ? (t2[u][e] - mu2[e]) * rs2[e] : 0.f;
                     float ge = g[u][e] * live;
-                    if (lrelu) ge = (n1[e] + n2[e]) > 0.f ? ge : 0.01f * ge;
-                    g[u][e] = ge;
+                    if (lrelu) ge = (n1 + n2) > 0.f ? ge : 0.01f * ge;
+                    acc[0][e] += ge;
+                    acc[1][e] += ge * n1;
+                    acc[2][e] += ge * n2;
                 }
-                acc[0] += g[u];
-                acc[1] += g[u] * n1;
-                acc[2] += g[u] * n2;
             }
         }
     }
-    in_block_reduce<3>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 3 * C, C);
+    in_block_reduce<3, W>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 3 * C, C);
 }
 
 __global__ void in_bwd_final_kernel(const float* __restrict__ part, int nchunk, long V, int C, int B, float* __restrict__ sums) {
@@ -356,35 +365,36 @@ __global__ void __launch_bounds__(256)
 in_bwd_apply_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
                     const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, const float* __restrict__ sums,
                     T* __restrict__ dx, long lddx, T* __restrict__ dx2, long lddx2, int B, long V, int C, int lrelu) {
-    const int cvn = C >> 2;
+    constexpr int W = Io<T>::W;
+    const int cvn = C / W;
     const long total = (long)B * V * cvn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int cv = (int)(i % cvn); long vox = i / cvn; int b = (int)(vox / V);
-        const float* s1 = sa + ((long)b * C + 4 * cv) * 2;
-        const float* sm = sums + ((long)b * C + 4 * cv) * 3;
-        f32x4 g = Io<T>::ld4(dy + vox * lddy + 4 * cv);
-        f32x4 t = Io<T>::ld4(x + vox * ldx + 4 * cv), n1, n2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* s1 = sa + ((long)b * C + W * cv) * 2;
+        const float* sm = sums + ((long)b * C + W * cv) * 3;
+        float g[W], t[W], t2[W], n1[W], n2[W], o[W];
+        Io<T>::ldw(dy + vox * lddy + W * cv, g);
+        Io<T>::ldw(x + vox * ldx + W * cv, t);
+        if (x2) Io<T>::ldw(x2 + vox * ldx2 + W * cv, t2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) n1[e] = (t[e] - s1[2 * e]) * s1[2 * e + 1];
+        for (int e = 0; e < W; ++e) { n1[e] = (t[e] - s1[2 * e]) * s1[2 * e + 1]; n2[e] = 0.f; }
         const float* s2 = nullptr;
         if (x2) {
-            s2 = sb + ((long)b * C + 4 * cv) * 2;
-            f32x4 t2 = Io<T>::ld4(x2 + vox * ldx2 + 4 * cv);
+            s2 = sb + ((long)b * C + W * cv) * 2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) n2[e] = (t2[e] - s2[2 * e]) * s2[2 * e + 1];
+            for (int e = 0; e < W; ++e) n2[e] = (t2[e] - s2[2 * e]) * s2[2 * e + 1];
         }
         if (lrelu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = (n1[e] + n2[e]) > 0.f ? g[e] : 0.01f * g[e];
+            for (int e = 0; e < W; ++e) g[e] = (n1[e] + n2[e]) > 0.f ? g[e] : 0.01f * g[e];
         }
-        f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = s1[2 * e + 1] * (g[e] - sm[3 * e] - n1[e] * sm[3 * e + 1]);
-        Io<T>::st4(dx + vox * lddx + 4 * cv, o);
+        for (int e = 0; e < W; ++e) o[e] = s1[2 * e + 1] * (g[e] - sm[3 * e] - n1[e] * sm[3 * e + 1]);
+        Io<T>::stw(dx + vox * lddx + W * cv, o);
         if (x2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = s2[2 * e + 1] * (g[e] - sm[3 * e] - n2[e] * sm[3 * e + 2]);
-            Io<T>::st4(dx2 + vox * lddx2 + 4 * cv, o);
+            for (int e = 0; e < W; ++e) o[e] = s2[2 * e + 1] * (g[e] - sm[3 * e] - n2[e] * sm[3 * e + 2]);
+            Io<T>::stw(dx2 + vox * lddx2 + W * cv, o);
         }
     }
 }
@@ -429,14 +439,21 @@ __global__ void patch_gather_kernel(const float* __restrict__ x, float* __restri
 
 template <class T>
 __global__ void add_rows_kernel(T* __restrict__ y, long ldy, const T* __restrict__ a, long lda, long rows, int cols, int accumulate) {
-    const int cvn = cols >> 2;
+    constexpr int W = Io<T>::W;
+    const int cvn = cols / W;
     const long total = rows * cvn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int cv = (int)(i % cvn); long r = i / cvn;
-        T* yp = y + r * ldy + 4 * cv;
-        f32x4 v = Io<T>::ld4(a + r * lda + 4 * cv);
-        if (accumulate) v += Io<T>::ld4(yp);
-        Io<T>::st4(yp, v);
+        T* yp = y + r * ldy + W * cv;
+        float v[W];
+        Io<T>::ldw(a + r * lda + W * cv, v);
+        if (accumulate) {
+            float o[W];
+            Io<T>::ldw(yp, o);
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] += o[e];
+        }
+        Io<T>::stw(yp, v);
     }
 }
 
@@ -658,20 +675,21 @@ extern "C" int unetr_colsum_grouped(const unetr_colsum_problem* probs, int n, vo
     return unetr_check_launch();
 }
 
-static int in_check(int C, long ld) {
-    if ((C & 3) || C > 1024 || (ld & 3) || (256 % (C >> 2)) != 0) return UNETR_ERR_UNSUPPORTED;
+static int in_check(int C, long ld, int act16 = 0) {
+    const int W = act16 ? 8 : 4;            // one 16-byte access per thread
+    if ((C % W) || C > 1024 || (ld % W) || (256 % (C / W)) != 0) return UNETR_ERR_UNSUPPORTED;
     return UNETR_OK;
 }
 
 extern "C" int unetr_instnorm_stats(const void* x, long ld, int B, long V, int C, float eps, float* stats,
                                     float* ws, size_t ws_bytes, int act16, void* stream) {
     if (!x || !stats || B <= 0 || V <= 0) return UNETR_ERR_ARG;
-    if (int e = in_check(C, ld)) return e;
+    if (int e = in_check(C, ld, act16)) return e;
     int nchunk = cdiv(V, IN_VPB);
     if (!ws || (size_t)B * nchunk * 2 * C * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    int cvn = C >> 2, nphase = 256 / cvn;
-    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_stats_kernel<AT>, dim3(nchunk, B), dim3(256), (size_t)2 * nphase * cvn * 16, st, (const AT*)x, ld, V, C, ws));
+    const int cvn = C / (act16 ? 8 : 4), nphase = 256 / cvn;
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_stats_kernel<AT>, dim3(nchunk, B), dim3(256), (size_t)2 * nphase * C * 4, st, (const AT*)x, ld, V, C, ws));
     hipLaunchKernelGGL(in_stats_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, eps, stats, B);
     return unetr_check_launch();
 }
@@ -711,8 +729,9 @@ extern "C" int unetr_instnorm_stats_finalize(const float* part, int nchunk, int 
 extern "C" int unetr_instnorm_apply(const void* x, long ldx, const float* sa, const void* x2, long ldx2, const float* sb,
                                     void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream) {
     if (!x || !sa || !y || (x2 && !sb)) return UNETR_ERR_ARG;
-    if ((C & 3) || (ldx & 3) || (ldy & 3) || (x2 && (ldx2 & 3))) return UNETR_ERR_UNSUPPORTED;
-    long total = (long)B * V * (C >> 2);
+    const int W = act16 ? 8 : 4;
+    if ((C % W) || (ldx % W) || (ldy % W) || (x2 && (ldx2 % W))) return UNETR_ERR_UNSUPPORTED;
+    long total = (long)B * V * (C / W);
     ACT_DISPATCH(act16, hipLaunchKernelGGL(in_apply_kernel<AT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const AT*)x, ldx, sa,
                                            (const AT*)x2, ldx2, sb, (AT*)y, ldy, B, V, C, lrelu));
     return unetr_check_launch();
@@ -722,18 +741,19 @@ extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long
                                   const void* x2, long ldx2, const float* sb, void* dx, long lddx, void* dx2, long lddx2,
                                   int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, int act16, void* stream) {
     if (!dy || !x || !sa || !dx || (x2 && (!sb || !dx2))) return UNETR_ERR_ARG;
-    if (int e = in_check(C, ldx)) return e;
-    if ((lddy & 3) || (lddx & 3) || (x2 && ((ldx2 & 3) || (lddx2 & 3)))) return UNETR_ERR_UNSUPPORTED;
+    if (int e = in_check(C, ldx, act16)) return e;
+    const int W = act16 ? 8 : 4;
+    if ((lddy % W) || (lddx % W) || (x2 && ((ldx2 % W) || (lddx2 % W)))) return UNETR_ERR_UNSUPPORTED;
     int nchunk = cdiv(V, IN_VPB);
     size_t need = ((size_t)B * nchunk * 3 * C + (size_t)B * C * 3) * sizeof(float);
     if (!ws || need > ws_bytes) return UNETR_ERR_WORKSPACE;
     float* sums = ws + (size_t)B * nchunk * 3 * C;
     hipStream_t st = (hipStream_t)stream;
-    int cvn = C >> 2, nphase = 256 / cvn;
-    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_reduce_kernel<AT>, dim3(nchunk, B), dim3(256), (size_t)3 * nphase * cvn * 16, st, (const AT*)dy, lddy,
+    const int cvn = C / W, nphase = 256 / cvn;
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_reduce_kernel<AT>, dim3(nchunk, B), dim3(256), (size_t)3 * nphase * C * 4, st, (const AT*)dy, lddy,
                                            (const AT*)x, ldx, sa, (const AT*)x2, ldx2, sb, V, C, lrelu, ws));
     hipLaunchKernelGGL(in_bwd_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, B, sums);
-    long total = (long)B * V * (C >> 2);
+    long total = (long)B * V * (C / W);
     ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_apply_kernel<AT>, dim3(grid_for(total)), dim3(256), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
                                            (const AT*)x2, ldx2, sb, sums, (AT*)dx, lddx, (AT*)dx2, lddx2, B, V, C, lrelu));
     return unetr_check_launch();
@@ -763,8 +783,9 @@ extern "C" int unetr_patch_gather(const float* x, float* patches, int B, int C, 
 }
 
 extern "C" int unetr_copy_rows(void* y, long ldy, const void* a, long lda, long rows, int cols, int accumulate, int act16, void* stream) {
-    if (!y || !a || (cols & 3) || (ldy & 3) || (lda & 3)) return UNETR_ERR_ARG;
-    ACT_DISPATCH(act16, hipLaunchKernelGGL(add_rows_kernel<AT>, dim3(grid_for(rows * (cols >> 2))), dim3(256), 0, (hipStream_t)stream, (AT*)y, ldy,
+    const int W = act16 ? 8 : 4;
+    if (!y || !a || (cols % W) || (ldy % W) || (lda % W)) return UNETR_ERR_ARG;
+    ACT_DISPATCH(act16, hipLaunchKernelGGL(add_rows_kernel<AT>, dim3(grid_for(rows * (cols / W))), dim3(256), 0, (hipStream_t)stream, (AT*)y, ldy,
                                            (const AT*)a, lda, rows, cols, accumulate));
     return unetr_check_launch();
 }

@@ -249,12 +249,17 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
                    "grad_comm_dtype": (str(comm_dtype).replace("torch.", "") if ddp_on else None),
                    "first_step_loss": first_loss, "final_loss": float(step.loss.item()), "graph_capture_error": graph_err},
     }
-    if rank == 0 and not args.no_roofline and args.config == "c2":
+    if rank == 0 and not args.no_roofline and args.config == "c2" and not ddp_on:
         try:
             from tools import roofline as rl
-            out.update(rl.step_report(pkg, model, crit, x, y, args.precision, ms_per_step))
+            out.update(rl.step_report(pkg, step, batch, args.precision, ms_per_step))
         except Exception as e:  # noqa: BLE001
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            from tools import roofline as rl
+            out.update(rl.encoder_report(pkg, model, x, args.precision))
+        except Exception as e:  # noqa: BLE001
+            out["encoder_fwd"] = {"error": f"{type(e).__name__}: {e}"}
         log("roofline done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, cfg, batch, first_loss)

@@ -1,114 +1,167 @@
-"""Live roofline measurement for bench.py.
+"""Whole-step kernel breakdown and roofline for bench.py (config[1]: 96^3, hidden 768, batch B per GPU, bf16 mode).
 
-Times the hot kernels of training steps with HIP events recorded on the stream the kernels are launched on
-(torch's current stream -- the C ABI receives exactly that stream), groups launches by (kernel family,
-shape), picks the group with the largest total time (the dominant kernel) and prices it:
+How the numbers are made (all inside the bench process, on the GPU that ran the step):
 
-  algorithmic bytes  = input feature map read once + output written once + weights (fp32 storage)
-  algorithmic flops  = 2 * voxels * Cout * Cin * 27
-  bound              = "mfma" if flops/bytes exceeds the ridge (peak_flops / peak_bw) else "hbm"
-
-Peaks from /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s; dense MFMA 2.5 PFLOP/s bf16, 157.3 TFLOP/s
-fp32.  `traffic` (PMC HBM bytes) is collected offline with rocprofv3 --pmc (profiles/), null here.
+* per-kernel device time: torch.profiler (roctracer) around replays of the captured step -- the same hipGraph the timed
+  region replays -- summed per kernel name, divided by the number of replays;
+* kernels are grouped into FAMILIES (regex on the kernel name); every family has an analytic model of its ALGORITHMIC work
+  per step (bytes it must move, flops it must do -- tensor sizes of the reference architecture; nothing
+  measured goes into it) and the roofline that bounds it: HBM (8 TB/s) for streaming / low-intensity kernels, bf16 MFMA
+  (2.5 PFLOP/s dense) where flops / bytes exceeds the ridge;
+* `roofline` = the family with the largest time per step: achieved = algorithmic work / measured time, frac = achieved / peak,
+  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc summary named in `traffic_source` (FETCH_SIZE x 2 x 1024
+  + WRITE_SIZE x 1024, separate passes, gfx950 correction of MI355X_MICROARCH.md) or null;
+* `families` = the same for every family (ms per step, launches, achieved, frac), so the line shows where the step goes.
 """
 import collections
+import json
+import os
+import re
 
 import torch
 
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
+# (family, regex on the demangled kernel name)
+FAMILIES = [
+    ("AdamW (fp32 master + moments, bf16 shadow)", r"adamw_kernel"),
+    ("ViT Linear GEMMs fwd + data-grad (bf16 operands)", r"gemm_bf16_kernel|splitk_reduce_kernel<.*EpBf"),
+    ("ViT Linear weight-grad (grouped)", r"gemm_bf16_grouped_wgrad|gemm_grouped_wgrad"),
+    ("attention fwd + bwd", r"attn16_|attn_fwd|attn_bwd"),
+    ("LayerNorm fwd + bwd", r"layernorm_"),
+    ("InstanceNorm passes", r"in_apply|in_bwd_|in_stats"),
+    ("3x3x3 conv fwd + data-grad", r"conv3_fwd"),
+    ("3x3x3 conv weight-grad", r"conv3_wgrad"),
+    ("2x2x2 transposed conv (voxel-tile kernels, shuffles)", r"tconv2_|pixel_"),
+    ("out conv + DiceCE", r"outconv|dicece"),
+]
 
-def dominant_kernel_roofline(pkg, model, crit, x, y, precision, reps=3):
-    Fn = pkg.functional
-    pending = []
 
-    def wrap(name, fam_fn):
-        orig = getattr(Fn, name)
+def _arch(B):
+    """algorithmic work per step of config[1] at batch B (bytes with bf16 feature maps, flops = 2 MAC)"""
+    P = 92452868
+    res = [(96 ** 3, 1, 16), (12 ** 3, 256, 128), (24 ** 3, 128, 64), (48 ** 3, 64, 32), (96 ** 3, 32, 16)]   # (V, Cin, Cout) of the 5 UnetResBlocks
+    a = {}
+    a["AdamW (fp32 master + moments, bf16 shadow)"] = dict(bytes=30.0 * P, flops=0.0)
+    lin_fwd = B * 1e9 * (1.359 + 12 * (0.7644 + 0.2548 + 2.0384))
+    lin_dg = B * 1e9 * 12 * (0.7644 + 0.2548 + 2.0384)
+    # per GEMM: bf16 operands + fp32/bf16 outputs are a few MB; the weights dominate: 88.3 M params x 2 B, read fwd and dgrad
+    a["ViT Linear GEMMs fwd + data-grad (bf16 operands)"] = dict(bytes=2 * 2.0 * 88.3e6, flops=lin_fwd + lin_dg)
+    a["ViT Linear weight-grad (grouped)"] = dict(bytes=4.0 * 88.3e6, flops=lin_fwd)
+    a["attention fwd + bwd"] = dict(bytes=B * 216 * 768 * 2.0 * 12 * (4 + 7), flops=B * 1e9 * 12 * 0.1434 * 3.5)
+    a["LayerNorm fwd + bwd"] = dict(bytes=B * 216 * 768 * (25 * (4 + 2) + 25 * (4 * 3 + 4 + 2)), flops=0.0)
+    inb = cvb = cwb = 0.0
+    cvf = cwf = 0.0
+    for V, ci, co in res:
+        u = 2.0 * B * V * co                     # one [V, Cout] bf16 feature map
+        # fwd: apply (r1 w1), dual apply (r2 w1); bwd: dual reduce r3, dual apply r3 w2, single reduce r2, single apply r2 w1
+        inb += 18 * u
+        xin = (4.0 if ci == 1 else 2.0) * B * V * ci
+        # fwd: conv1 (+1x1): read x, write c1, c3; conv2: read a1, write c2.  dgrad: conv2^T: r dc2 w da1; block input grad: r dc1, dc3, w dx
+        cvb += xin + 2 * u + 2 * u + 2 * u + (0 if ci == 1 else 2 * u + xin)
+        cvf += 2.0 * B * V * co * (27 * ci + ci + 27 * co) + 2.0 * B * V * 27 * co * co + (0 if ci == 1 else 2.0 * B * V * ci * co * 28)
+        cwb += (xin + 2 * u) + 2 * u             # conv1 wgrad (+1x1): x, dc1, dc3; conv2 wgrad: a1, dc2
+        cwf += 2.0 * B * V * co * (28 * ci + 27 * co)
+    a["InstanceNorm passes"] = dict(bytes=inb, flops=0.0)
+    a["3x3x3 conv fwd + data-grad"] = dict(bytes=cvb, flops=cvf)
+    a["3x3x3 conv weight-grad"] = dict(bytes=cwb, flops=cwf)
+    tc = [(6 ** 3, 768, 32), (12 ** 3, 32, 32), (24 ** 3, 32, 32), (6 ** 3, 768, 64), (12 ** 3, 64, 64), (6 ** 3, 768, 128),
+          (6 ** 3, 768, 128), (12 ** 3, 128, 64), (24 ** 3, 64, 32), (48 ** 3, 32, 16)]                 # (V_in, Cin, Cout) of the 10 transposed convs
+    tb = sum(2.0 * B * V * (ci + 8 * co) for V, ci, co in tc) * 3        # fwd, dgrad, wgrad each touch input + output once
+    tf = sum(2.0 * B * V * ci * co * 8 for V, ci, co in tc) * 3
+    a["2x2x2 transposed conv (voxel-tile kernels, shuffles)"] = dict(bytes=tb, flops=tf)
+    a["out conv + DiceCE"] = dict(bytes=B * 96 ** 3 * (2.0 * 16 * 3 + 4.0 * 4 * 5 + 4.0 * 2), flops=0.0)
+    return a
 
-        def timed(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(*a, **k)
-            e1.record()
-            pending.append((e0, e1) + fam_fn(*a, **k))
-            return r
-        setattr(Fn, name, timed)
-        return orig
 
-    def fam_conv3(xt, ldx, w, dims, prec, mode=0, out=None, ldo=None, accumulate=False):
-        B, D, H, W = dims
-        v = B * D * H * W
-        cout_w, cin_w = w.shape[0], w.shape[1]
-        cin, cout = (cin_w, cout_w) if mode == 0 else (cout_w, cin_w)
-        nbytes = 4.0 * v * (cin + cout) + 4.0 * w.numel() + (4.0 * v * cout if accumulate else 0.0)
-        return ("conv3_fwd_pipe_kernel (3x3x3 LDS-halo implicit GEMM, " + ("dgrad" if mode else "fwd") + ")",
-                f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27, nbytes)
+def _family_of(name):
+    for fam, rx in FAMILIES:
+        if re.search(rx, name):
+            return fam
+    return "other (packs, casts, column sums, copies, fills)"
 
-    def fam_fused(xt, ldx, w, w3, dims, prec):
-        B, D, H, W = dims
-        v = B * D * H * W
-        cout, cin = w.shape[0], w.shape[1]
-        n3 = 1 if w3 is not None else 0
-        nbytes = 4.0 * v * (cin + cout * (1 + n3)) + 4.0 * w.numel() + (4.0 * w3.numel() if n3 else 0.0)
-        return ("conv3_fwd_pipe_kernel (3x3x3 LDS-halo implicit GEMM, fwd + InstanceNorm sums" + (" + 1x1x1 conv)" if n3 else ")"),
-                f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * (27 + n3), nbytes)
 
-    def fam_wgrad(xt, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None):
-        B, D, H, W = dims
-        v = B * D * H * W
-        return ("conv3_wgrad_kernel (+reduce)", f"{cin}->{cout} ch @ {D}x{H}x{W}, B={B}", 2.0 * v * cin * cout * 27,
-                4.0 * v * (cin + cout) + 4.0 * cin * cout * 27)
-
-    saved = {"conv3": wrap("conv3", fam_conv3), "conv3_wgrad": wrap("conv3_wgrad", fam_wgrad), "conv3_fused": wrap("conv3_fused", fam_fused)}
-    try:
+def _kernel_times(run, reps=4):
+    """{kernel name: (device us per step, launches per step)} of `run()` via torch.profiler"""
+    from torch.profiler import ProfilerActivity, profile
+    run()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
         for _ in range(reps):
-            loss = crit(model(x), y)
-            loss.backward()
-            model.zero_grad(set_to_none=True)
+            run()
         torch.cuda.synchronize()
-    finally:
-        for k, v in saved.items():
-            setattr(Fn, k, v)
-    groups = collections.defaultdict(list)
-    for e0, e1, fam, label, flops, nbytes in pending:
-        groups[(fam, label)].append((e0.elapsed_time(e1), flops, nbytes))
-    tot = {k: sum(t for t, _, _ in v) for k, v in groups.items()}
-    (fam, label), _ = max(tot.items(), key=lambda kv: kv[1])
-    rows = groups[(fam, label)]
-    avg_ms = sum(t for t, _, _ in rows) / len(rows)
-    flops, nbytes = rows[0][1], rows[0][2]
+    out = {}
+    for ev in prof.key_averages():
+        t = getattr(ev, "device_time_total", None)
+        if t is None:
+            t = getattr(ev, "cuda_time_total", 0.0)
+        if t <= 0 or ev.key.startswith("hip") or ev.key.startswith("Memcpy") or ev.key.startswith("Memset"):
+            continue
+        out[ev.key] = (t / reps, ev.count / reps)
+    return out
+
+
+def _pmc_traffic(kernel_rx):
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    path = os.path.join(root, "r02_pmc_step_kernels.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    tot, n = 0.0, 0
+    for k, v in d.get("kernels", {}).items():
+        if re.search(kernel_rx, k):
+            tot += v["hbm_bytes_per_step"]
+            n += v["launches_per_step"]
+    if n == 0:
+        return None, None
+    return tot / n, "profiles/r02_pmc_step_kernels.json (" + d.get("command", "rocprofv3 --pmc") + ")"
+
+
+def step_report(pkg, step, batch, precision, ms_per_step):
+    times = _kernel_times(step.run)
+    arch = _arch(batch)
+    fam = collections.OrderedDict()
+    for name, (us, n) in times.items():
+        f = _family_of(name)
+        e = fam.setdefault(f, {"ms": 0.0, "launches": 0.0, "kernels": collections.Counter()})
+        e["ms"] += us / 1e3
+        e["launches"] += n
+        e["kernels"][name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:80]] += us / 1e3
     peak_tf = MFMA_PEAK_TFLOPS[precision]
     ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
-    if flops / nbytes > ridge:
-        bound, achieved, peak, unit = "mfma", flops / (avg_ms * 1e-3) / 1e12, peak_tf, "TFLOP/s"
-    else:
-        bound, achieved, peak, unit = "hbm", nbytes / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-    return {"kernel": fam, "shape": label, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 5), "traffic": _pmc_traffic(fam, label, precision), "avg_ms_per_launch": round(avg_ms, 4),
-            "launches_per_step": len(rows) // reps, "algorithmic_bytes_per_launch": nbytes,
-            "algorithmic_flops_per_launch": flops,
-            "share_of_conv_time": round(tot[(fam, label)] / max(sum(tot.values()), 1e-9), 4)}
-
-
-def _pmc_traffic(fam, label, precision):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc summary (tools/pmc_conv3.sh:
-    FETCH_SIZE x 2 (gfx950 half-count of 16 B/lane streams) + WRITE_SIZE, separate passes) whose "family" / "shape"
-    keys name the same kernel group; otherwise null."""
-    import glob
-    import json
-    import os
-    if precision != "bf16":
-        return None
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    for path in sorted(glob.glob(os.path.join(root, "r*_pmc_*.json"))):
-        try:
-            d = json.load(open(path))
-        except (OSError, ValueError):
-            continue
-        if d.get("family") == fam and d.get("shape") and label.startswith(d["shape"]):
-            return d.get("traffic_bytes_per_launch")
-    return None
+    table = []
+    for f, e in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        row = {"family": f, "ms_per_step": round(e["ms"], 4), "launches_per_step": round(e["launches"], 1),
+               "top_kernel": max(e["kernels"].items(), key=lambda kv: kv[1])[0]}
+        w = arch.get(f)
+        if w is not None and e["ms"] > 0:
+            sec = e["ms"] * 1e-3
+            if w["flops"] / max(w["bytes"], 1.0) > ridge:
+                row.update(bound="mfma", achieved=round(w["flops"] / sec / 1e12, 2), peak=peak_tf, unit="TFLOP/s")
+            else:
+                row.update(bound="hbm", achieved=round(w["bytes"] / sec / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
+            row["frac"] = round(row["achieved"] / row["peak"], 4)
+            row["algorithmic_bytes_per_step"] = w["bytes"]
+            row["algorithmic_flops_per_step"] = w["flops"]
+        table.append(row)
+    out = {"families": table, "kernel_time_ms_per_step": round(sum(r["ms_per_step"] for r in table), 4)}
+    dom = next((r for r in table if "bound" in r), None)
+    if dom is not None:
+        rx = dict(FAMILIES)[dom["family"]]
+        traffic, src = _pmc_traffic(rx)
+        n = max(dom["launches_per_step"], 1.0)
+        per = "bytes" if dom["bound"] == "hbm" else "flops"
+        out["roofline"] = {
+            "kernel": dom["family"] + ": " + dom["top_kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
+            "unit": dom["unit"], "frac": dom["frac"], "traffic": traffic, "traffic_source": src,
+            "avg_ms_per_launch": round(dom["ms_per_step"] / n, 5), "launches_per_step": dom["launches_per_step"],
+            "algorithmic_%s_per_launch" % per: dom["algorithmic_%s_per_step" % per] / n,
+            "share_of_step_kernel_time": round(dom["ms_per_step"] / max(out["kernel_time_ms_per_step"], 1e-9), 4),
+            "how": "device time of the family's kernels per replayed step (torch.profiler over hipGraph replays) against its analytic "
+                   "algorithmic work (tools/roofline.py:_arch)"}
+    return out
 
 
 def encoder_forward_rate(pkg, model, x_in, precision, iters=10):
@@ -150,14 +203,12 @@ def encoder_forward_rate(pkg, model, x_in, precision, iters=10):
     peak = MFMA_PEAK_TFLOPS[precision]
     return {"batch": B, "ms": round(ms, 4), "TFLOP/s": round(tf, 2), "peak_TFLOP/s": peak, "frac_of_mfma_peak": round(tf / peak, 5),
             "algorithmic_flops": flops,
-            "note": (f"batch {B} = {B * L} token rows per GEMM: launch/latency-bound, not MFMA-bound" if B * L < 2048 else
-                     f"batch {B} = {B * L} token rows per GEMM")}
+            "note": (f"batch {B} = {B * L} token rows per GEMM: 61 dependent launches, each bounded by launch boundary + the ~70 GB/s a "
+                     f"CU pulls from L2, not by MFMA rate (DESIGN.md section 5)" if B * L < 2048 else f"batch {B} = {B * L} token rows per GEMM")}
 
 
-def step_report(pkg, model, crit, x, y, precision, ms_per_step):
-    """objects bench.py merges into its JSON line"""
-    out = {"roofline": dominant_kernel_roofline(pkg, model, crit, x, y, precision)}
-    out["encoder_fwd"] = encoder_forward_rate(pkg, model, x, precision)
+def encoder_report(pkg, model, x, precision):
+    out = {"encoder_fwd": encoder_forward_rate(pkg, model, x, precision)}
     for b in (4, 8, 32):
         xb = x[:1].expand(b, -1, -1, -1, -1).contiguous()
         out[f"encoder_fwd_batch{b}"] = encoder_forward_rate(pkg, model, xb, precision, iters=5)
