@@ -626,3 +626,114 @@ def test_two_models_and_failed_backward(pkg, dev):
     assert torch.equal(fa["grad"], ga_alone)
     fa["state"].clear()
     fb["state"].clear()
+
+
+def test_encoder_checkpointing_is_exact(pkg, dev):
+    """UNETR.encoder_checkpointing (BASELINE config[3]: activation checkpointing on the encoder): the transformer blocks keep
+    only their input and recompute their forward inside backward -- same kernels on the same inputs, so loss and every gradient
+    are bit-identical to the run that keeps the activations, in both precision modes."""
+    from oracle.unetr_oracle import synthetic_volume
+    x, y = synthetic_volume(2, 1, 32, 2, seed=51)
+    xd, yd = x.to(dev), y.to(dev)
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    for precision in ("fp32", "bf16"):
+        grads = []
+        for ckpt in (False, True):
+            torch.manual_seed(13)
+            m = pkg.UNETRLogits(**C1).to(dev)
+            m.precision = precision
+            m.encoder_checkpointing = ckpt
+            loss = crit(m(xd), yd)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+        assert torch.equal(grads[0][0], grads[1][0])
+        assert grads[0][1].keys() == grads[1][1].keys()
+        for k in grads[0][1]:
+            assert torch.equal(grads[0][1][k], grads[1][1][k]), (precision, k)
+
+
+def test_c4_160_checkpointed_train_step_parity(pkg, dev):
+    """BASELINE config[3] AT ITS WORKLOAD: 160^3 input, hidden 768 / 12 heads / mlp 3072 (1000 tokens: attention chunk loop),
+    encoder activation checkpointing, batch 1 -- forward + DiceCE + backward against the fp32 CPU oracle.  fp32 mode: logits /
+    enc4 / Dice / CE within north_star's 1e-3, gradients by cosine; bf16 mode (the benched one): bf16 bounds."""
+    from oracle.unetr_oracle import OracleUNETR, oracle_dice_ce_terms, synthetic_volume
+    cfg = dict(C2, img_size=(160, 160, 160))
+    torch.manual_seed(21)
+    ref = OracleUNETR(**cfg)
+    x, y = synthetic_volume(1, 1, 160, 4, seed=23)
+    enc4_r, logits_r = ref(x)
+    d_r, c_r = oracle_dice_ce_terms(logits_r, y)
+    (d_r + c_r).backward()
+    gr = {k: p.grad for k, p in ref.named_parameters()}
+    keys = ["vit.blocks.0.attn.qkv.weight", "vit.blocks.6.mlp.linear1.weight", "vit.blocks.11.attn.out_proj.weight", "vit.norm.weight",
+            "vit.patch_embedding.patch_embeddings.1.weight", "encoder1.layer.conv2.conv.weight", "encoder3.blocks.0.conv.weight",
+            "decoder5.conv_block.conv1.conv.weight", "decoder2.conv_block.conv1.conv.weight", "decoder2.transp_conv.conv.weight",
+            "out.conv.conv.weight"]
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    for precision, tol, cmin in (("fp32", 1e-3, 0.9999), ("bf16", 5e-2, 0.98)):
+        hip = pkg.UNETR(**cfg)
+        hip.load_state_dict(ref.state_dict(), strict=True)
+        hip = hip.to(dev)
+        hip.precision = precision
+        hip.encoder_checkpointing = True
+        enc4, logits = hip(x.to(dev))
+        t = crit.terms(logits, y.to(dev))
+        t[0].backward()
+        torch.cuda.synchronize()
+        assert logits.shape == (1, 4, 160, 160, 160) and enc4.shape == (1, 128, 20, 20, 20)
+        assert relerr(logits, logits_r) < tol and relerr(enc4, enc4_r) < tol, precision
+        assert relerr(t[1], d_r) < max(tol / 5, 1e-3) and relerr(t[2], c_r) < max(tol / 5, 1e-3), precision
+        gh = dict(hip.named_parameters())
+        for k in keys:
+            assert cosine(gh[k].grad, gr[k]) > cmin, (precision, k, cosine(gh[k].grad, gr[k]))
+        for k, g in gr.items():
+            assert (g is None) == (gh[k].grad is None), k
+        del hip, enc4, logits, t
+
+
+def test_c5_ranking_pretraining_at_96(pkg, dev):
+    """BASELINE config[4] AT ITS WORKLOAD (unetr_ranking_pretraining_3d.py:238-296): a [4, 1, 96^3] batch (2 volumes x 2
+    transforms), for each of the three slice axes a 'feat' pass (Bradley-Terry loss on enc4 [4,128,12^3], everything trains) and a
+    'recon' pass (loss on the logits [4,2,96^3] = 16 slices of 18 432 features, encoder frozen) against the fp32 CPU oracle:
+    loss values for all six passes, gradients (cosine) for the two passes of slice axis 3, None-pattern of the frozen pass."""
+    from oracle.unetr_oracle import OracleUNETR, oracle_bt_loss, oracle_extract_triplets, synthetic_volume
+    cfg = dict(C2, out_channels=2)
+    torch.manual_seed(31)
+    ref = OracleUNETR(**cfg)
+    hip = pkg.UNETR(**cfg)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.to(dev)
+    hip.precision = "fp32"
+    x, _ = synthetic_volume(4, 1, 96, 2, seed=33)
+    xd = x.to(dev)
+    for axis in (2, 3, 4):
+        for stage, init_idx in (("feat", 1), ("recon", 7)):
+            ref.zero_grad()
+            hip.zero_grad()
+            grads = axis == 3
+            with torch.set_grad_enabled(grads):
+                if stage == "feat":
+                    inp_r, _ = ref(x)
+                    inp_h, _ = hip(xd)
+                else:
+                    _, inp_r = ref(x, freeze_encoder=True)
+                    _, inp_h = hip(xd, freeze_encoder=True)
+                f1, f2 = torch.split(inp_r, [2, 2], dim=0)
+                l_r = oracle_bt_loss(*oracle_extract_triplets(f1, f2, axis, init_idx), 0.1)
+                l_h = pkg.ranking_loss(inp_h, axis, init_idx, 0.1, kind="ranking")
+            assert relerr(l_h, l_r) < 1e-3, (axis, stage, float(l_h), float(l_r))
+            if not grads:
+                continue
+            l_r.backward()
+            l_h.backward()
+            gr, gh = dict(ref.named_parameters()), dict(hip.named_parameters())
+            for k, p in gr.items():
+                assert (p.grad is None) == (gh[k].grad is None), (stage, k)
+            keys = ["decoder2.conv_block.conv1.conv.weight", "decoder5.transp_conv.conv.weight", "out.conv.conv.weight"] if stage == "recon" else \
+                ["encoder4.transp_conv_init.conv.weight", "vit.blocks.9.mlp.linear1.weight", "vit.blocks.0.attn.qkv.weight",
+                 "vit.patch_embedding.patch_embeddings.1.weight"]
+            for k in keys:
+                assert cosine(gh[k].grad, gr[k].grad) > 0.999, (stage, k, cosine(gh[k].grad, gr[k].grad))
+            if stage == "recon":
+                assert gh["vit.blocks.0.attn.qkv.weight"].grad is None and gh["encoder1.layer.conv1.conv.weight"].grad is None

@@ -82,8 +82,10 @@ def _family_of(name):
     return "other (packs, casts, column sums, copies, fills)"
 
 
-def _kernel_times(run, reps=4):
-    """{kernel name: (device us per step, launches per step)} of `run()` via torch.profiler"""
+def _kernel_times(run, reps=6, once_per_step="dicece_fwd_kernel"):
+    """{kernel name: (device us per step, launches per step)} of `run()` via torch.profiler.  The tracer may drop the records
+    of a replay at either end of the window, so the number of steps actually recorded is read off a kernel that runs exactly
+    once per step (the loss forward)."""
     from torch.profiler import ProfilerActivity, profile
     run()
     torch.cuda.synchronize()
@@ -91,15 +93,22 @@ def _kernel_times(run, reps=4):
         for _ in range(reps):
             run()
         torch.cuda.synchronize()
-    out = {}
+    evs = []
     for ev in prof.key_averages():
         t = getattr(ev, "device_time_total", None)
         if t is None:
             t = getattr(ev, "cuda_time_total", 0.0)
         if t <= 0 or ev.key.startswith("hip") or ev.key.startswith("Memcpy") or ev.key.startswith("Memset"):
             continue
-        out[ev.key] = (t / reps, ev.count / reps)
-    return out
+        evs.append((ev.key, t, ev.count))
+    steps = next((c for k, t, c in evs if once_per_step in k), reps)
+    return {k: (t / steps, c / steps) for k, t, c in evs}
+
+
+def _short(name):
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    cut = min([i for i in (n.find("("),) if i > 0] or [len(n)])
+    return n[:cut][:90]
 
 
 def _pmc_traffic(kernel_rx):
@@ -128,7 +137,7 @@ def step_report(pkg, step, batch, precision, ms_per_step):
         e = fam.setdefault(f, {"ms": 0.0, "launches": 0.0, "kernels": collections.Counter()})
         e["ms"] += us / 1e3
         e["launches"] += n
-        e["kernels"][name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:80]] += us / 1e3
+        e["kernels"][_short(name)] += us / 1e3
     peak_tf = MFMA_PEAK_TFLOPS[precision]
     ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
     table = []
@@ -138,11 +147,14 @@ def step_report(pkg, step, batch, precision, ms_per_step):
         w = arch.get(f)
         if w is not None and e["ms"] > 0:
             sec = e["ms"] * 1e-3
+            f_hbm = w["bytes"] / sec / 1e9 / HBM_PEAK_GBS
+            f_mfma = w["flops"] / sec / 1e12 / peak_tf
             if w["flops"] / max(w["bytes"], 1.0) > ridge:
                 row.update(bound="mfma", achieved=round(w["flops"] / sec / 1e12, 2), peak=peak_tf, unit="TFLOP/s")
             else:
                 row.update(bound="hbm", achieved=round(w["bytes"] / sec / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
             row["frac"] = round(row["achieved"] / row["peak"], 4)
+            row["frac_of_hbm_peak"], row["frac_of_mfma_peak"] = round(f_hbm, 4), round(f_mfma, 4)
             row["algorithmic_bytes_per_step"] = w["bytes"]
             row["algorithmic_flops_per_step"] = w["flops"]
         table.append(row)
