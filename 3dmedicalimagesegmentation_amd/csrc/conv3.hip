@@ -32,6 +32,26 @@ constexpr int HZ = 6, HY = 6, HX = 18;          // halo
 constexpr int NHALO = HZ * HY * HX;             // 648
 constexpr int NVOX = TZ * TY * TX;              // 256
 
+// LDS window layouts (tools/lds_conflicts.py models the bank conflicts of every fragment read; round 1's padded pitches --
+// 48 / 80 bytes per voxel -- cost exactly 2x the conflict-free cycles on all of them, which is what the PMC profile showed:
+// SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE):
+//   LAY 0  plain rows, no padding.  Pair-mode forward window (32 B per voxel): the 16 lanes of a ds_read_b128 group read
+//          16 consecutive 16-byte slots -- conflict-free as it is.
+//   LAY 1  64-byte voxels (one k-block of channels, forward slab mode): 16-byte chunk c of the voxel at window column hx is
+//          stored in chunk slot c ^ (2 * ((hx >> 2) & 1)).
+//   LAY 2  32-byte voxels read by ds_read_b64_tr_b16 (weight gradient, 16-channel slab): the voxel at column hx is stored at
+//          column hx ^ ((hx & 8) >> 1), i.e. the two halves of columns 8..15 swap, so the 8 voxels a 32-lane half
+//          addresses (x .. x+3 and x+8 .. x+11) cover all 64 banks.
+constexpr int FPITCH = 64;  // one k-block of channels per halo voxel (LAY 1)
+__device__ __forceinline__ int lay_flip(int h) { return h ^ ((h & 8) >> 1); }
+template <int LAY>
+__device__ __forceinline__ int lay_off(int hv, int ch, int pitch) {
+    if constexpr (LAY == 0) return hv * pitch + ch * 16;
+    const int hx = hv % HX;
+    if constexpr (LAY == 1) return hv * pitch + ((ch ^ (((hx >> 2) & 1) << 1)) << 4);
+    return (hv - hx + lay_flip(hx)) * pitch + ch * 16;
+}
+
 template <class P> struct ElemOf;
 template <> struct ElemOf<PrecF32> { typedef float type; };
 template <> struct ElemOf<PrecBF16> { typedef uint16_t type; };
@@ -68,7 +88,7 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 // 96^3 convs at 1.1 TB/s).  vec: 16-byte loads (aligned, Cin % 4 == 0); otherwise predicated scalar loads.
 // XM = how the input tensor is stored: 0 fp32, predicated scalar loads (single-channel image); 1 fp32, 16-byte loads of four
 // channels; 2 bf16 (bf16 precision mode: feature maps are stored as bf16), one 16-byte load = the 8 channels of a piece.
-template <class P, int NCH, int XM>
+template <class P, int NCH, int XM, int LAY = 0>
 __device__ __forceinline__ void stage_halo(const void* __restrict__ xv, long ldx, int b, int z0, int y0, int x0, int D, int H, int W,
                                            int c0, int Cin, int pitch, char* halo) {
     constexpr int CH = P::CH, TOTAL = NHALO * NCH, ITERS = (TOTAL + 255) / 256, SB = 6, NQ = CH / 4;
@@ -93,7 +113,7 @@ __device__ __forceinline__ void stage_halo(const void* __restrict__ xv, long ldx
                 const int id = threadIdx.x + (it0 + j) * 256;
                 if (it0 + j < ITERS && id < TOTAL) {
                     const int hv = id / NCH, ch = id - hv * NCH;
-                    *(u32x4*)(halo + hv * pitch + ch * 16) = buf[j];
+                    *(u32x4*)(halo + lay_off<LAY>(hv, ch, pitch)) = buf[j];
                 }
             }
         }
@@ -138,7 +158,7 @@ __device__ __forceinline__ void stage_halo(const void* __restrict__ xv, long ldx
                 float v[CH];
 #pragma unroll
                 for (int c4 = 0; c4 < NQ; ++c4) { v[4 * c4] = buf[j][c4][0]; v[4 * c4 + 1] = buf[j][c4][1]; v[4 * c4 + 2] = buf[j][c4][2]; v[4 * c4 + 3] = buf[j][c4][3]; }
-                *(u32x4*)(halo + hv * pitch + ch * 16) = P::pack(v);
+                *(u32x4*)(halo + lay_off<LAY>(hv, ch, pitch)) = P::pack(v);
             }
         }
     }
@@ -163,8 +183,6 @@ __device__ __forceinline__ void tile_coords(int id, int total, int ntx, int nty,
     ty = yb * YB + yi;
 }
 
-constexpr int FPITCH = 80;  // 64 B of channels (one k-block) + 16 B pad per halo voxel
-
 template <class P, int NTB, int XM>
 __global__ void __launch_bounds__(256)
 conv3_fwd_kernel(const void* __restrict__ x, long ldx, const char* __restrict__ wp, typename ActOf<P>::type* __restrict__ y, long ldy, int accumulate,
@@ -186,7 +204,7 @@ conv3_fwd_kernel(const void* __restrict__ x, long ldx, const char* __restrict__ 
 
     for (int slab = 0; slab < nslab; ++slab) {
         __syncthreads();
-        stage_halo<P, 4, XM>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, FPITCH, halo);
+        stage_halo<P, 4, XM, 1>(x, ldx, b, z0, y0, x0, D, H, W, slab * SL, Cin, FPITCH, halo);
         __syncthreads();
         // B fragment of (tap, slab, n-tile j): 16 bytes at wp[((tap*nslab+slab)*Cout + n)*64 + g*16].
         // Fragments are prefetched one GROUP of GT taps ahead (L1/L2 latency ~ a few hundred cycles must hide
@@ -210,7 +228,7 @@ conv3_fwd_kernel(const void* __restrict__ x, long ldx, const char* __restrict__ 
             for (int t = 0; t < GT; ++t) {
                 const int tap = tg * GT + t;
                 const int dz = tap / 9, rem = tap - dz * 9, dy = rem / 3, dx = rem - dy * 3;
-                const char* hbase = halo + ((((wv + dz) * HY + dy) * HX) + (r + dx)) * FPITCH + g * 16;
+                const char* hbase = halo + (((wv + dz) * HY + dy) * HX) * FPITCH + lay_off<1>(r + dx, g, FPITCH);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     u32x4 a = *(const u32x4*)(hbase + i * HX * FPITCH);
@@ -340,7 +358,7 @@ __device__ __forceinline__ void halo_load(HaloRegs<P, NCH>& R, const void* __res
     R.okbits = bits;
 }
 
-template <class P, int NCH, int XM = 1>
+template <class P, int NCH, int XM = 1, int LAY = 0>
 __device__ __forceinline__ void halo_store(const HaloRegs<P, NCH>& R, int pitch, char* halo) {
     constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
 #pragma unroll
@@ -360,7 +378,7 @@ __device__ __forceinline__ void halo_store(const HaloRegs<P, NCH>& R, int pitch,
             // zero the out-of-window pieces on the PACKED words (dword d holds elements of piece d * NQ / 4)
 #pragma unroll
             for (int d = 0; d < 4; ++d) w[d] = ((R.okbits >> (j * NQ + d * NQ / 4)) & 1u) ? w[d] : 0u;
-            *(u32x4*)(halo + hv * pitch + ch * 16) = w;
+            *(u32x4*)(halo + lay_off<LAY>(hv, ch, pitch)) = w;
         }
     }
 }
@@ -425,9 +443,9 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                       float* __restrict__ part, const char* __restrict__ wp3, typename ActOf<P>::type* __restrict__ y3, long ldy3,
                       float* __restrict__ part3, int K3) {
     typedef typename ActOf<P>::type YT;
-    constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16 + 16;
+    constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16, LAY = PAIR ? 0 : 1;
     __shared__ __attribute__((aligned(16))) char halo[NHALO * PITCH];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NTB;
     const int nslab = PAIR ? 1 : (Cin + SL - 1) / SL;
 
@@ -506,7 +524,7 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 
         for (int slab = 0; slab < nslab; ++slab) {
             __syncthreads();                       // everyone is done reading the previous window
-            halo_store<P, NCH, XM>(R, PITCH, halo);    // (waits for the prefetched loads)
+            halo_store<P, NCH, XM, LAY>(R, PITCH, halo);    // (waits for the prefetched loads)
             __syncthreads();
             {   // prefetch the next (tile, slab) window; it lands while the MFMAs below run
                 int ntile = tile, nslb = slab + 1;
@@ -541,6 +559,8 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                 }
             } else {
                 constexpr int GT = NTB <= 2 ? 3 : 1, NG = 27 / GT;   // small groups: the halo prefetch registers are live here
+                // per-lane byte offset of (window column r + dx, chunk g) for the three dx of a tap row (LAY 1 swizzle folded in)
+                const int xo3[3] = {lay_off<LAY>(r, g, PITCH), lay_off<LAY>(r + 1, g, PITCH), lay_off<LAY>(r + 2, g, PITCH)};
                 const char* wbase = wp + ((long)slab * Cout + nt0 * 16 + r) * 64 + g * 16;
                 const long wtap = (long)nslab * Cout * 64;
                 u32x4 bcur[GT][NTB], bnxt[GT][NTB];
@@ -563,7 +583,9 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                     for (int t = 0; t < GT; ++t) {
                         const int tap = tg * GT + t;
                         const int dz = tap / 9, rem = tap - dz * 9, dy = rem / 3, dx = rem - dy * 3;
-                        const char* hbase = halo + ((((wv + dz) * HY + dy) * HX) + (r + dx)) * PITCH + g * 16;
+                        // (GT == 3: dx is the unrolled t; otherwise a wave-uniform runtime value -> selects, never an indexed array)
+                        const int xo = GT == 3 ? xo3[t % 3] : (dx == 0 ? xo3[0] : (dx == 1 ? xo3[1] : xo3[2]));
+                        const char* hbase = halo + (((wv + dz) * HY + dy) * HX) * PITCH + xo;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
@@ -659,7 +681,7 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
             }
             if constexpr (late3) {
                 // the window of this tile is still in LDS (the next halo_store waits behind the barrier at the loop top)
-                const char* hbase = halo + ((((wv + 1) * HY + 1) * HX) + (r + 1)) * PITCH + g * 16;      // centre tap
+                const char* hbase = halo + (((wv + 1) * HY + 1) * HX) * PITCH + lay_off<LAY>(r + 1, g, PITCH);      // centre tap
                 f32x4 a3[4][NTB];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -715,8 +737,12 @@ template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
     static constexpr int ES = sizeof(T);
     // image pitches: 16 B of padding when it is free; with the second dy image (HAS3) in bf16 the padding is dropped
     // so that two workgroups still fit a CU (measured: 76 KB per workgroup = one workgroup per CU, 1.35x slower)
-    static constexpr int PX = 16 * CIS * ES + ((HAS3 && ES == 2) ? 0 : 16);   // halo image pitch (16*CIS channels)
-    static constexpr int PY = 16 * ES + ((HAS3 && ES == 2) ? 8 : 16);        // dy image pitch (16 channels)
+    // FLIP: the bf16 16-channel slab (every weight gradient of the network by default): unpadded 32-byte voxels in the
+    // LAY 2 column order -- both transposing reads conflict-free (tools/lds_conflicts.py), 29 KB per workgroup
+    static constexpr bool FLIP = ES == 2 && CIS == 1;
+    static constexpr int PX = FLIP ? 32 : 16 * CIS * ES + ((HAS3 && ES == 2) ? 0 : 16);   // halo image pitch (16*CIS channels)
+    static constexpr int PY = FLIP ? 32 : 16 * ES + ((HAS3 && ES == 2) ? 8 : 16);        // dy image pitch (16 channels)
+    static constexpr int LAY = FLIP ? 2 : 0;
     static constexpr int KV = 4 * P::CH;      // voxels per MFMA k-block (32 bf16 / 16 f32)
     static constexpr int NKB = NVOX / KV;
     static constexpr int NU = 27 * CIS;                       // (tap, ci-tile) units
@@ -727,7 +753,7 @@ template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
 // XMX: storage of x (see stage_halo); dy / dy3 are feature-map gradients: ActOf<P> (bf16 in bf16 mode -- VECY is then moot:
 // a 16-channel dy row is two 16-byte pieces)
 template <class P, int XMX, bool VECY, bool HAS3, int CIS, bool PIPE_OK>
-__global__ void __launch_bounds__(256, CIS == 1 ? (HAS3 ? 2 : 3) : 1)   // CIS = 1: 41-43 KB of LDS -> three workgroups per CU (two with the second dy image: 168 registers would spill)
+__global__ void __launch_bounds__(256, CIS == 1 ? ((HAS3 && !WgCfg<P, HAS3, CIS>::FLIP) ? 2 : 3) : 1)   // CIS = 1: 29-43 KB of LDS -> three workgroups per CU (two for the fp32 variant with the second dy image: 168 registers would spill)
 conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>::type* __restrict__ dy, long lddy, float* __restrict__ part,
                    const typename ActOf<P>::type* __restrict__ dy3, long lddy3, float* __restrict__ part3,
                    int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
@@ -742,16 +768,41 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     char* yimg = lds + NHALO * C::PX;
     char* y3img = yimg + NVOX * C::PY;
     constexpr int nunits = C::NUX;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, g = lane >> 4;
     const int ci0 = blockIdx.y * 16 * CIS, co0 = blockIdx.z * 16;
     // per-unit LDS byte offsets of the shifted window (wave-uniform)
+    // FLIP layout: the column part of the address is per lane AND per tap column dx (the LAY 2 permutation is not a shift):
+    // the three candidates of this lane's two voxel rows are formed once (they do not depend on the k-block: v & 15 is
+    // (8g + q) & 15 for every kb), the per-unit choice is a wave-uniform select
     int uoff[WG_UPW];
 #pragma unroll
     for (int ui = 0; ui < WG_UPW; ++ui) {
         int u = wv + 4 * ui;
         int tap = u >= WG_UNITS ? 13 : (u / CIS), cit = u >= WG_UNITS ? u - WG_UNITS : u % CIS;
         int dz = tap / 9, rem = tap - dz * 9, dyy = rem / 3, dx = rem - dyy * 3;
-        uoff[ui] = ((dz * HY + dyy) * HX + dx) * C::PX + cit * 16 * C::ES;
+        uoff[ui] = ((dz * HY + dyy) * HX + (C::FLIP ? 0 : dx)) * C::PX + cit * 16 * C::ES;
+    }
+    // unit ui of wave wv handles tap wv + 4 ui, i.e. tap column dx = (wv + ui) % 3: the three column offsets are rotated
+    // ONCE by the wave's phase, so unit ui simply takes entry ui % 3 (a compile-time index), and every per-lane address part
+    // of the transposing reads -- lane row (g >> 1), 8-byte piece p, permuted column -- is summed here, outside the loops
+    int xs0[3] = {0, 0, 0}, xs1[3] = {0, 0, 0}, xc0 = 0, xc1 = 0, ylane0 = 0, ylane1 = 0;
+    if constexpr (C::FLIP) {
+        const int q = c >> 2, p = c & 3;
+        const int xl = (8 * g + q) & 15;
+        const int lane_zy = (g >> 1) * HX * C::PX + 8 * p;             // the k-block's second voxel row for lane groups 2, 3
+        int t0[3], t1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { t0[d] = lay_flip(xl + d) * C::PX + lane_zy; t1[d] = lay_flip(xl + 4 + d) * C::PX + lane_zy; }
+        const int w3 = wv % 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int d = (w3 + j) % 3;                 // wave-uniform
+            xs0[j] = d == 0 ? t0[0] : (d == 1 ? t0[1] : t0[2]);
+            xs1[j] = d == 0 ? t1[0] : (d == 1 ? t1[1] : t1[2]);
+        }
+        xc0 = t0[1]; xc1 = t1[1];                        // centre tap (the 1x1x1 units)
+        ylane0 = lay_flip(8 * g + q) * C::PY + 8 * p;
+        ylane1 = lay_flip(8 * g + q + 4) * C::PY + 8 * p;
     }
     f32x4 acc[WG_UPW];
 #pragma unroll
@@ -796,7 +847,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
             const int id = threadIdx.x + j * 256;
             const int v = id / YCH, ch = id - v * YCH;
             if constexpr (CH == 8) {
-                *(u32x4*)(img + v * C::PY + ch * 16) = __builtin_bit_cast(u32x4, buf[j][0]);
+                *(u32x4*)(img + (C::FLIP ? lay_flip(v) : v) * C::PY + ch * 16) = __builtin_bit_cast(u32x4, buf[j][0]);
             } else {
                 float vals[CH];
 #pragma unroll
@@ -825,7 +876,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
         if constexpr (PIPE) {
-            halo_store<P, 16 / CH, XMX>(R, C::PX, ximg);
+            halo_store<P, 16 / CH, XMX, C::LAY>(R, C::PX, ximg);
             store_dy(ybuf, yimg);
             if constexpr (HAS3) store_dy(y3buf, y3img);
             __syncthreads();
@@ -838,7 +889,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
                 if constexpr (HAS3) load_dy(dy3, lddy3, ab, az * TZ, ay * TY, ax * TX, y3buf);
             }
         } else {
-            stage_halo<P, 16 * CIS / CH, XMX>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
+            stage_halo<P, 16 * CIS / CH, XMX, C::LAY>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
             load_dy(dy, lddy, b, z0, y0, x0, ybuf);
             store_dy(ybuf, yimg);
             if constexpr (HAS3) { load_dy(dy3, lddy3, b, z0, y0, x0, y3buf); store_dy(y3buf, y3img); }
@@ -846,7 +897,35 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
         }
 
         for (int kb = 0; kb < C::NKB; ++kb) {
-            if constexpr (CH == 8) {
+            if constexpr (CH == 8 && C::FLIP) {
+                // bf16, 16-channel slab, conflict-free layout: every per-lane address part is k-block independent (formed once
+                // before the loop: ylane0/1, xs0/1[3]); per read one add of a wave-uniform (k-block, unit) offset
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const int ykb = kb * 32 * C::PY;
+                s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(yimg + ykb + ylane0));
+                s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(yimg + ykb + ylane1));
+                s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                const u32x4 afrag = __builtin_bit_cast(u32x4, a8);
+                u32x4 afrag3 = afrag;
+                if constexpr (HAS3) {
+                    s16x4 clo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + ykb + ylane0));
+                    s16x4 chi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + ykb + ylane1));
+                    s16x8 c8 = {clo[0], clo[1], clo[2], clo[3], chi[0], chi[1], chi[2], chi[3]};
+                    afrag3 = __builtin_bit_cast(u32x4, c8);
+                }
+                const int xkb = ((kb >> 1) * HY + (kb & 1) * 2) * HX * C::PX;       // window row of the k-block's first voxel row
+#pragma unroll
+                for (int ui = 0; ui < WG_UPW; ++ui) {
+                    if (wv + 4 * ui < nunits) {
+                        const bool ext1 = HAS3 && ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS;     // wave-uniform
+                        const int uo = xkb + uoff[ui];
+                        s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + uo + (ext1 ? xc0 : xs0[ui % 3])));
+                        s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + uo + (ext1 ? xc1 : xs1[ui % 3])));
+                        s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                        P::mma(acc[ui], ext1 ? afrag3 : afrag, __builtin_bit_cast(u32x4, b8));
+                    }
+                }
+            } else if constexpr (CH == 8) {
                 // bf16: k-block = 32 voxels; lane (c = 4q+p, g) addresses voxel rows 8g+q and 8g+4+q
                 const int q = c >> 2, p = c & 3;
                 const int v0 = kb * 32 + 8 * g + q, v1 = v0 + 4;
@@ -1133,7 +1212,7 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
     // persistent workgroups: all of them resident at once (3 per CU with the 16-channel slab, else 2 rounds of 2 per CU)
-    long G = std::max<long>(1, (cis == 1 ? (dy3 ? 512 : 768) : 1024) / ((long)nci * nco));
+    long G = std::max<long>(1, (cis == 1 ? ((dy3 && !B16) ? 512 : 768) : 1024) / ((long)nci * nco));
     G = std::min(G, ntiles);
     const long n3 = dy3 ? (long)Cin * Cout : 0;
     while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;
