@@ -400,27 +400,32 @@ __global__ void conv3_pack_pair_kernel(const float* __restrict__ w, uint16_t* __
 // valid output voxels per channel tile across the tiles its workgroup walks; a wave's tiles come in non-decreasing batch
 // order (tile_coords), so the sums are flushed -- reduced over the four lane groups, written by lane group 0 to row
 // (b, workgroup, wave) of part[B][rows][2][Cout] -- when the batch index changes and at the end of the walk.
+// (The persistent kernel runs its MFMAs with swapped operands -- weights as A, window as B -- so the accumulator tile is
+// the transposed one: lane (r = lane & 15, g = lane >> 4) holds the FOUR consecutive channels 4g..4g+3 of output voxel
+// column r.  A row of 16 voxels is then stored as one 512-byte (bf16) / 1-KiB (fp32) contiguous run by ONE store instruction
+// of 8 / 16 bytes per lane, instead of sixteen 2-byte-per-lane scatters.)
 template <int NTB>
-__device__ __forceinline__ void stats_add(const f32x4 (&acc)[4][NTB], const bool (&okv)[4][4], float (&s1)[NTB], float (&s2)[NTB]) {
+__device__ __forceinline__ void stats_add(const f32x4 (&acc)[4][NTB], const bool (&okv)[4], f32x4 (&s1)[NTB], f32x4 (&s2)[NTB]) {
 #pragma unroll
     for (int j = 0; j < NTB; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const float v = okv[i][rr] ? acc[i][j][rr] : 0.f;
-                s1[j] += v; s2[j] += v * v;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = okv[i] ? acc[i][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s1[j] += v; s2[j] += v * v;
+        }
 }
 template <int NTB>
-__device__ __forceinline__ void stats_flush(float (&s1)[NTB], float (&s2)[NTB], float* __restrict__ prow, int Cout, int ch0, int g) {
+__device__ __forceinline__ void stats_flush(f32x4 (&s1)[NTB], f32x4 (&s2)[NTB], float* __restrict__ prow, int Cout, int ch0, int r) {
+    // sum over the 16 voxel columns (lanes with equal g), lane r == 0 of each group writes its four channels
 #pragma unroll
     for (int j = 0; j < NTB; ++j) {
-        float a = s1[j], q = s2[j];
-        a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
-        a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
-        if (g == 0) { prow[ch0 + j * 16] = a; prow[Cout + ch0 + j * 16] = q; }
-        s1[j] = 0.f; s2[j] = 0.f;
+        f32x4 a = s1[j], q = s2[j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += __shfl_xor(a[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
+        if (r == 0) { *(f32x4*)(prow + ch0 + j * 16) = a; *(f32x4*)(prow + Cout + ch0 + j * 16) = q; }
+        s1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j];
     }
 }
 
@@ -464,14 +469,14 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)(nt0 + j) * 16 + r) * 64 + g * 16);
     }
     constexpr bool STATS = FUSE >= 1 && FUSE <= 3;
-    float rs1[STATS ? NTB : 1], rs2[STATS ? NTB : 1], rt1[any3 ? NTB : 1], rt2[any3 ? NTB : 1];
+    f32x4 rs1[STATS ? NTB : 1], rs2[STATS ? NTB : 1], rt1[any3 ? NTB : 1], rt2[any3 ? NTB : 1];
     if constexpr (STATS) {
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) { rs1[j] = 0.f; rs2[j] = 0.f; }
+        for (int j = 0; j < NTB; ++j) { rs1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; rs2[j] = rs1[j]; }
     }
     if constexpr (any3) {
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) { rt1[j] = 0.f; rt2[j] = 0.f; }
+        for (int j = 0; j < NTB; ++j) { rt1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; rt2[j] = rt1[j]; }
     }
     int cur_b = -1;
     const long srows = (long)gridDim.x * 4;       // partial rows per batch item
@@ -515,8 +520,8 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         if constexpr (STATS) {
             if (b != cur_b) {
                 if (cur_b >= 0) {
-                    stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
-                    if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+                    stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
+                    if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
                 }
                 cur_b = b;
             }
@@ -548,11 +553,11 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                     for (int i = 0; i < 4; ++i) {
                         u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, wres[tp][j]);
+                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], wres[tp][j], a);
                         if constexpr (has3) {
                             if (tp == 6) {             // w3res is zero on the tap-12 half of the K range
 #pragma unroll
-                                for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], a, w3res[j]);
+                                for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
                             }
                         }
                     }
@@ -590,11 +595,11 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                         for (int i = 0; i < 4; ++i) {
                             u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
 #pragma unroll
-                            for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], a, bcur[t][j]);
+                            for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], bcur[t][j], a);
                             if constexpr (has3) {
                                 if (tap == 13) {
 #pragma unroll
-                                    for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], a, w3res[j]);
+                                    for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
                                 }
                             }
                         }
@@ -608,18 +613,17 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         }
         const int zo = z0 + wv;
         {
-            // 16 voxel rows x NTB channel tiles per lane; out-of-volume voxels are clamped to voxel 0 of the tile row
-            // for the (batched, unconditional) read of the accumulate path and skipped on store
-            YT* yrow[4][4];
-            bool okv[4][4];
+            // this lane's voxel column x0 + r of the four output rows; out-of-volume voxels are clamped to voxel 0 of the tensor for
+            // the (batched, unconditional) read of the accumulate path and skipped on store
+            YT* yrow[4];
+            bool okv[4];
+            const int xo = x0 + r;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int yo = y0 + i, xo = x0 + 4 * g + rr;
-                    okv[i][rr] = zo < D && yo < H && xo < W;
-                    yrow[i][rr] = okv[i][rr] ? y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy + nt0 * 16 + r : y + nt0 * 16 + r;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int yo = y0 + i;
+                okv[i] = zo < D && yo < H && xo < W;
+                yrow[i] = (okv[i] ? y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy : y) + nt0 * 16 + 4 * g;
+            }
             if constexpr (FUSE == 4) {
                 // acc += x3[voxel, :] . w3: A rows = the 16 x-positions of output row i (lane r), chunk g of each 64-byte k-block
                 const YT* x3 = y3;
@@ -639,44 +643,37 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], av[i], w3f[j]);
+                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], w3f[j], av[i]);
                     }
                 }
             }
             if (accumulate) {
+                f32x4 old[4][NTB];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float old[4][NTB];
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
+                    for (int j = 0; j < NTB; ++j) old[i][j] = Io<YT>::ld4(yrow[i] + j * 16);
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) old[rr][j] = Io<YT>::ld1(yrow[i][rr] + j * 16);
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) Io<YT>::st1(yrow[i][rr] + j * 16, acc[i][j][rr] + old[rr][j]);
-                }
+                    for (int j = 0; j < NTB; ++j)
+                        if (okv[i]) Io<YT>::st4(yrow[i] + j * 16, acc[i][j] + old[i][j]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) Io<YT>::st1(yrow[i][rr] + j * 16, acc[i][j][rr]);
+                    for (int j = 0; j < NTB; ++j)
+                        if (okv[i]) Io<YT>::st4(yrow[i] + j * 16, acc[i][j]);
             }
             if constexpr (STATS) stats_add<NTB>(acc, okv, rs1, rs2);
             if constexpr (has3) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    YT* q = y3 + (yrow[i] - y);          // same pitch as y (checked by the host)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        YT* q = y3 + (yrow[i][rr] - y);          // same pitch as y (checked by the host)
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) Io<YT>::st1(q + j * 16, acc3[i][j][rr]);
-                    }
+                    for (int j = 0; j < NTB; ++j)
+                        if (okv[i]) Io<YT>::st4(q + j * 16, acc3[i][j]);
+                }
                 stats_add<NTB>(acc3, okv, rt1, rt2);
             }
             if constexpr (late3) {
@@ -689,26 +686,24 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 #pragma unroll
                     for (int j = 0; j < NTB; ++j) {
                         a3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        P::mma(a3[i][j], a, w3res[j]);
+                        P::mma(a3[i][j], w3res[j], a);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    YT* q = y3 + (yrow[i] - y);
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        YT* q = y3 + (yrow[i][rr] - y);
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j)
-                            if (okv[i][rr]) Io<YT>::st1(q + j * 16, a3[i][j][rr]);
-                    }
+                    for (int j = 0; j < NTB; ++j)
+                        if (okv[i]) Io<YT>::st4(q + j * 16, a3[i][j]);
+                }
                 stats_add<NTB>(a3, okv, rt1, rt2);
             }
         }
     }
     if constexpr (STATS) {
         if (cur_b >= 0) {
-            stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
-            if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + r, g);
+            stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
+            if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
         }
     }
 }
@@ -1133,6 +1128,8 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
         // persistent, software-pipelined kernel: a few resident workgroups per CU walk the tiles
         const bool pair = use_pair<P>(Cin);
         if (B16 && xm != 2 && !pair) return UNETR_ERR_UNSUPPORTED;   // fp32 input in bf16 mode = the image: pair layout only
+        // the transposed accumulator tile is stored four channels (8 / 16 bytes) per lane
+        if ((ldy & 3) || ((uintptr_t)y & (B16 ? 7 : 15)) || (fz && fz->k3 == 0 && fz->y3 && ((uintptr_t)fz->y3 & (B16 ? 7 : 15)))) return UNETR_ERR_UNSUPPORTED;
         if (pair && ntb > 2) ntb = 2;
         const long cap = 512;   // 2 resident workgroups per CU (VGPR-limited); more would queue behind them
         dim3 pgrid((unsigned)std::min<long>(spatial, cap), ntn / ntb);

@@ -127,6 +127,7 @@ def test_logits_only_and_train_step(pkg, dev):
     ref = OracleUNETR(**C1)
     hip = pkg.UNETRLogits(**C1)
     hip.load_state_dict(ref.state_dict(), strict=True)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
     hip = hip.to(dev)
     x, y = synthetic_volume(1, 1, 32, 2, seed=3)
     o_ref = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-5)
@@ -141,8 +142,13 @@ def test_logits_only_and_train_step(pkg, dev):
         o_hip.step()
         o_hip.zero_grad()
         assert relerr(loss, l_ref) < 1e-3
-    sd_r, sd_h = ref.state_dict(), hip.state_dict()
-    assert relerr(sd_h["decoder2.conv_block.conv1.conv.weight"], sd_r["decoder2.conv_block.conv1.conv.weight"]) < 1e-3
+    # the two AdamW steps moved the weights the same way.  (Compared as update DIRECTION: Adam's first steps are ~ lr * sign(g),
+    # so a gradient element near zero may flip its whole 1e-4 step on a last-bit difference -- an element-wise bound on the
+    # weights themselves, relative to max |w| ~ 3e-2, sits right at that noise level.)
+    k = "decoder2.conv_block.conv1.conv.weight"
+    w0 = sd0[k]
+    du_r, du_h = ref.state_dict()[k] - w0, hip.state_dict()[k].cpu() - w0
+    assert cosine(du_h, du_r) > 0.99 and relerr(hip.state_dict()[k], ref.state_dict()[k]) < 1e-2
 
 
 def test_flat_buffers_match_per_tensor_path(pkg, dev):
