@@ -2,8 +2,14 @@
 // Reference semantics: MONAI TransformerBlock / SABlock / MLPBlock as built at /root/reference/unetr.py:78-89
 // (x + attn(norm1(x)); x + mlp(norm2(x)); nn.LayerNorm eps 1e-5; exact-erf GELU).
 //
-// At 432 rows every per-layer GEMM is a single wave of workgroups whose time is launch boundary + pipeline fill + the
-// L2 -> LDS traffic of its tile, so the lever is the NUMBER of dependent launches and the bytes each workgroup pulls:
+// MEASURED NEGATIVE RESULT, OFF BY DEFAULT (functional.fused_ln_enabled): on MI355X at 432 rows this kernel costs 13.3 us for
+// norm1 -> qkv against 3.1 (LayerNorm) + 6.6 (GEMM) as two launches, 17.5 against 3.1 + 10.5 for norm2 -> linear1.  Every
+// column-tile workgroup re-reads its 64 rows as fp32 (twice the bytes of the bf16 rows the plain GEMM stages) through the
+// ~70 GB/s one CU gets from L2, which costs more than the launch boundary it removes.  Kept, tested, as an option
+// (UNETR_AMD_FUSED_LN=1) and as the record of the experiment.
+//
+// The idea it tests: at 432 rows every per-layer GEMM is a single wave of workgroups whose time is launch boundary +
+// pipeline fill + the L2 -> LDS traffic of its tile, so remove a dependent launch by making LayerNorm the GEMM's prologue:
 //
 //   unetr_ln_gemm_bf16   y = epilogue(LayerNorm(x) W^T + b)     LayerNorm is the GEMM's prologue
 //       one workgroup = 64 rows x BN columns, 8 waves.  The workgroup's weight tile starts streaming into an LDS ring by
