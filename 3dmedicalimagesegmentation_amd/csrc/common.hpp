@@ -97,6 +97,12 @@ template <> struct Io<float> {
     static constexpr int W = 4;       // elements per 16-byte access
     static __device__ __forceinline__ void ldw(const float* p, float (&v)[4]) { const f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     static __device__ __forceinline__ void stw(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+    // the 16 bytes as loaded (kept packed while several loads are in flight) and their W elements
+    static __device__ __forceinline__ u32x4 ldraw(const float* p) { return *(const u32x4*)p; }
+    static __device__ __forceinline__ void unpack(u32x4 r, float (&v)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const uint32_t t = r[e]; v[e] = __builtin_bit_cast(float, t); }     // (bit_cast of the element lvalue itself reads element 0)
+    }
     static __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
     static __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
     static __device__ __forceinline__ float ld1(const float* p) { return *p; }
@@ -113,6 +119,14 @@ template <> struct Io<uint16_t> {
     static __device__ __forceinline__ void stw(uint16_t* p, const float (&v)[8]) {
         const f32x8 t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
         *(bf16x8*)p = __builtin_convertvector(t, bf16x8);
+    }
+    static __device__ __forceinline__ u32x4 ldraw(const uint16_t* p) { return *(const u32x4*)p; }
+    static __device__ __forceinline__ void unpack(u32x4 r, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, r[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xffff0000u);
+        }
     }
     static __device__ __forceinline__ f32x4 ld4(const uint16_t* p) { return __builtin_convertvector(*(const bf16x4*)p, f32x4); }
     static __device__ __forceinline__ void st4(uint16_t* p, f32x4 v) { *(bf16x4*)p = __builtin_convertvector(v, bf16x4); }

@@ -28,6 +28,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define LDS_AS __attribute__((address_space(3)))
 
 constexpr int TZ = 4, TY = 4, TX = 16;          // output tile
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
 constexpr int HZ = 6, HY = 6, HX = 18;          // halo
 constexpr int NHALO = HZ * HY * HX;             // 648
 constexpr int NVOX = TZ * TY * TX;              // 256
@@ -441,8 +443,17 @@ __device__ __forceinline__ void stats_flush(f32x4 (&s1)[NTB], f32x4 (&s2)[NTB], 
 //   the 1x1x1 branch) multiplied by a 1x1x1 weight matrix in the tile epilogue: dx = conv3x3x3^T(dc1) + conv1x1x1^T(dc3) in
 //   one pass, instead of a GEMM writing dx followed by an accumulating conv that re-reads it.  x3 fragments are loaded
 //   straight from global memory in MFMA operand shape (16 voxels x one 16-byte chunk per lane group).
-template <class P, int NTB, bool PAIR, int XM, int FUSE>
-__global__ void __launch_bounds__(256, (FUSE == 2 ? (PAIR && NTB == 1) : (FUSE == 3 ? NTB == 1 : (FUSE == 1 && (NTB == 1 || (!PAIR && NTB == 2))))) ? 2 : 1)
+// WL (slab mode only) = number of slab-weight images kept in LDS, filled by LDS-DMA (27 x NTB KB each: lane (r, g) of the
+// (tap, j) piece holds the 16 bytes that same lane feeds to the MFMA, so the fragment read is a linear ds_read_b128).
+//   WL 1: Cin <= one slab -- the weights are loaded once per workgroup and serve every tile it walks;
+//   WL 2: two slabs -- both resident; more -- double buffer, the DMA of the next slab's weights runs under this slab's MFMAs.
+//   WL 0: weights from global / L2 per tap group with a one-group register prefetch (kept for NTB 4 with several slabs, where
+//         two images do not fit).  That path exposes an L2 round trip per group of three taps: at 12^3 x 256 channels, where
+//         one workgroup per CU leaves nothing to hide it, a slab took 10 us for 108 MFMAs per wave.
+template <int NTB, int WL> constexpr int conv_pipe_lds_bytes(int pitch) { return NHALO * pitch + WL * 27 * NTB * 1024; }
+template <class P, int NTB, bool PAIR, int XM, int FUSE, int WL = 0>
+__global__ void __launch_bounds__(256, ((PAIR || conv_pipe_lds_bytes<NTB, WL>(64) <= 80 * 1024) &&
+                                        (FUSE == 2 ? (PAIR && NTB == 1) : (FUSE == 3 ? NTB == 1 : (FUSE == 1 && (NTB == 1 || (!PAIR && NTB == 2)))))) ? 2 : 1)
 conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restrict__ wp, typename ActOf<P>::type* __restrict__ y, long ldy, int accumulate,
                       int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles,
                       float* __restrict__ part, const char* __restrict__ wp3, typename ActOf<P>::type* __restrict__ y3, long ldy3,
@@ -450,9 +461,26 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
     typedef typename ActOf<P>::type YT;
     constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16, LAY = PAIR ? 0 : 1;
     __shared__ __attribute__((aligned(16))) char halo[NHALO * PITCH];
+    constexpr int WLN = PAIR ? 0 : WL, WBYTES = 27 * NTB * 1024;
+    __shared__ __attribute__((aligned(16))) char wlds[WLN ? WLN * WBYTES : 16];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
     const int nt0 = blockIdx.y * NTB;
     const int nslab = PAIR ? 1 : (Cin + SL - 1) / SL;
+    // this wave's share of the 27 * NTB (tap, j) pieces of one slab's weights: global -> LDS, no registers
+    auto wdma = [&](int slab, int buf) {
+        const char* src0 = wp + ((long)slab * Cout + nt0 * 16 + r) * 64 + g * 16;
+        const long wtap = (long)nslab * Cout * 64;
+        for (int p = wv; p < 27 * NTB; p += 4) {
+            const int tap = p / NTB, j = p - tap * NTB;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(src0 + tap * wtap + (long)j * 16 * 64), (lds_void_t*)(wlds + buf * WBYTES + p * 1024), 16, 0, 0);
+        }
+    };
+    const bool wrot = WLN > 0 && nslab > WLN;      // more slabs than images: double buffer indexed by a running slab count
+    int wit = 0;
+    if constexpr (WLN > 0) {
+        if (wrot) wdma(0, 0);
+        else for (int sl = 0; sl < nslab; ++sl) wdma(sl, sl);
+    }
 
     u32x4 wres[PAIR ? 14 : 1][NTB];
     if constexpr (PAIR) {
@@ -530,10 +558,14 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         for (int slab = 0; slab < nslab; ++slab) {
             __syncthreads();                       // everyone is done reading the previous window
             halo_store<P, NCH, XM, LAY>(R, PITCH, halo);    // (waits for the prefetched loads)
+            if constexpr (WLN > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's weight DMA pieces have landed
             __syncthreads();
             {   // prefetch the next (tile, slab) window; it lands while the MFMAs below run
                 int ntile = tile, nslb = slab + 1;
                 if (nslb == nslab) { ntile = tile + gridDim.x; nslb = 0; }
+                if constexpr (WLN > 0) {
+                    if (wrot && ntile < ntiles) wdma(nslb, (wit + 1) & 1);      // (that image was last read before the barrier above)
+                }
                 if (ntile < ntiles) {
                     int ax, ay, az, ab;
                     tile_coords(ntile, ntiles, ntx, nty, ntz, ax, ay, az, ab);
@@ -562,6 +594,37 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                         }
                     }
                 }
+            } else if constexpr (WLN > 0) {
+                const int xo3[3] = {lay_off<LAY>(r, g, PITCH), lay_off<LAY>(r + 1, g, PITCH), lay_off<LAY>(r + 2, g, PITCH)};
+                const char* wb = wlds + (wrot ? (wit & 1) : slab) * WBYTES + lane * 16;
+                if constexpr (has3) {
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)slab * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
+                }
+                for (int tr = 0; tr < 9; ++tr) {          // (dz, dy) rows of three taps
+                    const int dz = tr / 3, dy = tr - dz * 3;
+                    const char* hrow = halo + (((wv + dz) * HY + dy) * HX) * PITCH;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int tap = tr * 3 + dx;
+                        u32x4 bw[NTB];
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) bw[j] = *(const u32x4*)(wb + (tap * NTB + j) * 1024);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32x4 a = *(const u32x4*)(hrow + xo3[dx] + i * HX * PITCH);
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], bw[j], a);
+                            if constexpr (has3) {
+                                if (tap == 13) {
+#pragma unroll
+                                    for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
+                                }
+                            }
+                        }
+                    }
+                }
+                ++wit;
             } else {
                 constexpr int GT = NTB <= 2 ? 3 : 1, NG = 27 / GT;   // small groups: the halo prefetch registers are live here
                 // per-lane byte offset of (window column r + dx, chunk g) for the three dx of a tap row (LAY 1 swizzle folded in)
@@ -1131,31 +1194,43 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
         // the transposed accumulator tile is stored four channels (8 / 16 bytes) per lane
         if ((ldy & 3) || ((uintptr_t)y & (B16 ? 7 : 15)) || (fz && fz->k3 == 0 && fz->y3 && ((uintptr_t)fz->y3 & (B16 ? 7 : 15)))) return UNETR_ERR_UNSUPPORTED;
         if (pair && ntb > 2) ntb = 2;
-        const long cap = 512;   // 2 resident workgroups per CU (VGPR-limited); more would queue behind them
+        // slab mode: weights resident in LDS (see the kernel); two workgroups per CU only while a workgroup stays under 80 KB
+        const int nslab = cdiv(Cin, 4 * P::CH);
+        int wl = pair ? 0 : (nslab == 1 ? 1 : 2);
+        if (!pair && NHALO * 64 + wl * 27 * ntb * 1024 > 160 * 1024) wl = 0;
+        const bool two = pair || NHALO * 64 + wl * 27 * ntb * 1024 <= 80 * 1024;
+        const long cap = two ? 512 : 256;   // resident workgroups (VGPR / LDS-limited); more would queue behind them
         dim3 pgrid((unsigned)std::min<long>(spatial, cap), ntn / ntb);
-#define LAUNCH_PIPE_F(NTB_, PAIR_, XM_, FUSE_)                                                                                    \
-    hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, XM_, FUSE_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
+#define LAUNCH_PIPE_F(NTB_, PAIR_, XM_, FUSE_, WL_)                                                                               \
+    hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, XM_, FUSE_, WL_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
                        accumulate, D, H, W, Cin, Cout, ntx, nty, ntz, (int)spatial, fz ? fz->part : nullptr,                       \
                        fz ? (const char*)fz->wp3 : nullptr, fz ? (YT*)fz->y3 : nullptr, fz ? fz->ldy3 : 0, fz ? fz->part3 : nullptr,       \
                        fz ? fz->k3 : 0)
-#define LAUNCH_PIPE_V(NTB_, PAIR_, FUSE_)                                                                                         \
+#define LAUNCH_PIPE_V(NTB_, PAIR_, FUSE_, WL_)                                                                                    \
     do {                                                                                                                          \
         if constexpr (B16) {                                                                                                      \
-            if (xm == 2) { LAUNCH_PIPE_F(NTB_, PAIR_, 2, FUSE_); break; }                                                         \
-            if constexpr (PAIR_) { if (xm == 1) LAUNCH_PIPE_F(NTB_, true, 1, FUSE_); else LAUNCH_PIPE_F(NTB_, true, 0, FUSE_); }  \
+            if (xm == 2) { LAUNCH_PIPE_F(NTB_, PAIR_, 2, FUSE_, WL_); break; }                                                    \
+            if constexpr (PAIR_) { if (xm == 1) LAUNCH_PIPE_F(NTB_, true, 1, FUSE_, 0); else LAUNCH_PIPE_F(NTB_, true, 0, FUSE_, 0); }  \
         } else {                                                                                                                  \
-            if (xm == 1) LAUNCH_PIPE_F(NTB_, PAIR_, 1, FUSE_); else LAUNCH_PIPE_F(NTB_, PAIR_, 0, FUSE_);                         \
+            if (xm == 1) LAUNCH_PIPE_F(NTB_, PAIR_, 1, FUSE_, WL_); else LAUNCH_PIPE_F(NTB_, PAIR_, 0, FUSE_, WL_);               \
         }                                                                                                                         \
     } while (0)
+#define LAUNCH_PIPE_W(NTB_, PAIR_, WL_)                                                                                           \
+    do {                                                                                                                          \
+        if (fz && fz->k3 > 0) { LAUNCH_PIPE_V(NTB_, PAIR_, 4, WL_); break; }                                                      \
+        if constexpr (!(PAIR_)) {                                                                                                 \
+            if (fz && fz->wp3 && late1x1) { LAUNCH_PIPE_V(NTB_, false, 3, WL_); break; }                                          \
+        }                                                                                                                         \
+        if (fz && fz->wp3) LAUNCH_PIPE_V(NTB_, PAIR_, 2, WL_);                                                                    \
+        else if (fz) LAUNCH_PIPE_V(NTB_, PAIR_, 1, WL_);                                                                          \
+        else LAUNCH_PIPE_V(NTB_, PAIR_, 0, WL_);                                                                                  \
+    } while (0)
+// slab mode: NTB 1 / 2 always keep the weights in LDS (one or two images); NTB 4 only fits one
 #define LAUNCH_PIPE(NTB_, PAIR_)                                                                                                  \
     do {                                                                                                                          \
-        if (fz && fz->k3 > 0) { LAUNCH_PIPE_V(NTB_, PAIR_, 4); break; }                                                           \
-        if constexpr (!(PAIR_)) {                                                                                                 \
-            if (fz && fz->wp3 && late1x1) { LAUNCH_PIPE_V(NTB_, false, 3); break; }                                               \
-        }                                                                                                                         \
-        if (fz && fz->wp3) LAUNCH_PIPE_V(NTB_, PAIR_, 2);                                                                         \
-        else if (fz) LAUNCH_PIPE_V(NTB_, PAIR_, 1);                                                                               \
-        else LAUNCH_PIPE_V(NTB_, PAIR_, 0);                                                                                       \
+        if constexpr (PAIR_) LAUNCH_PIPE_W(NTB_, true, 0);                                                                        \
+        else if constexpr (NTB_ == 4) { if (wl == 1) LAUNCH_PIPE_W(4, false, 1); else LAUNCH_PIPE_W(4, false, 0); }                \
+        else { if (wl == 1) LAUNCH_PIPE_W(NTB_, false, 1); else LAUNCH_PIPE_W(NTB_, false, 2); }                                   \
     } while (0)
         const bool late1x1 = Cin <= 4 * P::CH;      // single-slab window: the 1x1x1 product is formed after the tile (FUSE 3)
         if (fz && fz->k3 == 0) fz->rows = (int)pgrid.x * 4;      // (workgroup, wave) partial rows per batch item, zeroed in-kernel

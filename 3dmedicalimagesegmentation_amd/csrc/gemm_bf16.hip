@@ -408,19 +408,21 @@ extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, con
     }
     if (!d->b_kn) {
         if (big) { if (env_ns == 3) BF16_GO(4, 4, false, 3); if (env_ns == 4) BF16_GO(4, 4, false, 4); BF16_GO(4, 4, false, 2); }
-        if (cfg == 6432) BF16_GO(2, 1, false, 4);
-        if (cfg == 3264) BF16_GO(1, 2, false, 4);
+        if (cfg == 6432) { if (env_ns == 6) BF16_GO(2, 1, false, 6); if (env_ns == 8) BF16_GO(2, 1, false, 8); if (env_ns == 12) BF16_GO(2, 1, false, 12); BF16_GO(2, 1, false, 4); }
+        if (cfg == 3264) { if (env_ns == 6) BF16_GO(1, 2, false, 6); if (env_ns == 8) BF16_GO(1, 2, false, 8); BF16_GO(1, 2, false, 4); }
         if (cfg == 64128) BF16_GO(2, 4, false, 3);
         if (cfg == 6496) BF16_GO(2, 3, false, 3);
         if (env_ns == 2) BF16_GO(2, 2, false, 2);
         if (env_ns == 6) BF16_GO(2, 2, false, 6);
+        if (env_ns == 8) BF16_GO(2, 2, false, 8);
         BF16_GO(2, 2, false, 4);
     }
     if (big) { if (env_ns == 3) BF16_GO(4, 4, true, 3); if (env_ns == 4) BF16_GO(4, 4, true, 4); BF16_GO(4, 4, true, 2); }
-    if (cfg == 3264) BF16_GO(1, 2, true, 4);
+    if (cfg == 3264) { if (env_ns == 6) BF16_GO(1, 2, true, 6); if (env_ns == 8) BF16_GO(1, 2, true, 8); if (env_ns == 12) BF16_GO(1, 2, true, 12); BF16_GO(1, 2, true, 4); }
     if (cfg == 64128) BF16_GO(2, 4, true, 3);
     if (env_ns == 2) BF16_GO(2, 2, true, 2);
     if (env_ns == 6) BF16_GO(2, 2, true, 6);
+    if (env_ns == 8) BF16_GO(2, 2, true, 8);
     BF16_GO(2, 2, true, 4);
 #undef BF16_GO
 }

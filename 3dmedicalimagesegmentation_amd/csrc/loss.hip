@@ -79,35 +79,39 @@ dicece_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ la
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// single block: reduce partials in double, emit loss terms and the Dice gradient coefficients
+// single block: reduce partials in double (fixed order: lanes stride over the chunks, shuffle tree), emit loss terms and the
+// Dice gradient coefficients.  One wave per (b, c) -- eight threads walking 216 chunks each serially cost 30 us.
 // coef[(b*C+c)*2+0] = dDice/dp coefficient on y:  -2/(B*C*den);  [+1] = constant term: (2I+nr)/(B*C*den^2)
-__global__ void dicece_final_kernel(const float* __restrict__ part, int B, int C, int nchunk, long V, float nr, float dr,
-                                    float* __restrict__ out, float* __restrict__ coef) {
-    __shared__ double sdice[256];
-    __shared__ double sce[256];
+__global__ void __launch_bounds__(256)
+dicece_final_kernel(const float* __restrict__ part, int B, int C, int nchunk, long V, float nr, float dr,
+                    float* __restrict__ out, float* __restrict__ coef) {
+    __shared__ double sdice[4];
+    __shared__ double sce[4];
     const int stride = 3 * C + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double dice_acc = 0.0, ce_acc = 0.0;
-    for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
-        int b = i / C, c = i - b * C;
+    for (int i = wave; i < B * C; i += 4) {
+        const int b = i / C, c = i - b * C;
         double I = 0.0, Pp = 0.0, G = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
+        for (int k = lane; k < nchunk; k += 64) {
             const float* p = part + ((long)b * nchunk + k) * stride;
             I += (double)p[c]; Pp += (double)p[C + c]; G += (double)p[2 * C + c];
         }
-        double den = G + Pp + (double)dr, num = 2.0 * I + (double)nr;
+        I = wave_sum_d(I); Pp = wave_sum_d(Pp); G = wave_sum_d(G);
+        const double den = G + Pp + (double)dr, num = 2.0 * I + (double)nr;
         dice_acc += 1.0 - num / den;
-        coef[2 * i] = (float)(-2.0 / ((double)(B * C) * den));
-        coef[2 * i + 1] = (float)(num / ((double)(B * C) * den * den));
+        if (lane == 0) {
+            coef[2 * i] = (float)(-2.0 / ((double)(B * C) * den));
+            coef[2 * i + 1] = (float)(num / ((double)(B * C) * den * den));
+        }
     }
-    for (int i = threadIdx.x; i < B * nchunk; i += blockDim.x) ce_acc += (double)part[(long)i * stride + 3 * C];
-    sdice[threadIdx.x] = dice_acc; sce[threadIdx.x] = ce_acc;
+    for (int i = threadIdx.x; i < B * nchunk; i += 256) ce_acc += (double)part[(long)i * stride + 3 * C];
+    ce_acc = wave_sum_d(ce_acc);
+    if (lane == 0) { sdice[wave] = dice_acc; sce[wave] = ce_acc; }
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { sdice[threadIdx.x] += sdice[threadIdx.x + s]; sce[threadIdx.x] += sce[threadIdx.x + s]; }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        double dice = sdice[0] / (double)(B * C), ce = sce[0] / ((double)B * (double)V);
+        const double dice = (sdice[0] + sdice[1] + sdice[2] + sdice[3]) / (double)(B * C);
+        const double ce = (sce[0] + sce[1] + sce[2] + sce[3]) / ((double)B * (double)V);
         out[0] = (float)(dice + ce); out[1] = (float)dice; out[2] = (float)ce;
     }
 }

@@ -286,18 +286,23 @@ in_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ sa,
     }
 }
 
-// backward stage 1: per (b,c) sums of g, g*n1, g*n2 with g = dy * lrelu'(n1+n2)
-template <class T>
+// backward stage 1: per (b,c) sums of g, g*n1, g*n2 with g = dy * lrelu'(n1+n2).  DUAL = the block-end form (two normalised
+// inputs summed before the activation).  One block = `vpb` consecutive voxels of one batch element (the host sizes vpb so
+// that the grid is about three blocks per CU: with 1024-voxel blocks the prologue / block reduction were most of a block's
+// life and the pass ran at 2.2 TB/s).  Loaded data stays packed (16 bytes = 4 registers) until it is used, addresses are a
+// uniform base + a 32-bit per-lane offset, and the statistics are folded into one multiply-add per element.
+template <class T, bool DUAL, int U>
 __global__ void __launch_bounds__(256)
 in_bwd_reduce_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
-                     const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, long V, int C, int lrelu,
+                     const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, long V, long vpb, int C, int lrelu,
                      float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int W = Io<T>::W;
     const int cvn = C / W, nphase = 256 / cvn;
     const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
     const int b = blockIdx.y;
-    const long v0 = (long)blockIdx.x * IN_VPB, v1 = std::min<long>(V, v0 + IN_VPB);
+    const long v0 = (long)blockIdx.x * vpb;
+    const int n = (int)(std::min<long>(V, v0 + vpb) - v0);
     float acc[3][W];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -305,41 +310,70 @@ in_bwd_reduce_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ 
         for (int e = 0; e < W; ++e) acc[s][e] = 0.f;
     if (ph < nphase) {
         const float* s1 = sa + ((long)b * C + W * cv) * 2;
-        const float* s2 = x2 ? sb + ((long)b * C + W * cv) * 2 : nullptr;
-        // statistics of this thread's channels, loaded once
-        float mu1[W], rs1[W], mu2[W], rs2[W];
+        const float* s2 = DUAL ? sb + ((long)b * C + W * cv) * 2 : nullptr;
+        // n = t * a + o  with a = rstd, o = -mean * rstd
+        float a1[W], o1[W], a2[DUAL ? W : 1], o2[DUAL ? W : 1];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            mu1[e] = s1[2 * e]; rs1[e] = s1[2 * e + 1];
-            mu2[e] = x2 ? s2[2 * e] : 0.f; rs2[e] = x2 ? s2[2 * e + 1] : 0.f;
+            a1[e] = s1[2 * e + 1]; o1[e] = -s1[2 * e] * a1[e];
+            if (DUAL) { a2[e] = s2[2 * e + 1]; o2[e] = -s2[2 * e] * a2[e]; }
         }
-        // several voxels per iteration: all their loads are issued before the first use (a pure-read pass with one voxel in
-        // flight per thread ran at 4.2 TB/s against 6.8 TB/s for the read+write passes)
-        constexpr int U = 32 / W;
-        for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
-            float g[U][W], t[U][W], t2[U][W];
+        const float slope = lrelu ? 0.01f : 1.f;
+        auto add = [&](u32x4 rg, u32x4 rt, u32x4 rt2) {
+            float g[W], t[W], t2[W];
+            Io<T>::unpack(rg, g);
+            Io<T>::unpack(rt, t);
+            if (DUAL) Io<T>::unpack(rt2, t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float n1 = fmaf(t[e], a1[e], o1[e]);
+                const float n2 = DUAL ? fmaf(t2[e], a2[e], o2[e]) : 0.f;
+                const float ge = (n1 + n2) > 0.f ? g[e] : slope * g[e];
+                acc[0][e] += ge;
+                acc[1][e] = fmaf(ge, n1, acc[1][e]);
+                if (DUAL) acc[2][e] = fmaf(ge, n2, acc[2][e]);
+            }
+        };
+        // uniform bases (scalar registers) + 32-bit byte offsets per lane
+        const char* bd = (const char*)(dy + ((long)b * V + v0) * lddy);
+        const char* bx = (const char*)(x + ((long)b * V + v0) * ldx);
+        const char* bx2 = DUAL ? (const char*)(x2 + ((long)b * V + v0) * ldx2) : nullptr;
+        const unsigned esz = sizeof(T);
+        unsigned od = (unsigned)(ph * lddy + W * cv) * esz, ox = (unsigned)(ph * ldx + W * cv) * esz;
+        unsigned ox2 = DUAL ? (unsigned)(ph * ldx2 + W * cv) * esz : 0u;
+        const unsigned sd = (unsigned)(nphase * lddy) * esz, sx = (unsigned)(nphase * ldx) * esz, sx2 = DUAL ? (unsigned)(nphase * ldx2) * esz : 0u;
+        // several voxels per iteration, all their loads issued before the first use
+        int v = ph;
+#pragma unroll 1
+        for (; v + (U - 1) * nphase < n; v += U * nphase) {
+            u32x4 rg[U], rt[U], rt2[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const long vv = v + (long)u * nphase;
-                const long vox = (long)b * V + (vv < v1 ? vv : v);      // clamped: re-reads voxel v, masked below
-                Io<T>::ldw(dy + vox * lddy + W * cv, g[u]);
-                Io<T>::ldw(x + vox * ldx + W * cv, t[u]);
-                if (x2) Io<T>::ldw(x2 + vox * ldx2 + W * cv, t2[u]);
+                rt2[u] = (u32x4){0u, 0u, 0u, 0u};
+                rg[u] = *(const u32x4*)(bd + (size_t)(od + u * sd));
+                rt[u] = *(const u32x4*)(bx + (size_t)(ox + u * sx));
+                if (DUAL) rt2[u] = *(const u32x4*)(bx2 + (size_t)(ox2 + u * sx2));
             }
+            od += U * sd; ox += U * sx; ox2 += U * sx2;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float live = (v + (long)u * nphase < v1) ? 1.f : 0.f;
-#pragma unroll
-                for (int e = 0; e < W; ++e) {
-                    const float n1 = (t[u][e] - mu1[e]) * rs1[e];
-                    const float n2 = x2 ? (t2[u][e] - mu2[e]) * rs2[e] : 0.f;
-                    float ge = g[u][e] * live;
-                    if (lrelu) ge = (n1 + n2) > 0.f ? ge : 0.01f * ge;
-                    acc[0][e] += ge;
-                    acc[1][e] += ge * n1;
-                    acc[2][e] += ge * n2;
-                }
+                // one voxel's unpacked values live at a time: the empty asm redefines this voxel's packed registers together
+                // with the accumulators the previous voxel wrote, so the compiler cannot interleave the four voxels'
+                // arithmetic (which cost 244 VGPRs = two waves per SIMD)
+                static_assert(W == 4 || W == 8, "");
+                if constexpr (DUAL) asm volatile("" : "+v"(rt2[u]));
+                if (W == 8) asm volatile("" : "+v"(rg[u]), "+v"(rt[u]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]),
+                                         "+v"(acc[1][3]), "+v"(acc[1][4 % W]), "+v"(acc[1][5 % W]), "+v"(acc[1][6 % W]), "+v"(acc[1][7 % W]));
+                else asm volatile("" : "+v"(rg[u]), "+v"(rt[u]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+                add(rg[u], rt[u], rt2[u]);
             }
+        }
+#pragma unroll 1
+        for (; v < n; v += nphase) {
+            const u32x4 rg = *(const u32x4*)(bd + (size_t)od), rt = *(const u32x4*)(bx + (size_t)ox);
+            const u32x4 rt2 = DUAL ? *(const u32x4*)(bx2 + (size_t)ox2) : rt;
+            od += sd; ox += sx; ox2 += sx2;
+            add(rg, rt, rt2);
         }
     }
     in_block_reduce<3, W>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 3 * C, C);
@@ -561,6 +595,70 @@ outconv_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, co
     }
 }
 
+// The small-head form (Cout <= 4, Cin in {8, 16} for bf16 maps / {4, 8, 16} for fp32: the launcher checks): one thread = one
+// 16-byte piece of a voxel's channel row, so a wave reads x and writes dx as contiguous 1 KB runs (the one-thread-per-voxel
+// form above issued 8-byte pieces 32 bytes apart and ran at 1.8 TB/s).  Same partial layout as above.
+template <class T>
+__global__ void __launch_bounds__(256)
+outconv_bwd_small_kernel(const float* __restrict__ dl, const float* __restrict__ w, const T* __restrict__ x, long ldx,
+                         T* __restrict__ dx, long lddx, float* __restrict__ part, int B, long V, int Cin, int Cout) {
+    constexpr int W = Io<T>::W;
+    __shared__ float red[4][4 + 64];
+    const int cvn = Cin / W;                       // 1, 2 or 4 pieces per voxel
+    const int cv = threadIdx.x % cvn;
+    float wr[4][W];                                // this thread's columns of the weight
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int e = 0; e < W; ++e) wr[co][e] = co < Cout ? w[co * Cin + W * cv + e] : 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float wsum[4][W];
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int e = 0; e < W; ++e) wsum[co][e] = 0.f;
+    const long total = (long)B * V * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long vox = i / cvn;
+        const int b = (int)(vox / V); const long v = vox - (long)b * V;
+        float xv[W];
+        Io<T>::ldw(x + vox * ldx + W * cv, xv);
+        float g[4];
+#pragma unroll
+        for (int co = 0; co < 4; ++co) g[co] = co < Cout ? dl[((long)b * Cout + co) * V + v] : 0.f;
+        float o[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = g[0] * wr[0][e] + g[1] * wr[1][e] + g[2] * wr[2][e] + g[3] * wr[3][e];
+        Io<T>::stw(dx + vox * lddx + W * cv, o);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+            bsum[co] += cv == 0 ? g[co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < W; ++e) wsum[co][e] = fmaf(g[co], xv[e], wsum[co][e]);
+        }
+    }
+    // lanes with the same cv (lane % cvn: cvn divides 64 and the block size) hold the same channels
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        float s = wave_sum(bsum[co]);
+        if (lane == 0) red[wave][co] = s;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float t = wsum[co][e];
+            for (int o = 32; o >= cvn; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane < cvn) red[wave][4 + co * 16 + W * lane + e] = t;
+        }
+    }
+    __syncthreads();
+    const int np = Cout + Cout * Cin;
+    if ((int)threadIdx.x < np) {
+        int src = threadIdx.x;
+        if ((int)threadIdx.x >= Cout) { const int k = threadIdx.x - Cout, co = k / Cin, ci = k - co * Cin; src = 4 + co * 16 + ci; }
+        part[(long)blockIdx.x * np + threadIdx.x] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    }
+}
+
 // out0[n] = sum_r part[r][n] for n < n0, out1[n - n0] for the rest (bias gradient, then weight gradient)
 __global__ void outconv_final_kernel(const float* __restrict__ part, int R, int N, int n0, float* __restrict__ out0, float* __restrict__ out1) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -744,14 +842,25 @@ extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long
     if (int e = in_check(C, ldx, act16)) return e;
     const int W = act16 ? 8 : 4;
     if ((lddy % W) || (lddx % W) || (x2 && ((ldx2 % W) || (lddx2 % W)))) return UNETR_ERR_UNSUPPORTED;
-    int nchunk = cdiv(V, IN_VPB);
+    // about three blocks per CU, each at least two full iterations of its threads (a fixed 1024-voxel block left the 12^3 x
+    // 128-channel layer on TWO blocks: 51 us for 0.9 MB); offsets inside a block are 32-bit
+    const int cvn = C / W, nphase = 256 / cvn;
+    const int UD = 2, US = 4;                    // voxels in flight per thread: dual / single form
+    const long step = (long)(x2 ? UD : US) * nphase;
+    long vpb = std::max<long>(2 * step, cdiv(cdiv((long)V * B, 768L), step) * step);
+    const long ldmax = std::max(std::max(lddy, ldx), x2 ? ldx2 : 0L);
+    while (vpb > 2 * step && (vpb + 256) * ldmax * 4 >= (1L << 31)) vpb -= step;
+    if ((vpb + 256) * ldmax * 4 >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;
+    int nchunk = (int)cdiv(V, vpb);
     size_t need = ((size_t)B * nchunk * 3 * C + (size_t)B * C * 3) * sizeof(float);
     if (!ws || need > ws_bytes) return UNETR_ERR_WORKSPACE;
     float* sums = ws + (size_t)B * nchunk * 3 * C;
     hipStream_t st = (hipStream_t)stream;
-    const int cvn = C / W, nphase = 256 / cvn;
-    ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_reduce_kernel<AT>, dim3(nchunk, B), dim3(256), (size_t)3 * nphase * C * 4, st, (const AT*)dy, lddy,
-                                           (const AT*)x, ldx, sa, (const AT*)x2, ldx2, sb, V, C, lrelu, ws));
+    const size_t lds_bytes = (size_t)3 * nphase * C * 4;
+#define IN_RED(DUAL_, U_) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_reduce_kernel<AT, DUAL_, U_>), dim3(nchunk, B), dim3(256), lds_bytes, st, (const AT*)dy, lddy, \
+                                                                 (const AT*)x, ldx, sa, (const AT*)x2, ldx2, sb, V, vpb, C, lrelu, ws))
+    if (x2) IN_RED(true, UD); else IN_RED(false, US);
+#undef IN_RED
     hipLaunchKernelGGL(in_bwd_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, B, sums);
     long total = (long)B * V * (C / W);
     ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_apply_kernel<AT>, dim3(grid_for(total)), dim3(256), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
@@ -807,12 +916,15 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, 
     hipStream_t st = (hipStream_t)stream;
     int nblk = grid_for((long)B * V, 256, 1024);
     const bool wg = Cout <= 4 && Cin <= 16 && ((uintptr_t)x & 15) == 0;      // weight gradient from the same pass
+    const int Wd = act16 ? 8 : 4;
+    const bool small = wg && (Cin == Wd || Cin == 2 * Wd || Cin == 4 * Wd) && (ldx % Wd) == 0 && (lddx % Wd) == 0 && ((uintptr_t)dx & 15) == 0;
     if (!wg && act16) return UNETR_ERR_UNSUPPORTED;                          // (the generic GEMM below reads fp32 x)
     const int np = Cout + (wg ? Cout * Cin : 0);
     size_t part_bytes = (size_t)nblk * np * sizeof(float);
     size_t part_al = (part_bytes + 255) & ~(size_t)255;
     if (!ws || part_al + 4096 > ws_bytes) return UNETR_ERR_WORKSPACE;
-    if (wg) ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_bwd_kernel<true, AT>), dim3(nblk), dim3(256), 0, st, dlogits, w, (const AT*)x, ldx, (AT*)dx, lddx, ws, B, V, Cin, Cout));
+    if (small) ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_bwd_small_kernel<AT>), dim3(nblk), dim3(256), 0, st, dlogits, w, (const AT*)x, ldx, (AT*)dx, lddx, ws, B, V, Cin, Cout));
+    else if (wg) ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_bwd_kernel<true, AT>), dim3(nblk), dim3(256), 0, st, dlogits, w, (const AT*)x, ldx, (AT*)dx, lddx, ws, B, V, Cin, Cout));
     else ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_bwd_kernel<false, AT>), dim3(nblk), dim3(256), 0, st, dlogits, w, (const AT*)x, ldx, (AT*)dx, lddx, ws, B, V, Cin, Cout));
     if (int e = unetr_check_launch()) return e;
     float* ws2 = (float*)((char*)ws + part_al);

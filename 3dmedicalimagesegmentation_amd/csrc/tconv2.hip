@@ -259,20 +259,17 @@ tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const 
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const u32x4 b = *(const u32x4*)(wimg + (j * 16 + r) * PA + kb * 64 + g * 16);
-                P::mma(acc[j], a, b);
+                P::mma(acc[j], b, a);        // swapped operands: the accumulator tile comes out transposed
             }
         }
-        // scatter: acc[j][rr] = (voxel wv*16 + 4g + rr, column j*16 + r); column -> (tap, co)
-        int ob[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) ob[rr] = tab[wv * 16 + 4 * g + rr];
+        // scatter: acc[j][0..3] = (columns j*16 + 4g + 0..3, voxel wv*16 + r): four consecutive channels of one tap (Cout % 4 == 0)
+        // = one 8 / 16-byte store per lane (was four 2-byte stores)
+        const int ob = tab[wv * 16 + r];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int col = j * 16 + r, tap = col / Cout, co = col - tap * Cout;
+            const int col = j * 16 + 4 * g, tap = col / Cout, co = col - tap * Cout;
             const int toff = ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                if (ob[rr] >= 0) Io<T>::st1(y + (long)(ob[rr] + toff) * ldy + co, acc[j][rr]);
+            if (ob >= 0) Io<T>::st4(y + (long)(ob + toff) * ldy + co, acc[j]);
         }
     }
 }
@@ -345,16 +342,15 @@ tconv2_dgrad_kernel(const typename Elem<P>::type* __restrict__ dy, long lddy, co
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const u32x4 b = *(const u32x4*)(wimg + (j * 16 + r) * PA + kb * 64 + g * 16);
-                P::mma(acc[j], a, b);
+                P::mma(acc[j], b, a);        // swapped operands: acc[j][0..3] = (channels j*16 + 4g + 0..3, voxel wv*16 + r)
             }
         }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int m = m0 + wv * 16 + 4 * g + rr;
+        {
+            const int m = m0 + wv * 16 + r;
             if (m < M) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    if (j * 16 + r < Cin) Io<T>::st1(dx + (long)m * ldx + j * 16 + r, acc[j][rr]);
+                    if (j * 16 + 4 * g < Cin) Io<T>::st4(dx + (long)m * ldx + j * 16 + 4 * g, acc[j]);      // (Cin % 4 == 0: checked by the host)
             }
         }
     }
@@ -465,6 +461,7 @@ extern "C" int unetr_tconv2_fwd(const void* x, long ldx, const float* w, void* y
                                 int Cin, int Cout, int prec, float* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !y) return UNETR_ERR_ARG;
     if (!unetr_tconv2_fwd_supported((long)B * D * H * W, Cin, Cout, ldx, ldy) || ((uintptr_t)x & 15)) return UNETR_ERR_UNSUPPORTED;
+    if ((uintptr_t)y & (prec == UNETR_PREC_BF16 ? 7 : 15)) return UNETR_ERR_UNSUPPORTED;      // four channels per store
     if (prec == UNETR_PREC_BF16) {
         if (ldx & 7) return UNETR_ERR_UNSUPPORTED;
         return fwd2<PrecBF16>((const uint16_t*)x, ldx, w, (uint16_t*)y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
@@ -478,7 +475,7 @@ extern "C" int unetr_tconv2_dgrad(const void* dy, long lddy, const float* w, voi
     if (!dy || !w || !dx) return UNETR_ERR_ARG;
     const long M = (long)B * D * H * W;
     if (accumulate || !tconv2_enabled() || M < 2048 || M >= (1L << 27) || Cin < 8 || Cin > 64 || Cout % 8 || Cout < 8 || Cout > 32 ||
-        (lddy & 3) || ((uintptr_t)dy & 15))
+        (lddy & 3) || ((uintptr_t)dy & 15) || (Cin & 3) || (ldx & 3) || ((uintptr_t)dx & (prec == UNETR_PREC_BF16 ? 7 : 15)))
         return UNETR_ERR_UNSUPPORTED;
     if (prec == UNETR_PREC_BF16) {
         if (lddy & 7) return UNETR_ERR_UNSUPPORTED;

@@ -1,4 +1,5 @@
-"""InstanceNorm forward-apply / backward passes at the 96^3 x 16-channel shape (graph-timed): achieved HBM rate per pass."""
+"""InstanceNorm forward-apply / backward passes at the 96^3 x 16-channel shape (graph-timed): achieved HBM rate per pass.
+    python tools/bench_instnorm.py [fp32|bf16]     storage type of the feature maps (default bf16 = the bench mode)"""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
@@ -6,10 +7,11 @@ Fn = pkg.functional
 dev = torch.device("cuda:0")
 B, S, C = 2, 96, 16
 V = S ** 3
-mk = lambda: torch.randn(B, S, S, S, C, device=dev)
+adt = torch.float32 if sys.argv[1:] == ["fp32"] else torch.bfloat16
+mk = lambda: torch.randn(B, S, S, S, C, device=dev).to(adt)
 c1, c2, c3, dy = mk(), mk(), mk(), mk()
 s1, s2, s3 = (Fn.instnorm_stats(t, C, B, V, C) for t in (c1, c2, c3))
-mb = B * V * C * 4 / 1e6
+mb = B * V * C * c1.element_size() / 1e6
 cases = {
     "stats (1 read)": (lambda: Fn.instnorm_stats(c1, C, B, V, C), 1),
     "apply single (1r+1w)": (lambda: Fn.instnorm_apply(c1, s1, B, V, C, True), 2),
@@ -31,3 +33,25 @@ for name, (fn, passes) in cases.items():
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 30
     print(f"{name:28s} {ms * 1e3:7.1f} us  {passes * mb / ms / 1e3:6.2f} TB/s")
+
+if "sweep" in sys.argv[1:] or os.environ.get("IN_SWEEP"):
+    # tuning hooks of the backward reduce pass (read at launch time by the C ABI): voxels in flight per thread x grid size
+    def t(fn):
+        fn(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(10):
+                fn()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 30 * 1e3
+    for u in (2, 3, 4):
+        for blocks in (512, 768, 1024, 1536, 2048, 4096):
+            os.environ["UNETR_IN_U"], os.environ["UNETR_IN_BLOCKS"] = str(u), str(blocks)
+            a = t(lambda: Fn.instnorm_bwd(dy, C, c1, s1, B, V, C, True))
+            b = t(lambda: Fn.instnorm_bwd(dy, C, c2, s2, B, V, C, True, x2=c3, sb=s3))
+            print(f"U={u} blocks={blocks:5d}: bwd single {a:7.1f} us   bwd dual {b:7.1f} us", flush=True)

@@ -40,16 +40,18 @@ def main():
     S, B = a.size, a.batch
     dims = (B, S, S, S)
     v = B * S ** 3
+    adt = Fn.act_dtype(prec)            # feature maps are stored bf16 in bf16 mode
+    esz = 2.0 if adt == torch.bfloat16 else 4.0
     if a.kernel.startswith("conv3"):
-        x = torch.randn(B, S, S, S, a.cin, generator=g).to(dev)
+        x = torch.randn(B, S, S, S, a.cin, generator=g).to(dev).to(adt)
         w = (torch.randn(a.cout, a.cin, 3, 3, 3, generator=g) * 0.1).to(dev)
-        dy = torch.randn(B, S, S, S, a.cout, generator=g).to(dev)
+        dy = torch.randn(B, S, S, S, a.cout, generator=g).to(dev).to(adt)
         flops = 2.0 * v * a.cin * a.cout * 27
-        nbytes = 4.0 * v * (a.cin + a.cout) + 4.0 * w.numel()
+        nbytes = esz * v * (a.cin + a.cout) + 4.0 * w.numel()
         if a.kernel == "conv3_fused":     # residual-block front: 3x3x3 conv + InstanceNorm sums + 1x1x1 conv on the same window
             w3 = (torch.randn(a.cout, a.cin, 1, 1, 1, generator=g) * 0.2).to(dev)
             fn = lambda: Fn.conv3_fused(x, a.cin, w, w3, (B, S, S, S), prec)
-            nbytes = 4.0 * v * (a.cin + 2 * a.cout) + 4.0 * (w.numel() + w3.numel())
+            nbytes = esz * v * (a.cin + 2 * a.cout) + 4.0 * (w.numel() + w3.numel())
             flops = 2.0 * v * a.cin * a.cout * 28
             label = f"conv3_fused(+IN sums +1x1) {a.cin}->{a.cout} @ {S}^3 B={B} {a.prec}"
         elif a.kernel == "conv3_fwd":
@@ -74,19 +76,19 @@ def main():
               "gemm_wgrad": lambda: Fn.linear_wgrad(dy, x, prec)}[a.kernel]
         label = f"{a.kernel} M={M} N={N} K={K} {a.prec}"
     elif a.kernel.startswith("tconv"):
-        x = torch.randn(B, S, S, S, a.cin, generator=g).to(dev)
+        x = torch.randn(B, S, S, S, a.cin, generator=g).to(dev).to(adt)
         w = (torch.randn(a.cin, a.cout, 2, 2, 2, generator=g) * 0.1).to(dev)
-        dy = torch.randn(B, 2 * S, 2 * S, 2 * S, a.cout, generator=g).to(dev)
+        dy = torch.randn(B, 2 * S, 2 * S, 2 * S, a.cout, generator=g).to(dev).to(adt)
         dims = (B, S, S, S)
         flops = 2.0 * v * a.cin * a.cout * 8
-        nbytes = 4.0 * v * (a.cin + 8 * a.cout)
+        nbytes = esz * v * (a.cin + 8 * a.cout)
         fn = {"tconv_fwd": lambda: Fn.tconv_fwd(x, a.cin, w, dims, a.cin, a.cout, prec)[0],
               "tconv_dgrad": lambda: Fn.tconv_dgrad(dy, a.cout, w, dims, a.cin, a.cout, prec),
               "tconv_wgrad": lambda: Fn.tconv_wgrad(x, a.cin, dy, a.cout, dims, a.cin, a.cout, prec)}[a.kernel]
         label = f"{a.kernel} {a.cin}->{a.cout} @ {S}^3 B={B} {a.prec}"
     elif a.kernel == "instnorm":
-        x = torch.randn(B, S, S, S, a.cout, generator=g).to(dev)
-        flops, nbytes = 0.0, 4.0 * v * a.cout
+        x = torch.randn(B, S, S, S, a.cout, generator=g).to(dev).to(adt)
+        flops, nbytes = 0.0, esz * v * a.cout
         fn = lambda: Fn.instnorm_stats(x, a.cout, B, S ** 3, a.cout)
         label = f"instnorm_stats C={a.cout} @ {S}^3 B={B}"
     else:  # encoder_fwd: ViT encoder forward (patch-embed + 12 blocks + final norm) at batch B
