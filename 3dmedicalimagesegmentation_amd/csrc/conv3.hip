@@ -1199,7 +1199,9 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
         int wl = pair ? 0 : (nslab == 1 ? 1 : 2);
         if (!pair && NHALO * 64 + wl * 27 * ntb * 1024 > 160 * 1024) wl = 0;
         const bool two = pair || NHALO * 64 + wl * 27 * ntb * 1024 <= 80 * 1024;
-        const long cap = two ? 512 : 256;   // resident workgroups (VGPR / LDS-limited); more would queue behind them
+        long cap = two ? 512 : 256;   // resident workgroups (VGPR / LDS-limited); more would queue behind them
+        if (const char* e = getenv("UNETR_CONV_CAP")) { if (pair && atoi(e) > 0) cap = atoi(e); }      // tuning hook (pair layout)
+        if (const char* e = getenv("UNETR_CONV_CAP_SLAB")) { if (!pair && two && atoi(e) > 0) cap = atoi(e); }
         dim3 pgrid((unsigned)std::min<long>(spatial, cap), ntn / ntb);
 #define LAUNCH_PIPE_F(NTB_, PAIR_, XM_, FUSE_, WL_)                                                                               \
     hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, XM_, FUSE_, WL_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \

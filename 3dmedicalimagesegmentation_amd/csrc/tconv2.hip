@@ -229,6 +229,32 @@ tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const 
         const int row = id / (KB * 4), q = id - row * (KB * 4);
         *(u32x4*)(wimg + row * PA + q * 16) = *(const u32x4*)(wr + (long)row * RB + q * 16);
     }
+    // the x tile of the NEXT tile is in flight in registers while this tile's MFMAs and stores run (one 64-voxel tile is only
+    // one 16-byte piece per thread per k-block: unpipelined, every tile paid a full global-load round trip)
+    constexpr int QX = KB * 4;
+    constexpr int IT = (TV * QX + 255) / 256;
+    u32x4 nx[IT];
+    auto xload = [&](int tile) {
+        const int m0 = tile * TV;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = id / QX, q = id - v * QX;
+            const bool ok = id < TV * QX && m0 + v < M && q * CH < Cin;
+            nx[j] = act_chunk<P>(x + (long)(ok ? m0 + v : 0) * ldx + (ok ? q * CH : 0), ok);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) xload(blockIdx.x);
+    // the weight fragments do not depend on the tile: small shapes keep them in registers for the whole launch
+    constexpr bool WREG = KB * NT <= 16;
+    u32x4 breg[WREG ? KB : 1][WREG ? NT : 1];
+    if constexpr (WREG) {
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) breg[kb][j] = *(const u32x4*)(wimg + (j * 16 + r) * PA + kb * 64 + g * 16);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * TV;
         __syncthreads();
@@ -236,20 +262,16 @@ tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const 
             const int m = m0 + threadIdx.x;
             tab[threadIdx.x] = m < M ? out_base(m, D, H, W) : -1;
         }
-        {
-            constexpr int QX = KB * 4;
-            constexpr int IT = (TV * QX + 255) / 256;
 #pragma unroll
-            for (int j = 0; j < IT; ++j) {
-                const int id = threadIdx.x + j * 256;
-                if (id < TV * QX) {
-                    const int v = id / QX, q = id - v * QX;
-                    const bool ok = m0 + v < M && q * CH < Cin;
-                    *(u32x4*)(ximg + v * PA + q * 16) = act_chunk<P>(x + (long)(ok ? m0 + v : 0) * ldx + (ok ? q * CH : 0), ok);
-                }
+        for (int j = 0; j < IT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            if (id < TV * QX) {
+                const int v = id / QX, q = id - v * QX;
+                *(u32x4*)(ximg + v * PA + q * 16) = nx[j];
             }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) xload(tile + gridDim.x);
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -258,7 +280,8 @@ tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const 
             const u32x4 a = *(const u32x4*)(ximg + (wv * 16 + r) * PA + kb * 64 + g * 16);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const u32x4 b = *(const u32x4*)(wimg + (j * 16 + r) * PA + kb * 64 + g * 16);
+                u32x4 b;
+                if constexpr (WREG) b = breg[kb][j]; else b = *(const u32x4*)(wimg + (j * 16 + r) * PA + kb * 64 + g * 16);
                 P::mma(acc[j], b, a);        // swapped operands: the accumulator tile comes out transposed
             }
         }

@@ -733,10 +733,11 @@ def instnorm_stats(x, ld, B, V, C):
     return stats
 
 
-def instnorm_apply(x, sa, B, V, C, lrelu, x2=None, sb=None):
-    y = torch.empty_like(x)
+def instnorm_apply(x, sa, B, V, C, lrelu, x2=None, sb=None, out=None, ldo=None):
+    """``out`` / ``ldo``: write into an existing buffer with row pitch ldo (the skip half of a concatenation buffer)"""
+    y = torch.empty_like(x) if out is None else out
     call("unetr_instnorm_apply", x.data_ptr(), C, sa.data_ptr(), x2.data_ptr() if x2 is not None else None, C,
-         sb.data_ptr() if sb is not None else None, y.data_ptr(), C, B, V, C, int(lrelu), _a16(x), _stream())
+         sb.data_ptr() if sb is not None else None, y.data_ptr(), C if out is None else ldo, B, V, C, int(lrelu), _a16(x), _stream())
     return y
 
 
@@ -1053,7 +1054,24 @@ class LayerNormFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------ conv-side building blocks
-def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec):
+def skip_half(dims, C, prec, device):
+    """A fresh concatenation buffer [B,D,H,W,2C] for UnetrUpBlock's torch.cat((up, skip), dim=1), and the view of its second
+    half: the producer of the skip tensor writes there directly (``to_cat``) and UpBlockFn(skip_in_cat=True) writes the
+    transposed conv into the first half -- the concatenation then costs nothing (it was a 113 MB copy at 96^3)."""
+    cat = torch.empty(*dims, 2 * C, dtype=act_dtype(prec), device=device)
+    return cat, cat[..., C:]
+
+
+def cat_of_skip(skip, C):
+    """the whole concatenation buffer whose second half ``skip`` is (see skip_half); raises when it is not such a view"""
+    B, D, H, W, c = skip.shape
+    want = (D * H * W * 2 * C, H * W * 2 * C, W * 2 * C, 2 * C, 1)
+    if c != C or tuple(skip.stride()) != want or skip.storage_offset() != C or skip.untyped_storage().nbytes() != B * want[0] * skip.element_size():
+        raise RuntimeError("skip_in_cat=True needs the second half of a buffer made by functional.skip_half")
+    return skip.as_strided((B, D, H, W, 2 * C), want, 0)
+
+
+def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec, to_cat=False):
     """MONAI UnetResBlock (instance norm, in != out): lrelu(IN(conv2(lrelu(IN(conv1 x)))) + IN(conv3 x))."""
     B, D, H, W = dims
     V = D * H * W
@@ -1080,7 +1098,11 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec):
     else:
         c2 = conv3(a1, cout, w2, dims, prec)
         s2 = instnorm_stats(c2, cout, B, V, cout)
-    out = instnorm_apply(c2, s2, B, V, cout, True, x2=c3, sb=s3)
+    if to_cat:
+        _, half = skip_half(dims, cout, prec, x.device)
+        out = instnorm_apply(c2, s2, B, V, cout, True, x2=c3, sb=s3, out=half, ldo=2 * cout)
+    else:
+        out = instnorm_apply(c2, s2, B, V, cout, True, x2=c3, sb=s3)
     return out, (c1, s1, a1, c2, s2, c3, s3)
 
 
@@ -1113,12 +1135,13 @@ class ResBlockFn(torch.autograd.Function):
     """UnetrBasicBlock(res_block=True) = one UnetResBlock (encoder1, unetr.py:90-98)."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, w3, prec):
+    def forward(ctx, x, w1, w2, w3, prec, to_cat=False):
+        """to_cat: the result is the second half of a fresh concatenation buffer (functional.skip_half)"""
         _require_gpu(x, act=True)
         x, ldx = _rows(x)
         B, D, H, W, cin = x.shape
         cout = w1.shape[0]
-        out, saved = _resblock_fwd(x, ldx, (B, D, H, W), cin, cout, w1, w2, w3, prec)
+        out, saved = _resblock_fwd(x, ldx, (B, D, H, W), cin, cout, w1, w2, w3, prec, to_cat)
         ctx.save_for_backward(x, w1, w2, w3, *saved)
         ctx.meta = (ldx, (B, D, H, W), cin, cout, prec)
         return out
@@ -1128,19 +1151,24 @@ class ResBlockFn(torch.autograd.Function):
         x, w1, w2, w3, *saved = ctx.saved_tensors
         ldx, dims, cin, cout, prec = ctx.meta
         dx, dw1, dw2, dw3 = _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, ctx.needs_input_grad[0])
-        return dx, _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None
+        return dx, _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None, None
 
 
 class TconvFn(torch.autograd.Function):
     """2x2x2 stride-2 ConvTranspose3d, bias=False (UnetrPrUpBlock with conv_block=False, unetr.py:99-134)."""
 
     @staticmethod
-    def forward(ctx, x, w, prec):
+    def forward(ctx, x, w, prec, to_cat=False):
+        """to_cat: the result is the second half of a fresh concatenation buffer (functional.skip_half)"""
         _require_gpu(x, act=True)
         x, ldx = _rows(x)
         B, D, H, W, cin = x.shape
         cout = w.shape[1]
-        y, xb = tconv_fwd(x, ldx, w, (B, D, H, W), cin, cout, prec)
+        if to_cat:
+            _, y = skip_half((B, 2 * D, 2 * H, 2 * W), cout, prec, x.device)
+            _, xb = tconv_fwd(x, ldx, w, (B, D, H, W), cin, cout, prec, out=y, ldo=2 * cout)
+        else:
+            y, xb = tconv_fwd(x, ldx, w, (B, D, H, W), cin, cout, prec)
         ctx.save_for_backward(x, w)
         ctx.xb = xb
         ctx.meta = (ldx, (B, D, H, W), cin, cout, prec)
@@ -1152,7 +1180,7 @@ class TconvFn(torch.autograd.Function):
         ldx, dims, cin, cout, prec = ctx.meta
         dy, lddy = _rows(dy)
         dx, dw = tconv_bwd(x, ldx, ctx.xb, dy, lddy, w, dims, cin, cout, prec, ctx.needs_input_grad[0])
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class UpBlockFn(torch.autograd.Function):
@@ -1160,17 +1188,23 @@ class UpBlockFn(torch.autograd.Function):
     The transposed conv writes straight into the first half of the concatenation buffer."""
 
     @staticmethod
-    def forward(ctx, inp, skip, wt, w1, w2, w3, prec):
+    def forward(ctx, inp, skip, wt, w1, w2, w3, prec, skip_in_cat=False):
+        """skip_in_cat: ``skip`` already is the second half of a concatenation buffer made by functional.skip_half (its
+        producer ran with to_cat=True): no copy"""
         _require_gpu(inp, act=True)
         inp, ldi = _rows(inp)
         B, D, H, W, cin = inp.shape
         C = wt.shape[1]
         dims2 = (B, 2 * D, 2 * H, 2 * W)
         rows2 = B * 8 * D * H * W
-        cat = torch.empty(*dims2, 2 * C, dtype=act_dtype(prec), device=inp.device)
-        skip, lds = _rows(_as_act(skip, prec))
-        _, ctx.xb = tconv_fwd(inp, ldi, wt, (B, D, H, W), cin, C, prec, out=cat, ldo=2 * C)
-        call("unetr_copy_rows", cat.data_ptr() + cat.element_size() * C, 2 * C, skip.data_ptr(), lds, rows2, C, 0, _a16(cat), _stream())
+        if skip_in_cat and skip.dtype == act_dtype(prec):
+            cat = cat_of_skip(skip, C)
+            _, ctx.xb = tconv_fwd(inp, ldi, wt, (B, D, H, W), cin, C, prec, out=cat, ldo=2 * C)
+        else:
+            cat = torch.empty(*dims2, 2 * C, dtype=act_dtype(prec), device=inp.device)
+            skip, lds = _rows(_as_act(skip, prec))
+            _, ctx.xb = tconv_fwd(inp, ldi, wt, (B, D, H, W), cin, C, prec, out=cat, ldo=2 * C)
+            call("unetr_copy_rows", cat.data_ptr() + cat.element_size() * C, 2 * C, skip.data_ptr(), lds, rows2, C, 0, _a16(cat), _stream())
         out, saved = _resblock_fwd(cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, prec)
         ctx.save_for_backward(inp, wt, w1, w2, w3, cat, *saved)
         ctx.meta = (ldi, (B, D, H, W), cin, C, prec)
@@ -1185,7 +1219,7 @@ class UpBlockFn(torch.autograd.Function):
         dcat, dw1, dw2, dw3 = _resblock_bwd(dout, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True)
         dinp, dwt = tconv_bwd(inp, ldi, ctx.xb, dcat, 2 * C, wt, dims, cin, C, prec, ctx.needs_input_grad[0])
         dskip = dcat[..., C:] if ctx.needs_input_grad[1] else None
-        return dinp, dskip, dwt, _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None
+        return dinp, dskip, dwt, _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None, None
 
 
 class OutConvFn(torch.autograd.Function):

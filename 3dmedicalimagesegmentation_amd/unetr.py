@@ -344,12 +344,13 @@ class UNETR(nn.Module):
         x = Fn.LayerNormFn.apply(x, self.vit.norm.weight, self.vit.norm.bias,
                                  Fn._bf16_path(prec, self.hidden_size, self.vit.blocks[0].mlp.linear1.weight.shape[0]))
         x = cut(x, 0)
-        enc1 = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec)
+        # every skip tensor is produced straight into the second half of the decoder's concatenation buffer (to_cat)
+        enc1 = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec, True)
         enc = []
         for tap, blk in ((3, self.encoder2), (6, self.encoder3), (9, self.encoder4)):
-            t = Fn.TconvFn.apply(self._tokens_cl(hidden_states_out[tap], B), blk.transp_conv_init.conv.weight, prec)
-            for sub in blk.blocks:
-                t = Fn.TconvFn.apply(t, sub.conv.weight, prec)
+            t = Fn.TconvFn.apply(self._tokens_cl(hidden_states_out[tap], B), blk.transp_conv_init.conv.weight, prec, len(blk.blocks) == 0)
+            for k, sub in enumerate(blk.blocks):
+                t = Fn.TconvFn.apply(t, sub.conv.weight, prec, k == len(blk.blocks) - 1)
             enc.append(t)
         return x, enc1, enc[0], enc[1], enc[2]
 
@@ -357,13 +358,13 @@ class UNETR(nn.Module):
         B = x_in.shape[0]
         dec4 = self._tokens_cl(x, B)
         d = self.decoder5
-        dec3 = Fn.UpBlockFn.apply(dec4, enc4, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec)
+        dec3 = Fn.UpBlockFn.apply(dec4, enc4, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
         d = self.decoder4
-        dec2 = Fn.UpBlockFn.apply(dec3, enc3, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec)
+        dec2 = Fn.UpBlockFn.apply(dec3, enc3, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
         d = self.decoder3
-        dec1 = Fn.UpBlockFn.apply(dec2, enc2, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec)
+        dec1 = Fn.UpBlockFn.apply(dec2, enc2, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
         d = self.decoder2
-        out = Fn.UpBlockFn.apply(dec1, enc1, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec)
+        out = Fn.UpBlockFn.apply(dec1, enc1, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
         logits = Fn.OutConvFn.apply(out, self.out.conv.conv.weight, self.out.conv.conv.bias)
         return Fn.ToNCDHWFn.apply(enc4), logits
 

@@ -606,3 +606,42 @@ def test_attention_bf16_storage(pkg, dev, B, L, heads):
     dqb = Fn.attention_bf16_bwd(qd, outb, dout.to(dev), lse, B, L, heads, dh, dqkv=dq32)
     assert relerr(dq32, ref_in.grad) < 2e-2
     assert torch.equal(dqb.cpu(), dq32.cpu().bfloat16())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("producer", ["tconv", "resblock"])
+def test_skip_written_into_concat_buffer(pkg, dev, prec, producer):
+    """torch.cat((up, skip), dim=1) of UnetrUpBlock (unetr.py:135-174) without the copy: the skip's producer writes the second
+    half of the concatenation buffer (to_cat), UpBlockFn(skip_in_cat=True) the first.  Bit-identical to the copying path,
+    outputs and every gradient."""
+    Fn = pkg.functional
+    B, S, C = 2, 8, 16
+    adt = Fn.act_dtype(prec)
+    inp = act(cl(g(B, 2 * C, S, S, S, seed=1)), prec, dev)                       # decoder input at half resolution
+    wt = (g(2 * C, C, 2, 2, 2, seed=2) * 0.2).to(dev)
+    w1, w2, w3 = (g(C, 2 * C, 3, 3, 3, seed=3) * 0.1).to(dev), (g(C, C, 3, 3, 3, seed=4) * 0.1).to(dev), (g(C, 2 * C, 1, 1, 1, seed=5) * 0.2).to(dev)
+    if producer == "tconv":
+        src = act(cl(g(B, 32, S, S, S, seed=6)), prec, dev)
+        pw = [(g(32, C, 2, 2, 2, seed=7) * 0.2).to(dev)]
+        make = lambda s, p, to_cat: Fn.TconvFn.apply(s, p[0], prec, to_cat)
+    else:
+        src = act(cl(g(B, 8, 2 * S, 2 * S, 2 * S, seed=6)), prec, dev)
+        pw = [(g(C, 8, 3, 3, 3, seed=7) * 0.1).to(dev), (g(C, C, 3, 3, 3, seed=8) * 0.1).to(dev), (g(C, 8, 1, 1, 1, seed=9) * 0.2).to(dev)]
+        make = lambda s, p, to_cat: Fn.ResBlockFn.apply(s, *p, prec, to_cat)
+    dout = act(cl(g(B, C, 2 * S, 2 * S, 2 * S, seed=10)), prec, dev)
+    res = []
+    for in_cat in (False, True):
+        leaves = [t.clone().requires_grad_(True) for t in (inp.float(), src.float(), wt, w1, w2, w3, *pw)]
+        i_, s_, wt_, w1_, w2_, w3_, *pw_ = leaves
+        skip = make(s_.to(adt), pw_, in_cat)
+        assert skip.shape == (B, 2 * S, 2 * S, 2 * S, C)
+        assert (skip.stride(-2) == 2 * C) == in_cat
+        out = Fn.UpBlockFn.apply(i_.to(adt), skip, wt_, w1_, w2_, w3_, prec, in_cat)
+        out.backward(dout)
+        res.append([out.detach()] + [t.grad for t in leaves])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # a tensor that is not the second half of such a buffer is refused rather than overwritten
+    with pytest.raises(RuntimeError):
+        Fn.UpBlockFn.apply(inp, torch.zeros(B, 2 * S, 2 * S, 2 * S, C, device=dev, dtype=adt), wt, w1, w2, w3, prec, True)
