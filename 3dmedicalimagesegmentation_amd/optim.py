@@ -126,15 +126,38 @@ class AdamW(torch.optim.Optimizer):
         return True
 
     # ---- data-parallel arena update: all-reduce pieces overlap the optimizer kernels of the pieces before them ----
-    def plan_reduced(self, max_elems=None, cuts=()):
-        """Freeze the current gradient pattern (which parameters have .grad) into arena ranges of <= max_elems that never
-        straddle an offset in ``cuts``.  The plan is reused every step by ``step_reduced`` -- under hipGraph replay
-        ``.grad`` attributes do not change."""
+    def plan_reduced(self, max_elems=None, cuts=(), pattern=None):
+        """Freeze a gradient pattern (default: which parameters have .grad now) into arena ranges of <= max_elems that never
+        straddle an offset in ``cuts``.  The plan is reused every step by ``step_reduced`` / ``step_runs`` -- under hipGraph
+        replay ``.grad`` attributes do not change."""
         if self._flat is None or len(self.param_groups) != 1:
             raise RuntimeError("plan_reduced needs AdamW(..., flat=model.use_flat_buffers())")
         params = self.param_groups[0]["params"]
-        pattern = tuple(p.grad is not None for p in params)
+        pattern = tuple(p.grad is not None for p in params) if pattern is None else tuple(bool(f) for f in pattern)
         return dict(pattern=pattern, runs=self._flat_runs(params, pattern, max_elems, cuts))
+
+    # ---- the reduced step in pieces (train_step.TrainStep, data-parallel form): begin -> step_runs per piece -> end, each on
+    # whatever stream is current (the communication stream, right behind the piece's all-reduce)
+    @torch.no_grad()
+    def begin_reduced_step(self, plan):
+        if self._flat_state is None:
+            self._flat_state = (torch.zeros_like(self._flat["param"]), torch.zeros_like(self._flat["param"]))
+        return self._advance_steps(0, self.param_groups[0]["params"], plan["pattern"], self._flat["param"].device)
+
+    @torch.no_grad()
+    def step_runs(self, plan, ks, steps, gsrc, gscale):
+        g_bf16 = gsrc.dtype == torch.bfloat16
+        if not g_bf16 and gsrc.dtype != torch.float32:
+            raise RuntimeError("gradient source must be fp32 or bf16")
+        stream = torch.cuda.current_stream().cuda_stream
+        for k in ks:
+            self._launch_run(self.param_groups[0], plan["runs"][k], steps, gsrc.data_ptr(), g_bf16, gscale, stream)
+
+    @torch.no_grad()
+    def end_reduced_step(self, plan):
+        if self._flat.get("shadow") is not None:
+            Fn.mark_flat_maintained([p for p, has in zip(self.param_groups[0]["params"], plan["pattern"]) if has])
+        Fn.refresh_conv_packs()
 
     @torch.no_grad()
     def step_reduced(self, plan, gsrc, gscale, before_run=None, order=None):
