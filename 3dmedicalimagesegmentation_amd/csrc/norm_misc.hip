@@ -286,6 +286,58 @@ in_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ sa,
     }
 }
 
+// The same pass for channel counts whose 16-byte pieces divide the block (C / W a power of two <= 256: every layer of the
+// network): block = (voxel chunk, batch item), thread = (piece cv, phase), so the statistics of the thread's channels are
+// folded into multiply-add coefficients ONCE instead of being re-read from global memory for every element (the generic
+// kernel above issues 32 scalar loads of statistics per 16 bytes of data).
+template <class T, bool DUAL>
+__global__ void __launch_bounds__(256)
+in_apply_hoist_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ sa, const T* __restrict__ x2, long ldx2,
+                      const float* __restrict__ sb, T* __restrict__ y, long ldy, long V, long vpb, int C, int lrelu) {
+    constexpr int W = Io<T>::W, U = 2;
+    const int cvn = C / W, nphase = 256 / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    const float* s1 = sa + ((long)b * C + W * cv) * 2;
+    const float* s2 = DUAL ? sb + ((long)b * C + W * cv) * 2 : nullptr;
+    float a1[W], o1[W], a2[DUAL ? W : 1];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        a1[e] = s1[2 * e + 1]; o1[e] = -s1[2 * e] * a1[e];
+        if (DUAL) { a2[e] = s2[2 * e + 1]; o1[e] -= s2[2 * e] * a2[e]; }      // both offsets in one constant
+    }
+    const float slope = lrelu ? 0.01f : 1.f;
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    const T* px2 = DUAL ? x2 + ((long)b * V) * ldx2 + W * cv : nullptr;
+    T* py = y + ((long)b * V) * ldy + W * cv;
+    for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+        u32x4 rt[U], rt2[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long vv = v + (long)u * nphase;
+            live[u] = vv < v1;
+            const long vc = live[u] ? vv : v;
+            rt[u] = *(const u32x4*)(px + vc * ldx);
+            rt2[u] = DUAL ? *(const u32x4*)(px2 + vc * ldx2) : rt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float t[W], t2[W], o[W];
+            Io<T>::unpack(rt[u], t);
+            if (DUAL) Io<T>::unpack(rt2[u], t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float n = fmaf(t[e], a1[e], o1[e]);
+                if (DUAL) n = fmaf(t2[e], a2[e], n);
+                o[e] = n > 0.f ? n : slope * n;
+            }
+            if (live[u]) Io<T>::stw(py + (v + (long)u * nphase) * ldy, o);
+        }
+    }
+}
+
 // backward stage 1: per (b,c) sums of g, g*n1, g*n2 with g = dy * lrelu'(n1+n2).  DUAL = the block-end form (two normalised
 // inputs summed before the activation).  One block = `vpb` consecutive voxels of one batch element (the host sizes vpb so
 // that the grid is about three blocks per CU: with 1024-voxel blocks the prologue / block reduction were most of a block's
@@ -429,6 +481,71 @@ in_bwd_apply_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x
 #pragma unroll
             for (int e = 0; e < W; ++e) o[e] = s2[2 * e + 1] * (g[e] - sm[3 * e] - n2[e] * sm[3 * e + 2]);
             Io<T>::stw(dx2 + vox * lddx2 + W * cv, o);
+        }
+    }
+}
+
+// hoisted-coefficient form of the pass above (see in_apply_hoist_kernel): dx = a1*g - a1*m0 - a1*m1*n1 with g the
+// lrelu-masked gradient, n1 = t*a1 + o1; the second branch alike.  56 scalar loads of statistics per 16 bytes before.
+template <class T, bool DUAL>
+__global__ void __launch_bounds__(256)
+in_bwd_apply_hoist_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
+                          const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, const float* __restrict__ sums,
+                          T* __restrict__ dx, long lddx, T* __restrict__ dx2, long lddx2, long V, long vpb, int C, int lrelu) {
+    constexpr int W = Io<T>::W, U = 2;
+    const int cvn = C / W, nphase = 256 / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    const float* s1 = sa + ((long)b * C + W * cv) * 2;
+    const float* s2 = DUAL ? sb + ((long)b * C + W * cv) * 2 : nullptr;
+    const float* sm = sums + ((long)b * C + W * cv) * 3;
+    float a1[W], o1[W], k0[W], k1[W], a2[DUAL ? W : 1], o2[DUAL ? W : 1], q0[DUAL ? W : 1], q2[DUAL ? W : 1];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        a1[e] = s1[2 * e + 1]; o1[e] = -s1[2 * e] * a1[e];
+        k0[e] = a1[e] * sm[3 * e]; k1[e] = a1[e] * sm[3 * e + 1];
+        if (DUAL) {
+            a2[e] = s2[2 * e + 1]; o2[e] = -s2[2 * e] * a2[e];
+            q0[e] = a2[e] * sm[3 * e]; q2[e] = a2[e] * sm[3 * e + 2];
+        }
+    }
+    const float slope = lrelu ? 0.01f : 1.f;
+    const T* pg = dy + ((long)b * V) * lddy + W * cv;
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    const T* px2 = DUAL ? x2 + ((long)b * V) * ldx2 + W * cv : nullptr;
+    T* pd = dx + ((long)b * V) * lddx + W * cv;
+    T* pd2 = DUAL ? dx2 + ((long)b * V) * lddx2 + W * cv : nullptr;
+    for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+        u32x4 rg[U], rt[U], rt2[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long vv = v + (long)u * nphase;
+            live[u] = vv < v1;
+            const long vc = live[u] ? vv : v;
+            rg[u] = *(const u32x4*)(pg + vc * lddy);
+            rt[u] = *(const u32x4*)(px + vc * ldx);
+            rt2[u] = DUAL ? *(const u32x4*)(px2 + vc * ldx2) : rt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float g[W], t[W], t2[W], o[W], p[W];
+            Io<T>::unpack(rg[u], g);
+            Io<T>::unpack(rt[u], t);
+            if (DUAL) Io<T>::unpack(rt2[u], t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float n1 = fmaf(t[e], a1[e], o1[e]);
+                const float n2 = DUAL ? fmaf(t2[e], a2[e], o2[e]) : 0.f;
+                const float ge = (n1 + n2) > 0.f ? g[e] : slope * g[e];
+                o[e] = fmaf(a1[e], ge, -k0[e]) - k1[e] * n1;
+                if (DUAL) p[e] = fmaf(a2[e], ge, -q0[e]) - q2[e] * n2;
+            }
+            if (live[u]) {
+                Io<T>::stw(pd + (v + (long)u * nphase) * lddx, o);
+                if (DUAL) Io<T>::stw(pd2 + (v + (long)u * nphase) * lddx2, p);
+            }
         }
     }
 }
@@ -711,6 +828,13 @@ adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale,
     }
 }
 
+// voxel chunks for the (chunk, batch item) kernels: about `blocks` workgroups in all, each a whole number of `step`-voxel
+// iterations of its threads (at least one)
+inline void in_chunks(long V, int B, long step, long blocks, long& vpb, int& nchunk) {
+    vpb = std::max<long>(step, ((V * B + blocks - 1) / blocks + step - 1) / step * step);
+    nchunk = (int)((V + vpb - 1) / vpb);
+}
+
 inline int grid_for(long total, int per_block = 256, int cap = 8192) {
     long b = (total + per_block - 1) / per_block;
     return (int)std::max<long>(1, std::min<long>(b, cap));
@@ -830,6 +954,17 @@ extern "C" int unetr_instnorm_apply(const void* x, long ldx, const float* sa, co
     const int W = act16 ? 8 : 4;
     if ((C % W) || (ldx % W) || (ldy % W) || (x2 && (ldx2 % W))) return UNETR_ERR_UNSUPPORTED;
     long total = (long)B * V * (C / W);
+    const int cvn = C / W;
+    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)x2) & 15) == 0;
+    if (al && cvn <= 256 && (cvn & (cvn - 1)) == 0 && B <= 65535) {
+        long vpb; int nchunk;
+        in_chunks(V, B, 2 * (256 / cvn), 2048, vpb, nchunk);
+        if (x2) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_hoist_kernel<AT, true>), dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, (const AT*)x, ldx, sa,
+                                                       (const AT*)x2, ldx2, sb, (AT*)y, ldy, V, vpb, C, lrelu));
+        else ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_hoist_kernel<AT, false>), dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, (const AT*)x, ldx, sa,
+                                                    (const AT*)x2, ldx2, sb, (AT*)y, ldy, V, vpb, C, lrelu));
+        return unetr_check_launch();
+    }
     ACT_DISPATCH(act16, hipLaunchKernelGGL(in_apply_kernel<AT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const AT*)x, ldx, sa,
                                            (const AT*)x2, ldx2, sb, (AT*)y, ldy, B, V, C, lrelu));
     return unetr_check_launch();
@@ -863,6 +998,16 @@ extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long
 #undef IN_RED
     hipLaunchKernelGGL(in_bwd_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, B, sums);
     long total = (long)B * V * (C / W);
+    const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)x2 | (uintptr_t)dx | (uintptr_t)dx2) & 15) == 0;
+    if (al && B <= 65535) {          // (in_check: C / W divides the block)
+        long vpa; int nca;
+        in_chunks(V, B, 2 * nphase, 2048, vpa, nca);
+        if (x2) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_apply_hoist_kernel<AT, true>), dim3(nca, B), dim3(256), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
+                                                       (const AT*)x2, ldx2, sb, sums, (AT*)dx, lddx, (AT*)dx2, lddx2, V, vpa, C, lrelu));
+        else ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_apply_hoist_kernel<AT, false>), dim3(nca, B), dim3(256), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
+                                                    (const AT*)x2, ldx2, sb, sums, (AT*)dx, lddx, (AT*)dx2, lddx2, V, vpa, C, lrelu));
+        return unetr_check_launch();
+    }
     ACT_DISPATCH(act16, hipLaunchKernelGGL(in_bwd_apply_kernel<AT>, dim3(grid_for(total)), dim3(256), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
                                            (const AT*)x2, ldx2, sb, sums, (AT*)dx, lddx, (AT*)dx2, lddx2, B, V, C, lrelu));
     return unetr_check_launch();
