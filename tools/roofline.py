@@ -82,10 +82,10 @@ def _family_of(name):
     return "other (packs, casts, column sums, copies, fills)"
 
 
-def _kernel_times(run, reps=6, once_per_step="dicece_fwd_kernel"):
-    """{kernel name: (device us per step, launches per step)} of `run()` via torch.profiler.  The tracer may drop the records
-    of a replay at either end of the window, so the number of steps actually recorded is read off a kernel that runs exactly
-    once per step (the loss forward)."""
+def _kernel_times(run, reps=7, once_per_step="dicece_fwd_kernel"):
+    """{kernel name: (device us per step, launches per step)} of `run()` via torch.profiler.  The tracer may drop records of the
+    replays at either end of the window, so only the launches between the first and the last occurrence of a kernel that runs
+    exactly once per step (the loss forward) are counted: whole steps, mid-step to mid-step."""
     from torch.profiler import ProfilerActivity, profile
     run()
     torch.cuda.synchronize()
@@ -93,16 +93,26 @@ def _kernel_times(run, reps=6, once_per_step="dicece_fwd_kernel"):
         for _ in range(reps):
             run()
         torch.cuda.synchronize()
-    evs = []
-    for ev in prof.key_averages():
-        t = getattr(ev, "device_time_total", None)
-        if t is None:
-            t = getattr(ev, "cuda_time_total", 0.0)
-        if t <= 0 or ev.key.startswith("hip") or ev.key.startswith("Memcpy") or ev.key.startswith("Memset"):
+    raw = []
+    for ev in prof.events():
+        if "cuda" not in str(getattr(ev, "device_type", "")).lower():
             continue
-        evs.append((ev.key, t, ev.count))
-    steps = next((c for k, t, c in evs if once_per_step in k), reps)
-    return {k: (t / steps, c / steps) for k, t, c in evs}
+        k = ev.name
+        if k.startswith("hip") or k.startswith("Memcpy") or k.startswith("Memset"):
+            continue
+        tr = ev.time_range
+        raw.append((tr.start, tr.end - tr.start, k))
+    raw.sort()
+    marks = [i for i, (_, _, k) in enumerate(raw) if once_per_step in k]
+    if len(marks) >= 2:
+        raw, steps = raw[marks[0]:marks[-1]], len(marks) - 1
+    else:
+        steps = reps
+    acc = {}
+    for _, d, k in raw:
+        t, c = acc.get(k, (0.0, 0))
+        acc[k] = (t + d, c + 1)
+    return {k: (t / steps, c / steps) for k, (t, c) in acc.items() if t > 0}
 
 
 def _short(name):
