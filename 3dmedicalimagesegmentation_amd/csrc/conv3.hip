@@ -560,6 +560,11 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
             halo_store<P, NCH, XM, LAY>(R, PITCH, halo);    // (waits for the prefetched loads)
             if constexpr (WLN > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's weight DMA pieces have landed
             __syncthreads();
+            // every older VMEM operation (the previous tile's output stores) has retired before the prefetch below is issued: the
+            // fragment registers of the MFMA phase are the ones those stores read, and guarding them with the in-order vmcnt
+            // counter AFTER the prefetch had been issued made the MFMA phase wait for the prefetch itself (s_waitcnt vmcnt(0)
+            // at its top)
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only
             {   // prefetch the next (tile, slab) window; it lands while the MFMAs below run
                 int ntile = tile, nslb = slab + 1;
                 if (nslb == nslab) { ntile = tile + gridDim.x; nslb = 0; }
@@ -573,26 +578,37 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                 }
             }
             if constexpr (PAIR) {
+                // 56 (tap pair, row) steps; the window fragments of the next DPT steps are in flight while a step's MFMAs run
+                // (written as load, MFMA, load, MFMA the compiler kept exactly that order with ONE fragment register and a
+                // full lgkmcnt(0) wait per MFMA: ~130 cycles of LDS latency exposed 56 times per tile = 80 % of the tile time)
                 const char* hb0 = halo + ((wv * HY) * HX + r) * PITCH + (g & 1) * 16;
-#pragma unroll
-                for (int tp = 0; tp < 14; ++tp) {
-                    constexpr int dummy = 0; (void)dummy;
+                const bool upper = (g >> 1) != 0;
+                constexpr int NSTEP = 14 * 4, DPT = 12;
+                auto frag = [&](int s) {
+                    const int tp = s >> 2, i = s & 3;
                     const int tA = 2 * tp, tB = (2 * tp + 1 < 27) ? 2 * tp + 1 : 26;
                     const int offA = (((tA / 9) * HY + (tA % 9) / 3) * HX + tA % 3) * PITCH;
                     const int offB = (((tB / 9) * HY + (tB % 9) / 3) * HX + tB % 3) * PITCH;
-                    const char* hbase = hb0 + ((g >> 1) ? offB : offA);
+                    return *(const u32x4*)(hb0 + (upper ? offB : offA) + i * HX * PITCH);
+                };
+                u32x4 ring[DPT];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        u32x4 a = *(const u32x4*)(hbase + i * HX * PITCH);
+                for (int s = 0; s < DPT; ++s) ring[s] = frag(s);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], wres[tp][j], a);
-                        if constexpr (has3) {
-                            if (tp == 6) {             // w3res is zero on the tap-12 half of the K range
+                for (int s = 0; s < NSTEP; ++s) {
+                    const int tp = s >> 2, i = s & 3;
+                    const u32x4 a = ring[s % DPT];
 #pragma unroll
-                                for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
-                            }
+                    for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], wres[tp][j], a);
+                    if constexpr (has3) {
+                        if (tp == 6) {             // w3res is zero on the tap-12 half of the K range
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
                         }
                     }
+                    if (s + DPT < NSTEP) ring[s % DPT] = frag(s + DPT);
+                    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks every load back in front of its use)
                 }
             } else if constexpr (WLN > 0) {
                 const int xo3[3] = {lay_off<LAY>(r, g, PITCH), lay_off<LAY>(r + 1, g, PITCH), lay_off<LAY>(r + 2, g, PITCH)};
@@ -601,28 +617,39 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 #pragma unroll
                     for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)slab * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
                 }
-                for (int tr = 0; tr < 9; ++tr) {          // (dz, dy) rows of three taps
-                    const int dz = tr / 3, dy = tr - dz * 3;
-                    const char* hrow = halo + (((wv + dz) * HY + dy) * HX) * PITCH;
+                // 108 (tap, row) steps, software-pipelined like the pair loop above: window fragments DPT steps ahead, the weight
+                // fragments of the next tap one tap ahead
+                constexpr int NSTEP = 27 * 4, DPT = NTB == 1 ? 10 : 8;
+                const char* hw = halo + (wv * HY * HX) * PITCH;
+                auto afrag = [&](int s) {
+                    const int tap = s >> 2, i = s & 3;
+                    const int dz = tap / 9, dy = (tap % 9) / 3, dx = tap % 3;
+                    return *(const u32x4*)(hw + ((dz * HY + dy) * HX + i * HX) * PITCH + xo3[dx]);
+                };
+                u32x4 ring[DPT], bw[2][NTB];
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int tap = tr * 3 + dx;
-                        u32x4 bw[NTB];
+                for (int j = 0; j < NTB; ++j) bw[0][j] = *(const u32x4*)(wb + j * 1024);
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) bw[j] = *(const u32x4*)(wb + (tap * NTB + j) * 1024);
+                for (int s = 0; s < DPT; ++s) ring[s] = afrag(s);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const u32x4 a = *(const u32x4*)(hrow + xo3[dx] + i * HX * PITCH);
+                for (int s = 0; s < NSTEP; ++s) {
+                    const int tap = s >> 2, i = s & 3;
+                    if (i == 0 && tap + 1 < 27) {
 #pragma unroll
-                            for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], bw[j], a);
-                            if constexpr (has3) {
-                                if (tap == 13) {
+                        for (int j = 0; j < NTB; ++j) bw[(tap + 1) & 1][j] = *(const u32x4*)(wb + ((tap + 1) * NTB + j) * 1024);
+                    }
+                    const u32x4 a = ring[s % DPT];
 #pragma unroll
-                                    for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
-                                }
-                            }
+                    for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], bw[tap & 1][j], a);
+                    if constexpr (has3) {
+                        if (tap == 13) {
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
                         }
                     }
+                    if (s + DPT < NSTEP) ring[s % DPT] = afrag(s + DPT);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 ++wit;
             } else {
