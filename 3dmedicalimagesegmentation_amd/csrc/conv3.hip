@@ -185,6 +185,26 @@ __device__ __forceinline__ void tile_coords(int id, int total, int ntx, int nty,
     ty = yb * YB + yi;
 }
 
+// The tiles a persistent workgroup walks (blockIdx.x + k * gridDim.x, k = 0, 1, ...) with their coordinates computed 64 at a
+// time, one per lane (tx | ty << 8 | tz << 16 | b << 24), and fetched per tile with one v_readlane: tile_coords is five
+// integer divisions on the scalar unit -- ~100 SALU instructions, twice per tile (current + prefetched), on a unit the waves
+// of a CU share.  (The host rejects shapes whose tile counts / batch exceed 255.)
+struct TileTable {
+    unsigned packed;
+    __device__ __forceinline__ void fill(int k0, int ntiles, int ntx, int nty, int ntz) {
+        const int t = blockIdx.x + (k0 + (int)(threadIdx.x & 63)) * gridDim.x;
+        int tx = 0, ty = 0, tz = 0, b = 0;
+        if (t < ntiles) tile_coords(t, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        packed = (unsigned)tx | ((unsigned)ty << 8) | ((unsigned)tz << 16) | ((unsigned)b << 24);
+    }
+    // coordinates of the k-th tile of this workgroup; refills the table when k enters a new group of 64
+    __device__ __forceinline__ void get(int k, int ntiles, int ntx, int nty, int ntz, int& tx, int& ty, int& tz, int& b) {
+        if ((k & 63) == 0) fill(k, ntiles, ntx, nty, ntz);
+        const unsigned pk = __builtin_amdgcn_readlane(packed, k & 63);
+        tx = pk & 255u; ty = (pk >> 8) & 255u; tz = (pk >> 16) & 255u; b = pk >> 24;
+    }
+};
+
 template <class P, int NTB, int XM>
 __global__ void __launch_bounds__(256)
 conv3_fwd_kernel(const void* __restrict__ x, long ldx, const char* __restrict__ wp, typename ActOf<P>::type* __restrict__ y, long ldy, int accumulate,
@@ -385,6 +405,77 @@ __device__ __forceinline__ void halo_store(const HaloRegs<P, NCH>& R, int pitch,
     }
 }
 
+// ---- the tile-invariant part of the window staging (bf16-stored input, XM == 2), computed ONCE per thread: which window piece
+// a thread loads in iteration j, its element offset relative to the window origin, and where it goes in LDS.  Per tile only a
+// wave-uniform base offset is added; tiles whose window lies inside the volume (wave-uniform test) skip the per-piece bounds
+// checks.  Before, every tile re-derived all of it per piece (div / mod chains, three range checks, 64-bit multiplies): with
+// the MFMA loop, the loads and the stores removed the kernel still took 24 of its 52 us at 96^3 x 16 channels.
+template <int NCH>
+struct HaloPlan {
+    static constexpr int ITERS = (NHALO * NCH + 255) / 256;
+    int rel[ITERS];           // element offset from the window origin (voxel (z0-1, y0-1, x0-1), channel c0)
+    int lo[ITERS];            // byte offset in the LDS window
+    unsigned pk[ITERS];       // hz | hy << 8 | hx << 16 | chunk << 24
+    unsigned valid;           // okbits of a fully interior window
+};
+template <class P, int NCH, int LAY>
+__device__ __forceinline__ void halo_plan(HaloPlan<NCH>& pl, int H, int W, int ld32, int pitch) {
+    constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
+    pl.valid = 0;
+#pragma unroll
+    for (int j = 0; j < HaloPlan<NCH>::ITERS; ++j) {
+        const int id = threadIdx.x + j * 256;
+        const bool v = id < TOTAL;
+        const int hv = v ? id / NCH : 0, ch = v ? id - hv * NCH : 0;
+        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        pl.rel[j] = ((hz * H + hy) * W + hx) * ld32 + ch * CH;
+        pl.lo[j] = lay_off<LAY>(hv, ch, pitch);
+        pl.pk[j] = (unsigned)hz | ((unsigned)hy << 8) | ((unsigned)hx << 16) | ((unsigned)ch << 24);
+        pl.valid |= v ? (((1u << NQ) - 1u) << (j * NQ)) : 0u;
+    }
+}
+template <class P, int NCH>
+__device__ __forceinline__ void halo_load_planned(HaloRegs<P, NCH>& R, const HaloPlan<NCH>& pl, const uint16_t* __restrict__ xh,
+                                                  int ld32, int z0, int y0, int x0, int D, int H, int W, int c0, int Cin) {
+    constexpr int CH = P::CH, TOTAL = NHALO * NCH, NQ = CH / 4;
+    const int base = (((z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * ld32 + c0;          // wave-uniform (negative on some borders)
+    const bool interior = z0 >= 1 && z0 - 1 + HZ <= D && y0 >= 1 && y0 - 1 + HY <= H && x0 >= 1 && x0 - 1 + HX <= W && c0 + NCH * CH <= Cin;
+    if (interior) {
+#pragma unroll
+        for (int j = 0; j < HaloPlan<NCH>::ITERS; ++j) {
+            const bool v = (j + 1) * 256 <= TOTAL || (int)threadIdx.x + j * 256 < TOTAL;
+            R.v[j][0] = __builtin_bit_cast(f32x4, *(const u32x4*)(xh + (v ? base + pl.rel[j] : 0)));
+        }
+        R.okbits = pl.valid;
+    } else {
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < HaloPlan<NCH>::ITERS; ++j) {
+            const unsigned k = pl.pk[j];
+            const int gz = z0 - 1 + (int)(k & 255u), gy = y0 - 1 + (int)((k >> 8) & 255u), gx = x0 - 1 + (int)((k >> 16) & 255u);
+            const int c = c0 + (int)(k >> 24) * CH;
+            const bool ok = (int)threadIdx.x + j * 256 < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
+                            (unsigned)gx < (unsigned)W && c < Cin;
+            R.v[j][0] = __builtin_bit_cast(f32x4, *(const u32x4*)(xh + (ok ? base + pl.rel[j] : 0)));
+            bits |= ok ? (((1u << NQ) - 1u) << (j * NQ)) : 0u;
+        }
+        R.okbits = bits;
+    }
+}
+template <class P, int NCH>
+__device__ __forceinline__ void halo_store_planned(const HaloRegs<P, NCH>& R, const HaloPlan<NCH>& pl, char* halo) {
+    constexpr int TOTAL = NHALO * NCH, NQ = P::CH / 4;
+#pragma unroll
+    for (int j = 0; j < HaloPlan<NCH>::ITERS; ++j) {
+        if ((j + 1) * 256 <= TOTAL || (int)threadIdx.x + j * 256 < TOTAL) {
+            u32x4 w = __builtin_bit_cast(u32x4, R.v[j][0]);
+            const bool ok = (R.okbits >> (j * NQ)) & 1u;            // (bf16: both bits of a piece carry the same mask)
+            w = ok ? w : (u32x4){0u, 0u, 0u, 0u};
+            *(u32x4*)(halo + pl.lo[j]) = w;
+        }
+    }
+}
+
 // pair-mode weights: wp[pair][n][k], k = (tap - 2*pair)*16 + ci   (bf16; zero for tap 27 and ci >= K)
 __global__ void conv3_pack_pair_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Cin, int Cout, int mode) {
     const int K = mode ? Cout : Cin, N = mode ? Cin : Cout;
@@ -525,16 +616,25 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         }
     }
 
+    const int ylane = r * (int)ldy + nt0 * 16 + 4 * g;      // this lane's element offset inside an output row of 16 voxels
     HaloRegs<P, NCH> R;
+    HaloPlan<NCH> plan;
+    if constexpr (XM == 2) halo_plan<P, NCH, LAY>(plan, H, W, (int)ldx, PITCH);
+    const long item = (long)D * H * W * ldx;      // elements per batch item
+    auto wload = [&](int b_, int z_, int y_, int x_, int c_) {
+        if constexpr (XM == 2) halo_load_planned<P, NCH>(R, plan, (const uint16_t*)x + b_ * item, (int)ldx, z_, y_, x_, D, H, W, c_, Cin);
+        else halo_load<P, NCH, XM>(R, x, ldx, b_, z_, y_, x_, D, H, W, c_, Cin);
+    };
     int tile = blockIdx.x;
+    TileTable tt;
+    int kt = 0;                       // index of the current tile in this workgroup's walk
+    int tx = 0, ty = 0, tz = 0, b = 0;
     if (tile < ntiles) {
-        int tx, ty, tz, b;
-        tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
-        halo_load<P, NCH, XM>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, 0, Cin);
+        tt.get(0, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        wload(b, tz * TZ, ty * TY, tx * TX, 0);
     }
-    for (; tile < ntiles; tile += gridDim.x) {
-        int tx, ty, tz, b;
-        tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+    for (; tile < ntiles; tile += gridDim.x, ++kt) {
+        int ntx_ = tx, nty_ = ty, ntz_ = tz, nb_ = b;      // coordinates of the next tile (set when its prefetch is issued)
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         f32x4 acc[4][NTB];
         f32x4 acc3[has3 ? 4 : 1][has3 ? NTB : 1];
@@ -557,7 +657,8 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 
         for (int slab = 0; slab < nslab; ++slab) {
             __syncthreads();                       // everyone is done reading the previous window
-            halo_store<P, NCH, XM, LAY>(R, PITCH, halo);    // (waits for the prefetched loads)
+            if constexpr (XM == 2) halo_store_planned<P, NCH>(R, plan, halo);    // (waits for the prefetched loads)
+            else halo_store<P, NCH, XM, LAY>(R, PITCH, halo);
             if constexpr (WLN > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's weight DMA pieces have landed
             __syncthreads();
             // every older VMEM operation (the previous tile's output stores) has retired before the prefetch below is issued: the
@@ -572,9 +673,12 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                     if (wrot && ntile < ntiles) wdma(nslb, (wit + 1) & 1);      // (that image was last read before the barrier above)
                 }
                 if (ntile < ntiles) {
-                    int ax, ay, az, ab;
-                    tile_coords(ntile, ntiles, ntx, nty, ntz, ax, ay, az, ab);
-                    halo_load<P, NCH, XM>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, nslb * SL, Cin);
+                    int ax = tx, ay = ty, az = tz, ab = b;
+                    if (nslb == 0) {
+                        tt.get(kt + 1, ntiles, ntx, nty, ntz, ax, ay, az, ab);
+                        ntx_ = ax; nty_ = ay; ntz_ = az; nb_ = ab;
+                    }
+                    wload(ab, az * TZ, ay * TY, ax * TX, nslb * SL);
                 }
             }
             if constexpr (PAIR) {
@@ -708,11 +812,12 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
             YT* yrow[4];
             bool okv[4];
             const int xo = x0 + r;
+            const long tb = (((long)b * D + zo) * H + y0) * W + x0;          // wave-uniform: voxel (zo, y0, x0)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int yo = y0 + i;
                 okv[i] = zo < D && yo < H && xo < W;
-                yrow[i] = (okv[i] ? y + ((((long)b * D + zo) * H + yo) * W + xo) * ldy : y) + nt0 * 16 + 4 * g;
+                yrow[i] = okv[i] ? y + (tb + (long)i * W) * ldy + ylane : y + (nt0 * 16 + 4 * g);
             }
             if constexpr (FUSE == 4) {
                 // acc += x3[voxel, :] . w3: A rows = the 16 x-positions of output row i (lane r), chunk g of each 64-byte k-block
@@ -789,6 +894,7 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                 stats_add<NTB>(a3, okv, rt1, rt2);
             }
         }
+        tx = ntx_; ty = nty_; tz = ntz_; b = nb_;
     }
     if constexpr (STATS) {
         if (cur_b >= 0) {
@@ -1214,7 +1320,7 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
     }
     if (B16 && fz && fz->k3 > 0 && ((fz->ldy3 & 7) || ((uintptr_t)fz->y3 & 15) || (fz->k3 & 7))) return UNETR_ERR_UNSUPPORTED;
     if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
-    if (conv_pipe_enabled() && ntb <= 4) {
+    if (conv_pipe_enabled() && ntb <= 4 && ntx < 256 && nty < 256 && ntz < 256 && B < 256) {      // (TileTable packs the coordinates in bytes)
         // persistent, software-pipelined kernel: a few resident workgroups per CU walk the tiles
         const bool pair = use_pair<P>(Cin);
         if (B16 && xm != 2 && !pair) return UNETR_ERR_UNSUPPORTED;   // fp32 input in bf16 mode = the image: pair layout only
