@@ -1052,18 +1052,19 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     constexpr bool PIPE = CIS == 1 && PIPE_OK;
     HaloRegs<P, PIPE ? 16 / CH : 1> R;
     f32x4 ybuf[YIT][NQ], y3buf[HAS3 ? YIT : 1][NQ];
+    TileTable tt;
+    int kt = 0, tx = 0, ty = 0, tz = 0, b = 0;
+    if ((int)blockIdx.x < ntiles) tt.get(0, ntiles, ntx, nty, ntz, tx, ty, tz, b);
     if constexpr (PIPE) {
         if ((int)blockIdx.x < ntiles) {
-            int tx, ty, tz, b;
-            tile_coords(blockIdx.x, ntiles, ntx, nty, ntz, tx, ty, tz, b);
             halo_load<P, 16 / CH, XMX>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, ci0, Cin);
             load_dy(dy, lddy, b, tz * TZ, ty * TY, tx * TX, ybuf);
             if constexpr (HAS3) load_dy(dy3, lddy3, b, tz * TZ, ty * TY, tx * TX, y3buf);
         }
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int tx, ty, tz, b;
-        tile_coords(tile, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++kt) {
+        int ax = tx, ay = ty, az = tz, ab = b;            // the next tile's coordinates
+        if (tile + (int)gridDim.x < ntiles) tt.get(kt + 1, ntiles, ntx, nty, ntz, ax, ay, az, ab);
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
         if constexpr (PIPE) {
@@ -1073,8 +1074,6 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
             __syncthreads();
             const int nt = tile + gridDim.x;
             if (nt < ntiles) {
-                int ax, ay, az, ab;
-                tile_coords(nt, ntiles, ntx, nty, ntz, ax, ay, az, ab);
                 halo_load<P, 16 / CH, XMX>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, ci0, Cin);
                 load_dy(dy, lddy, ab, az * TZ, ay * TY, ax * TX, ybuf);
                 if constexpr (HAS3) load_dy(dy3, lddy3, ab, az * TZ, ay * TY, ax * TX, y3buf);
@@ -1087,6 +1086,48 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
             __syncthreads();
         }
 
+        if constexpr (CH == 8 && C::FLIP && XMX == 2) {
+            // bf16, 16-channel slab, conflict-free layout: every per-lane address part is k-block independent (formed once before
+            // the loop: ylane0/1, xs0/1[3]); per read one add of a wave-uniform (k-block, unit) offset.  The NKB x UPW (k-block,
+            // unit) steps run as ONE straight line, software-pipelined: the x fragments of the next DPT steps and the dy fragment
+            // of the next k-block are in flight while a step's MFMA runs (as a guarded loop every MFMA waited for its own two
+            // reads: lgkmcnt(0) 56 times per tile).  A wave's unit beyond the last one (wave 3 without the 1x1x1 units) reads the
+            // centre tap and accumulates into a register that is never written out.
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            constexpr int NST = C::NKB * WG_UPW, DPT = HAS3 ? 4 : 5;      // (fp32-stored x, the image: the guarded loop below -- its prefetch registers leave no room)
+            auto aread = [&](int kb, const char* img, u32x4& af) {
+                const int ykb = kb * 32 * C::PY;
+                s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + ykb + ylane0));
+                s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + ykb + ylane1));
+                s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                af = __builtin_bit_cast(u32x4, a8);
+            };
+            auto bread = [&](int st, s16x4& lo, s16x4& hi) {
+                const int kb = st / WG_UPW, ui = st % WG_UPW;
+                const bool ext1 = HAS3 && ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS;     // wave-uniform
+                const int uo = ((kb >> 1) * HY + (kb & 1) * 2) * HX * C::PX + uoff[ui];    // window row of the k-block's first voxel row
+                lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + uo + (ext1 ? xc0 : xs0[ui % 3])));
+                hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + uo + (ext1 ? xc1 : xs1[ui % 3])));
+            };
+            s16x4 rlo[DPT], rhi[DPT];
+            u32x4 af[2], af3 = {0u, 0u, 0u, 0u};          // dy fragment: this k-block's and the next one's; dy3: fetched two steps before its unit
+            aread(0, yimg, af[0]);
+#pragma unroll
+            for (int st = 0; st < DPT; ++st) bread(st, rlo[st], rhi[st]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int kb = st / WG_UPW, ui = st % WG_UPW;
+                if (ui == 0 && kb + 1 < C::NKB) aread(kb + 1, yimg, af[(kb + 1) & 1]);
+                if constexpr (HAS3) { if (ui == WG_UPW - 3) aread(kb, y3img, af3); }
+                const s16x4 blo = rlo[st % DPT], bhi = rhi[st % DPT];
+                s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                const bool ext1 = HAS3 && ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS;
+                P::mma(acc[ui], ext1 ? af3 : af[kb & 1], __builtin_bit_cast(u32x4, b8));
+                if (st + DPT < NST) bread(st + DPT, rlo[st % DPT], rhi[st % DPT]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         for (int kb = 0; kb < C::NKB; ++kb) {
             if constexpr (CH == 8 && C::FLIP) {
                 // bf16, 16-channel slab, conflict-free layout: every per-lane address part is k-block independent (formed once
@@ -1169,6 +1210,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
                 }
             }
         }
+        tx = ax; ty = ay; tz = az; b = ab;
     }
     // partial sums: part[blockIdx.x][co][ci][tap]
 #pragma unroll
@@ -1412,6 +1454,7 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     const int ntx = cdiv(W, TX), nty = cdiv(H, TY), ntz = cdiv(D, TZ);
     const long ntiles = (long)B * ntx * nty * ntz;
     if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
+    if (ntx > 255 || nty > 255 || ntz > 255 || B > 255) return UNETR_ERR_UNSUPPORTED;     // TileTable packs the coordinates in bytes
     // 16-channel slabs everywhere (measured: 32->16 @ 96^3 200 -> 170 us, 64->32 @ 48^3 133 -> 88 us, step -0.16 ms): the dy tile is
     // re-staged once per slab, but three pipelined workgroups per CU beat two with the 32-channel window.  UNETR_WG_CIS1 = largest
     // Cin that still takes the 16-channel variant (tuning hook).
