@@ -655,6 +655,21 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
             }
         }
 
+        // FUSE 4: the second input's fragments (x3 rows of this tile, 1x1x1 weights) of k-block kb, straight from global memory
+        u32x4 w3f0[FUSE == 4 ? NTB : 1], av0[FUSE == 4 ? 4 : 1];
+        auto x3_load = [&](int kb, int z0_, int y0_, int x0_, int b_, u32x4 (&wf)[FUSE == 4 ? NTB : 1], u32x4 (&av)[FUSE == 4 ? 4 : 1]) {
+            if constexpr (FUSE == 4) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) wf[j] = *(const u32x4*)(wp3 + ((long)kb * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
+                const int c3 = kb * 4 * CH + g * CH, zo_ = z0_ + wv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int yo = y0_ + i, xo = x0_ + r;
+                    const bool ok = zo_ < D && yo < H && xo < W && c3 + CH <= K3;
+                    av[i] = act_chunk<P>((const YT*)y3 + (ok ? ((((long)b_ * D + zo_) * H + yo) * W + xo) * ldy3 + c3 : 0), ok);
+                }
+            }
+        };
         for (int slab = 0; slab < nslab; ++slab) {
             __syncthreads();                       // everyone is done reading the previous window
             if constexpr (XM == 2) halo_store_planned<P, NCH>(R, plan, halo);    // (waits for the prefetched loads)
@@ -680,6 +695,9 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                     }
                     wload(ab, az * TZ, ay * TY, ax * TX, nslb * SL);
                 }
+                // (requested behind the window prefetch: in flight during the MFMA phase, consumed in the tile epilogue -- loaded
+                // there, every tile waited a global round trip for them)
+                if constexpr (FUSE == 4) { if (slab == 0) x3_load(0, z0, y0, x0, b, w3f0, av0); }
             }
             if constexpr (PAIR) {
                 // 56 (tap pair, row) steps; the window fragments of the next DPT steps are in flight while a step's MFMAs run
@@ -820,21 +838,18 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                 yrow[i] = okv[i] ? y + (tb + (long)i * W) * ldy + ylane : y + (nt0 * 16 + 4 * g);
             }
             if constexpr (FUSE == 4) {
-                // acc += x3[voxel, :] . w3: A rows = the 16 x-positions of output row i (lane r), chunk g of each 64-byte k-block
-                const YT* x3 = y3;
+                // acc += x3[voxel, :] . w3: A rows = the 16 x-positions of output row i (lane r), chunk g of each 64-byte k-block.
+                // The first k-block's operands were requested before the tile's MFMA phase (x3_load), the rest (K3 > 32 bf16
+                // channels) are loaded here.
                 const int n3 = (K3 + 4 * CH - 1) / (4 * CH);
-                for (int kb = 0; kb < n3; ++kb) {
-                    u32x4 w3f[NTB];
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) w3f[j] = *(const u32x4*)(wp3 + ((long)kb * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
-                    const int c3 = kb * 4 * CH + g * CH;
-                    u32x4 av[4];
+                for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int yo = y0 + i, xo = x0 + r;
-                        const bool ok = zo < D && yo < H && xo < W && c3 + CH <= K3;
-                        av[i] = act_chunk<P>(x3 + (ok ? ((((long)b * D + zo) * H + yo) * W + xo) * ldy3 + c3 : 0), ok);
-                    }
+                    for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], w3f0[j], av0[i]);
+                }
+                for (int kb = 1; kb < n3; ++kb) {
+                    u32x4 w3f[NTB], av[4];
+                    x3_load(kb, z0, y0, x0, b, w3f, av);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll

@@ -173,16 +173,19 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
         if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
         const char* la = lds + (kt % NS) * STAGE;
         const char* lb = la + A_BYTES;
+        // all fragment reads of the stage (both 32-deep halves) are issued before its first MFMA, so the second half's LDS latency
+        // hides under the first half's MFMAs (read 4, wait, MFMA 4, read 4, wait, MFMA 4 exposed it twice per stage -- with
+        // one workgroup per CU nothing else runs on the SIMD meanwhile)
+        u32x4 a[2][WM], b[2][WN];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            u32x4 a[WM], b[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                a[i] = *(const u32x4*)(la + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+                a[kb][i] = *(const u32x4*)(la + lds_tile_off((wm * WM + i) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 if constexpr (!BKN) {
-                    b[j] = *(const u32x4*)(lb + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+                    b[kb][j] = *(const u32x4*)(lb + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
                 } else {
                     constexpr int CPR = BN / 8;
                     const int cc = lane & 15, g = lane >> 4, q = cc >> 2, p = cc & 3;
@@ -193,14 +196,19 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
                     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(lb + r0 * (BN * 2) + s0 * 16 + (p & 1) * 8));
                     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)(lb + r1 * (BN * 2) + s1 * 16 + (p & 1) * 8));
                     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    b[j] = __builtin_bit_cast(u32x4, v);
+                    b[kb][j] = __builtin_bit_cast(u32x4, v);
                 }
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], b[j], a[i]);    // transposed tile: a lane holds 4 consecutive n of one m
+                for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], b[kb][j], a[kb][i]);    // transposed tile: a lane holds 4 consecutive n of one m
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // The MFMAs above ran with swapped operands, so the accumulator tile is C^T: lane (c, g) holds C[m = tile row c]
