@@ -415,7 +415,6 @@ struct HaloPlan {
     static constexpr int ITERS = (NHALO * NCH + 255) / 256;
     int rel[ITERS];           // element offset from the window origin (voxel (z0-1, y0-1, x0-1), channel c0)
     int lo[ITERS];            // byte offset in the LDS window
-    unsigned pk[ITERS];       // hz | hy << 8 | hx << 16 | chunk << 24
     unsigned valid;           // okbits of a fully interior window
 };
 template <class P, int NCH, int LAY>
@@ -430,7 +429,6 @@ __device__ __forceinline__ void halo_plan(HaloPlan<NCH>& pl, int H, int W, int l
         const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
         pl.rel[j] = ((hz * H + hy) * W + hx) * ld32 + ch * CH;
         pl.lo[j] = lay_off<LAY>(hv, ch, pitch);
-        pl.pk[j] = (unsigned)hz | ((unsigned)hy << 8) | ((unsigned)hx << 16) | ((unsigned)ch << 24);
         pl.valid |= v ? (((1u << NQ) - 1u) << (j * NQ)) : 0u;
     }
 }
@@ -451,11 +449,13 @@ __device__ __forceinline__ void halo_load_planned(HaloRegs<P, NCH>& R, const Hal
         unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < HaloPlan<NCH>::ITERS; ++j) {
-            const unsigned k = pl.pk[j];
-            const int gz = z0 - 1 + (int)(k & 255u), gy = y0 - 1 + (int)((k >> 8) & 255u), gx = x0 - 1 + (int)((k >> 16) & 255u);
-            const int c = c0 + (int)(k >> 24) * CH;
-            const bool ok = (int)threadIdx.x + j * 256 < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
-                            (unsigned)gx < (unsigned)W && c < Cin;
+            // (border tiles only: the piece's window coordinates are re-derived -- divisions by compile-time constants)
+            const int id = threadIdx.x + j * 256;
+            const int hv = id / NCH, ch = id - hv * NCH;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const int c = c0 + ch * CH;
+            const bool ok = id < TOTAL && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin;
             R.v[j][0] = __builtin_bit_cast(f32x4, *(const u32x4*)(xh + (ok ? base + pl.rel[j] : 0)));
             bits |= ok ? (((1u << NQ) - 1u) << (j * NQ)) : 0u;
         }
@@ -958,8 +958,13 @@ template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
 
 // XMX: storage of x (see stage_halo); dy / dy3 are feature-map gradients: ActOf<P> (bf16 in bf16 mode -- VECY is then moot:
 // a 16-channel dy row is two 16-byte pieces)
+// resident weight-gradient workgroups per CU for the 16-channel slab: with the software-pipelined unit loop and the staging plans two
+// workgroups of <= 181 registers beat three with spills (5.17 vs 5.26 ms per step); the host sizes the grid to match
+#ifndef WG_LB
+#define WG_LB 2
+#endif
 template <class P, int XMX, bool VECY, bool HAS3, int CIS, bool PIPE_OK>
-__global__ void __launch_bounds__(256, CIS == 1 ? ((HAS3 && !WgCfg<P, HAS3, CIS>::FLIP) ? 2 : 3) : 1)   // CIS = 1: 29-43 KB of LDS -> three workgroups per CU (two for the fp32 variant with the second dy image: 168 registers would spill)
+__global__ void __launch_bounds__(256, CIS == 1 ? ((HAS3 && !WgCfg<P, HAS3, CIS>::FLIP) ? 2 : WG_LB) : 1)   // CIS = 1: WG_LB workgroups per CU
 conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>::type* __restrict__ dy, long lddy, float* __restrict__ part,
                    const typename ActOf<P>::type* __restrict__ dy3, long lddy3, float* __restrict__ part3,
                    int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
@@ -1070,11 +1075,50 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     TileTable tt;
     int kt = 0, tx = 0, ty = 0, tz = 0, b = 0;
     if ((int)blockIdx.x < ntiles) tt.get(0, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+    // tile-invariant staging plans (see HaloPlan): window pieces of x, and the two 16-byte pieces of the dy tile per thread
+    constexpr bool PLAN = PIPE && XMX == 2;
+    HaloPlan<PLAN ? 16 / CH : 1> xplan;
+    int dyrel[YIT], dyrel3[HAS3 ? YIT : 1], dylo[YIT];
+    if constexpr (PLAN) {
+        halo_plan<P, 16 / CH, C::LAY>(xplan, H, W, (int)ldx, C::PX);
+#pragma unroll
+        for (int j = 0; j < YIT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = id / YCH, ch = id - v * YCH;
+            const int vz = v >> 6, vy = (v >> 4) & 3, vx = v & 15;
+            dyrel[j] = ((vz * H + vy) * W + vx) * (int)lddy + co0 + ch * CH;
+            if constexpr (HAS3) dyrel3[j] = ((vz * H + vy) * W + vx) * (int)lddy3 + co0 + ch * CH;
+            dylo[j] = (C::FLIP ? lay_flip(v) : v) * C::PY + ch * 16;
+        }
+    }
+    const long xitem = (long)D * H * W * ldx;
+    // window + dy tile(s) of tile (b_, z_, y_, x_) into the prefetch registers
+    auto tile_load = [&](int b_, int z_, int y_, int x_) {
+        if constexpr (PLAN) {
+            halo_load_planned<P, 16 / CH>(R, xplan, (const uint16_t*)x + b_ * xitem, (int)ldx, z_, y_, x_, D, H, W, ci0, Cin);
+            const bool interior = z_ + TZ <= D && y_ + TY <= H && x_ + TX <= W && co0 + 16 <= Cout;      // wave-uniform
+            const long vb = (((long)b_ * D + z_) * H + y_) * W + x_;
+            const GT* __restrict__ pdy = dy + vb * lddy;
+            const GT* __restrict__ pdy3 = HAS3 ? dy3 + vb * lddy3 : nullptr;
+#pragma unroll
+            for (int j = 0; j < YIT; ++j) {
+                bool ok = true;
+                if (!interior) {
+                    const int id = threadIdx.x + j * 256, v = id / YCH, ch = id - v * YCH;
+                    ok = z_ + (v >> 6) < D && y_ + ((v >> 4) & 3) < H && x_ + (v & 15) < W && co0 + ch * CH < Cout;
+                }
+                ybuf[j][0] = __builtin_bit_cast(f32x4, act_chunk<P>(pdy + (ok ? dyrel[j] : 0), ok));
+                if constexpr (HAS3) y3buf[j][0] = __builtin_bit_cast(f32x4, act_chunk<P>(pdy3 + (ok ? dyrel3[j] : 0), ok));
+            }
+        } else if constexpr (PIPE) {
+            halo_load<P, 16 / CH, XMX>(R, x, ldx, b_, z_, y_, x_, D, H, W, ci0, Cin);
+            load_dy(dy, lddy, b_, z_, y_, x_, ybuf);
+            if constexpr (HAS3) load_dy(dy3, lddy3, b_, z_, y_, x_, y3buf);
+        }
+    };
     if constexpr (PIPE) {
         if ((int)blockIdx.x < ntiles) {
-            halo_load<P, 16 / CH, XMX>(R, x, ldx, b, tz * TZ, ty * TY, tx * TX, D, H, W, ci0, Cin);
-            load_dy(dy, lddy, b, tz * TZ, ty * TY, tx * TX, ybuf);
-            if constexpr (HAS3) load_dy(dy3, lddy3, b, tz * TZ, ty * TY, tx * TX, y3buf);
+            tile_load(b, tz * TZ, ty * TY, tx * TX);
         }
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++kt) {
@@ -1083,16 +1127,21 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         __syncthreads();
         if constexpr (PIPE) {
-            halo_store<P, 16 / CH, XMX, C::LAY>(R, C::PX, ximg);
-            store_dy(ybuf, yimg);
-            if constexpr (HAS3) store_dy(y3buf, y3img);
+            if constexpr (PLAN) {
+                halo_store_planned<P, 16 / CH>(R, xplan, ximg);
+#pragma unroll
+                for (int j = 0; j < YIT; ++j) {
+                    *(u32x4*)(yimg + dylo[j]) = __builtin_bit_cast(u32x4, ybuf[j][0]);
+                    if constexpr (HAS3) *(u32x4*)(y3img + dylo[j]) = __builtin_bit_cast(u32x4, y3buf[j][0]);
+                }
+            } else {
+                halo_store<P, 16 / CH, XMX, C::LAY>(R, C::PX, ximg);
+                store_dy(ybuf, yimg);
+                if constexpr (HAS3) store_dy(y3buf, y3img);
+            }
             __syncthreads();
             const int nt = tile + gridDim.x;
-            if (nt < ntiles) {
-                halo_load<P, 16 / CH, XMX>(R, x, ldx, ab, az * TZ, ay * TY, ax * TX, D, H, W, ci0, Cin);
-                load_dy(dy, lddy, ab, az * TZ, ay * TY, ax * TX, ybuf);
-                if constexpr (HAS3) load_dy(dy3, lddy3, ab, az * TZ, ay * TY, ax * TX, y3buf);
-            }
+            if (nt < ntiles) tile_load(ab, az * TZ, ay * TY, ax * TX);
         } else {
             stage_halo<P, 16 * CIS / CH, XMX, C::LAY>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
             load_dy(dy, lddy, b, z0, y0, x0, ybuf);
@@ -1109,7 +1158,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
             // reads: lgkmcnt(0) 56 times per tile).  A wave's unit beyond the last one (wave 3 without the 1x1x1 units) reads the
             // centre tap and accumulates into a register that is never written out.
             typedef short s16x8 __attribute__((ext_vector_type(8)));
-            constexpr int NST = C::NKB * WG_UPW, DPT = HAS3 ? 4 : 5;      // (fp32-stored x, the image: the guarded loop below -- its prefetch registers leave no room)
+            constexpr int NST = C::NKB * WG_UPW, DPT = HAS3 ? 3 : 5;      // (fp32-stored x, the image: the guarded loop below -- its prefetch registers leave no room)
             auto aread = [&](int kb, const char* img, u32x4& af) {
                 const int ykb = kb * 32 * C::PY;
                 s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + ykb + ylane0));
@@ -1470,6 +1519,7 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     const long ntiles = (long)B * ntx * nty * ntz;
     if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
     if (ntx > 255 || nty > 255 || ntz > 255 || B > 255) return UNETR_ERR_UNSUPPORTED;     // TileTable packs the coordinates in bytes
+    if ((long)D * H * W * lddy >= (1L << 31) || (dy3 && (long)D * H * W * lddy3 >= (1L << 31))) return UNETR_ERR_UNSUPPORTED;   // 32-bit in-tile offsets
     // 16-channel slabs everywhere (measured: 32->16 @ 96^3 200 -> 170 us, 64->32 @ 48^3 133 -> 88 us, step -0.16 ms): the dy tile is
     // re-staged once per slab, but three pipelined workgroups per CU beat two with the 32-channel window.  UNETR_WG_CIS1 = largest
     // Cin that still takes the 16-channel variant (tuning hook).
@@ -1477,7 +1527,7 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
     // persistent workgroups: all of them resident at once (3 per CU with the 16-channel slab, else 2 rounds of 2 per CU)
-    long G = std::max<long>(1, (cis == 1 ? ((dy3 && !B16) ? 512 : 768) : 1024) / ((long)nci * nco));
+    long G = std::max<long>(1, (cis == 1 ? ((dy3 && !B16) ? 512 : 256 * WG_LB) : 1024) / ((long)nci * nco));
     G = std::min(G, ntiles);
     const long n3 = dy3 ? (long)Cin * Cout : 0;
     while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;
