@@ -63,51 +63,50 @@ tconv2_wgrad_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, cons
 #pragma unroll
         for (int j = 0; j < CTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // the x tile and the gathered dy tile of the NEXT voxel tile travel in registers while this tile's MFMAs run (loaded at the
+    // top of every tile behind two barriers and an LDS table of output bases, each tile paid two global round trips)
+    constexpr int QX = RT * 16 / CH, ITX = (TV * QX + 255) / 256;     // x: pieces of CH elements per voxel
+    constexpr int QY = NC / CH, ITY = TV * QY / 256;                  // dy: pieces per voxel row of NC columns
+    u32x4 xr[ITX], yr[ITY];
+    auto tload = [&](int tile) {
         const int m0 = tile * TV;
+#pragma unroll
+        for (int j = 0; j < ITX; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = id / QX, q = id - v * QX;
+            const bool ok = id < TV * QX && m0 + v < M;
+            xr[j] = act_chunk<P>(x + (long)(ok ? m0 + v : 0) * ldx + (ok ? q * CH : 0), ok);
+        }
+#pragma unroll
+        for (int j = 0; j < ITY; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = id / QY, q = id - v * QY;
+            const int col = col0 + q * CH, tap = col / Cout, co = col - tap * Cout;
+            const int m = m0 + v;
+            const bool ok = m < M && tap < 8;
+            const int ov = (ok ? out_base(m, D, H, W) : 0) + ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
+            yr[j] = act_chunk<P>(dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0), ok);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) tload(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                                  // previous tile's fragments are read
-        if (threadIdx.x < TV) {
-            const int m = m0 + threadIdx.x;
-            tab[threadIdx.x] = m < M ? out_base(m, D, H, W) : -1;
-        }
-        // x tile: TV voxels x Cin channels, 16-byte pieces
-        {
-            constexpr int QX = RT * 16 / CH;              // pieces of CH elements per voxel
-            constexpr int IT = (TV * QX + 255) / 256;
 #pragma unroll
-            for (int j = 0; j < IT; ++j) {
-                const int id = threadIdx.x + j * 256;
-                if (id < TV * QX) {
-                    const int v = id / QX, q = id - v * QX;
-                    const bool ok = m0 + v < M;
-                    *(u32x4*)(ximg + v * PXI + q * 16) = act_chunk<P>(x + (long)(ok ? m0 + v : 0) * ldx + q * CH, ok);
-                }
+        for (int j = 0; j < ITX; ++j) {
+            const int id = threadIdx.x + j * 256;
+            if (id < TV * QX) {
+                const int v = id / QX, q = id - v * QX;
+                *(u32x4*)(ximg + v * PXI + q * 16) = xr[j];
             }
         }
-        __syncthreads();                                  // table visible
-        // gathered dy tile: TV voxels x NC columns (column = tap*Cout + co), 16-byte pieces of CH elements
-        {
-            constexpr int QY = NC / CH;
-            constexpr int IT = TV * QY / 256;
-            u32x4 buf[IT];
 #pragma unroll
-            for (int j = 0; j < IT; ++j) {
-                const int id = threadIdx.x + j * 256;
-                const int v = id / QY, q = id - v * QY;
-                const int col = col0 + q * CH, tap = col / Cout, co = col - tap * Cout;
-                const int ob = tab[v];
-                const bool ok = ob >= 0 && tap < 8;
-                const int ov = ob + ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
-                buf[j] = act_chunk<P>(dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0), ok);
-            }
-#pragma unroll
-            for (int j = 0; j < IT; ++j) {
-                const int id = threadIdx.x + j * 256;
-                const int v = id / QY, q = id - v * QY;
-                *(u32x4*)(yimg + v * PYI + q * 16) = buf[j];
-            }
+        for (int j = 0; j < ITY; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = id / QY, q = id - v * QY;
+            *(u32x4*)(yimg + v * PYI + q * 16) = yr[j];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) tload(tile + gridDim.x);
         // result tile (row tile i = ci block, column tile wv*CTW + j): A = x^T fragments, B = dy fragments, k = voxel
         if constexpr (CH == 8) {
             const int q = c >> 2, p = c & 3;
@@ -327,36 +326,37 @@ tconv2_dgrad_kernel(const typename Elem<P>::type* __restrict__ dy, long lddy, co
         const int row = id / (RB / 16), q = id - row * (RB / 16);
         *(u32x4*)(wimg + row * PA + q * 16) = row < Cin ? *(const u32x4*)(wd + (long)row * RB + q * 16) : (u32x4){0u, 0u, 0u, 0u};
     }
+    // the gathered dy tile of the NEXT voxel tile travels in registers while this tile's MFMAs and stores run (Cout <= 32: at
+    // most 8 pieces of 16 bytes per thread with bf16 storage, 16 with fp32)
+    constexpr int MAXIT = CH == 8 ? 8 : 16;
+    u32x4 yr[MAXIT];
+    auto tload = [&](int tile) {
+        const int m0 = tile * TV;
+#pragma unroll
+        for (int j = 0; j < MAXIT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int v = min(id / QY, TV - 1), q = id - (id / QY) * QY;
+            const int col = q * CH, tap = col / Cout, co = col - tap * Cout;
+            const int m = m0 + v;
+            const bool ok = id < TV * QY && m < M;
+            const int ov = (ok ? out_base(m, D, H, W) : 0) + ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
+            yr[j] = act_chunk<P>(dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0), ok);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) tload(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * TV;
         __syncthreads();
-        if (threadIdx.x < TV) {
-            const int m = m0 + threadIdx.x;
-            tab[threadIdx.x] = m < M ? out_base(m, D, H, W) : -1;
-        }
-        __syncthreads();
-        for (int id0 = 0; id0 < TV * QY; id0 += 1024) {          // 4 pieces per thread in flight
-            u32x4 buf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = id0 + threadIdx.x + j * 256;
-                const int v = min(id / QY, TV - 1), q = id - (id / QY) * QY;
-                const int col = q * CH, tap = col / Cout, co = col - tap * Cout;
-                const int ob = tab[v];
-                const bool ok = id < TV * QY && ob >= 0;
-                const int ov = ob + ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
-                buf[j] = act_chunk<P>(dy + (long)(ok ? ov : 0) * lddy + (ok ? co : 0), ok);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = id0 + threadIdx.x + j * 256;
-                if (id < TV * QY) {
-                    const int v = id / QY, q = id - v * QY;
-                    *(u32x4*)(yimg + v * PA + q * 16) = buf[j];
-                }
+        for (int j = 0; j < MAXIT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            if (id < TV * QY) {
+                const int v = id / QY, q = id - v * QY;
+                *(u32x4*)(yimg + v * PA + q * 16) = yr[j];
             }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) tload(tile + gridDim.x);
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
