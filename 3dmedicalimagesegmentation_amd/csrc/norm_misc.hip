@@ -800,9 +800,10 @@ adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale,
         return ((const float*)gsrc)[i] * gscale;
     };
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i], gv;
-        if (GB16) gv = __builtin_convertvector(((const bf16x4*)gsrc)[i], f32x4) * gscale;
-        else gv = ((const f32x4*)gsrc)[i] * gscale;
+        // streamed once per step: non-temporal accesses keep the 2.8 GB of optimizer traffic from evicting what the next forward reads
+        f32x4 pv = __builtin_nontemporal_load((f32x4*)p + i), mv = __builtin_nontemporal_load((f32x4*)m + i), vv = __builtin_nontemporal_load((f32x4*)v + i), gv;
+        if (GB16) gv = __builtin_convertvector(__builtin_nontemporal_load((const bf16x4*)gsrc + i), f32x4) * gscale;
+        else gv = __builtin_nontemporal_load((const f32x4*)gsrc + i) * gscale;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float pe = pv[e] * (1.f - lr * wd);
@@ -812,7 +813,7 @@ adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale,
             pv[e] = pe - step_size * (me / denom);
             mv[e] = me; vv[e] = ve;
         }
-        ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+        __builtin_nontemporal_store(pv, (f32x4*)p + i); __builtin_nontemporal_store(mv, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i);
         if (shadow) ((bf16x4*)shadow)[i] = __builtin_convertvector(pv, bf16x4);
     }
     // tail (n not a multiple of 4)
