@@ -551,7 +551,12 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                       float* __restrict__ part3, int K3) {
     typedef typename ActOf<P>::type YT;
     constexpr int CH = P::CH, SL = PAIR ? 16 : 4 * CH, NCH = PAIR ? 2 : 4, PITCH = NCH * 16, LAY = PAIR ? 0 : 1;
-    __shared__ __attribute__((aligned(16))) char halo[NHALO * PITCH];
+    // DMAW (pair layout on bf16-stored input: the 96^3 layers): the window goes global -> LDS by LDS-DMA into one of two images
+    // (piece id = its 16-byte slot: the pair layout is linear in id), no registers, no ds_write, ONE barrier per tile; pieces
+    // outside the volume are fetched from 16 zero bytes of the packed weights (tap 27 of pair 13)
+    constexpr bool DMAW = PAIR && XM == 2;
+    constexpr int WSTRIDE = HaloPlan<NCH>::ITERS * 256 * 16;      // bytes per window image incl. the slots of the idle lanes
+    __shared__ __attribute__((aligned(16))) char halo[DMAW ? 2 * WSTRIDE : NHALO * PITCH];
     constexpr int WLN = PAIR ? 0 : WL, WBYTES = 27 * NTB * 1024;
     __shared__ __attribute__((aligned(16))) char wlds[WLN ? WLN * WBYTES : 16];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
@@ -625,16 +630,53 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         if constexpr (XM == 2) halo_load_planned<P, NCH>(R, plan, (const uint16_t*)x + b_ * item, (int)ldx, z_, y_, x_, D, H, W, c_, Cin);
         else halo_load<P, NCH, XM>(R, x, ldx, b_, z_, y_, x_, D, H, W, c_, Cin);
     };
+    // DMAW: window of tile (b_, z_, y_, x_) -> image `win`
+    auto window_dma = [&](int win, int b_, int z_, int y_, int x_) {
+        if constexpr (DMAW) {
+            constexpr int TOTAL = NHALO * NCH;
+            const uint16_t* __restrict__ xh = (const uint16_t*)x + b_ * item;
+            const char* zsrc = wp + ((long)13 * Cout) * 64 + 32;             // 16 zero bytes
+            const int ld32 = (int)ldx;
+            const int base = (((z_ - 1) * H + (y_ - 1)) * W + (x_ - 1)) * ld32;
+            const bool interior = z_ >= 1 && z_ - 1 + HZ <= D && y_ >= 1 && y_ - 1 + HY <= H && x_ >= 1 && x_ - 1 + HX <= W && NCH * CH <= Cin;
+            char* img = halo + win * WSTRIDE + wv * 1024;
+#pragma unroll
+            for (int j = 0; j < HaloPlan<NCH>::ITERS; ++j) {
+                const int id = threadIdx.x + j * 256;
+                bool ok = (j + 1) * 256 <= TOTAL || id < TOTAL;
+                if (!interior) {
+                    const int hv = id / NCH, ch = id - hv * NCH;
+                    const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                    ok = ok && (unsigned)(z_ - 1 + hz) < (unsigned)D && (unsigned)(y_ - 1 + hy) < (unsigned)H &&
+                         (unsigned)(x_ - 1 + hx) < (unsigned)W && ch * CH < Cin;
+                }
+                const char* src = ok ? (const char*)(xh + (base + plan.rel[j])) : zsrc;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(img + j * 4096), 16, 0, 0);
+            }
+        }
+    };
     int tile = blockIdx.x;
     TileTable tt;
     int kt = 0;                       // index of the current tile in this workgroup's walk
     int tx = 0, ty = 0, tz = 0, b = 0;
+    int n1x = 0, n1y = 0, n1z = 0, n1b = 0;      // DMAW: coordinates of the tile after the current one
     if (tile < ntiles) {
         tt.get(0, ntiles, ntx, nty, ntz, tx, ty, tz, b);
-        wload(b, tz * TZ, ty * TY, tx * TX, 0);
+        if constexpr (DMAW) {
+            window_dma(0, b, tz * TZ, ty * TY, tx * TX);
+            if (tile + (int)gridDim.x < ntiles) {
+                tt.get(1, ntiles, ntx, nty, ntz, n1x, n1y, n1z, n1b);
+                window_dma(1, n1b, n1z * TZ, n1y * TY, n1x * TX);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            __syncthreads();
+        } else {
+            wload(b, tz * TZ, ty * TY, tx * TX, 0);
+        }
     }
     for (; tile < ntiles; tile += gridDim.x, ++kt) {
         int ntx_ = tx, nty_ = ty, ntz_ = tz, nb_ = b;      // coordinates of the next tile (set when its prefetch is issued)
+        if constexpr (DMAW) { ntx_ = n1x; nty_ = n1y; ntz_ = n1z; nb_ = n1b; }
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         f32x4 acc[4][NTB];
         f32x4 acc3[has3 ? 4 : 1][has3 ? NTB : 1];
@@ -671,6 +713,9 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
             }
         };
         for (int slab = 0; slab < nslab; ++slab) {
+          if constexpr (DMAW) {
+            if constexpr (FUSE == 4) x3_load(0, z0, y0, x0, b, w3f0, av0);
+          } else {
             __syncthreads();                       // everyone is done reading the previous window
             if constexpr (XM == 2) halo_store_planned<P, NCH>(R, plan, halo);    // (waits for the prefetched loads)
             else halo_store<P, NCH, XM, LAY>(R, PITCH, halo);
@@ -699,11 +744,12 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                 // there, every tile waited a global round trip for them)
                 if constexpr (FUSE == 4) { if (slab == 0) x3_load(0, z0, y0, x0, b, w3f0, av0); }
             }
+          }
             if constexpr (PAIR) {
                 // 56 (tap pair, row) steps; the window fragments of the next DPT steps are in flight while a step's MFMAs run
                 // (written as load, MFMA, load, MFMA the compiler kept exactly that order with ONE fragment register and a
                 // full lgkmcnt(0) wait per MFMA: ~130 cycles of LDS latency exposed 56 times per tile = 80 % of the tile time)
-                const char* hb0 = halo + ((wv * HY) * HX + r) * PITCH + (g & 1) * 16;
+                const char* hb0 = halo + (DMAW ? (kt & 1) * WSTRIDE : 0) + ((wv * HY) * HX + r) * PITCH + (g & 1) * 16;
                 const bool upper = (g >> 1) != 0;
                 constexpr int NSTEP = 14 * 4, DPT = 12;
                 auto frag = [&](int s) {
@@ -821,6 +867,17 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 #pragma unroll
                         for (int j = 0; j < NTB; ++j) bcur[t][j] = bnxt[t][j];
                 }
+            }
+        }
+        if constexpr (DMAW) {
+            // the image of the next tile has landed (requested a whole tile ago) and so have the previous tile's output stores; after
+            // the barrier every wave is done with this tile's image, which the tile after next now streams into.  The output
+            // stores of this tile follow, so the wait above never waits for a store it has just issued.
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            __syncthreads();
+            if (tile + 2 * (int)gridDim.x < ntiles) {
+                tt.get(kt + 2, ntiles, ntx, nty, ntz, n1x, n1y, n1z, n1b);
+                window_dma(kt & 1, n1b, n1z * TZ, n1y * TY, n1x * TX);
             }
         }
         const int zo = z0 + wv;
