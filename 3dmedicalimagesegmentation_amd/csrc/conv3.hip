@@ -1498,6 +1498,10 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
         long cap = two ? 512 : 256;   // resident workgroups (VGPR / LDS-limited); more would queue behind them
         if (const char* e = getenv("UNETR_CONV_CAP")) { if (pair && atoi(e) > 0) cap = atoi(e); }      // tuning hook (pair layout)
         if (const char* e = getenv("UNETR_CONV_CAP_SLAB")) { if (!pair && two && atoi(e) > 0) cap = atoi(e); }
+        if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) cap = std::min<long>(cap, atoi(e)); }   // test hook: long tile walks
+        // a workgroup that walks several tiles must see them in non-decreasing batch order (the fused statistics are flushed when
+        // the batch item changes): tile_coords guarantees that for grids that are multiples of the 8 XCDs
+        if (cap < spatial) cap = std::max<long>(8, cap / 8 * 8);
         dim3 pgrid((unsigned)std::min<long>(spatial, cap), ntn / ntb);
 #define LAUNCH_PIPE_F(NTB_, PAIR_, XM_, FUSE_, WL_)                                                                               \
     hipLaunchKernelGGL((conv3_fwd_pipe_kernel<P, NTB_, PAIR_, XM_, FUSE_, WL_>), pgrid, dim3(256), 0, st, x, ldx, (const char*)wp, y, ldy, \
@@ -1586,6 +1590,7 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     // persistent workgroups: all of them resident at once (3 per CU with the 16-channel slab, else 2 rounds of 2 per CU)
     long G = std::max<long>(1, (cis == 1 ? ((dy3 && !B16) ? 512 : 256 * WG_LB) : 1024) / ((long)nci * nco));
     G = std::min(G, ntiles);
+    if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) G = std::min<long>(G, atoi(e)); }   // test hook: long tile walks
     const long n3 = dy3 ? (long)Cin * Cout : 0;
     while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;
     if (!ws || (size_t)G * (n + n3) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;

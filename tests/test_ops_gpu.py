@@ -645,3 +645,29 @@ def test_skip_written_into_concat_buffer(pkg, dev, prec, producer):
     # a tensor that is not the second half of such a buffer is refused rather than overwritten
     with pytest.raises(RuntimeError):
         Fn.UpBlockFn.apply(inp, torch.zeros(B, 2 * S, 2 * S, 2 * S, C, device=dev, dtype=adt), wt, w1, w2, w3, prec, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,dims3", [(16, 16, (36, 32, 64)), (32, 16, (36, 32, 64)), (64, 32, (36, 32, 64))])
+def test_conv3_long_tile_walks(pkg, dev, monkeypatch, cin, cout, dims3):
+    """A persistent workgroup that walks MORE than 64 tiles (the per-workgroup tile table is refilled every 64; the bench
+    shapes stay below that): the grid is capped at 8 workgroups through the test hook, so each walks 72 tiles.
+    Forward (pair layout with the LDS-DMA window / slab layout with one and two weight images), data gradient, weight
+    gradient, in bf16 mode against torch on the bf16-rounded operands."""
+    Fn = pkg.functional
+    monkeypatch.setenv("UNETR_TEST_MAX_WG", "8")
+    B, prec = 2, 1
+    D, H, W = dims3
+    x, w, dy = rq(g(B, cin, D, H, W, seed=1), prec), g(cout, cin, 3, 3, 3, seed=2, scale=0.2), rq(g(B, cout, D, H, W, seed=3), prec)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, padding=1)
+    yr.backward(dy)
+    dims = (B, D, H, W)
+    xd, wd, dyd = act(cl(x), prec, dev), w.to(dev), act(cl(dy), prec, dev)
+    assert relerr(ncdhw(Fn.conv3(xd, cin, wd, dims, prec).cpu()), yr) < TOL[prec]
+    assert relerr(ncdhw(Fn.conv3(dyd, cout, wd, dims, prec, mode=1).cpu()), xr.grad) < TOL[prec]
+    assert relerr(Fn.conv3_wgrad(xd, cin, dyd, cout, dims, cin, cout, prec), wr.grad) < TOL[prec]
+    f1 = Fn.conv3_fused(xd, cin, wd, None, dims, prec)          # + InstanceNorm sums flushed across the batch boundary of a long walk
+    if f1 is not None:
+        st = Fn.instnorm_stats(f1[0], cout, B, D * H * W, cout)
+        assert relerr(f1[1].cpu(), st.cpu()) < 1e-3
