@@ -76,6 +76,65 @@ __device__ __forceinline__ void prod_T(f32x4 (&out)[4], f32x4 x0, f32x4 x1, cons
     }
 }
 
+// The same two products over a FULL chunk (all CT tiles) as one software-pipelined straight line: the image fragments of the
+// next DPT tiles are in flight while a tile's MFMAs run, order pinned with sched_barrier.  (As a guarded per-tile loop every
+// tile waited for its own two reads: 14 exposed LDS round trips per product -- for 216 tokens the chunk is always full.)
+template <class F>
+__device__ __forceinline__ void prod_rows_full(const char* img, const u32x4 (&vec)[2], F&& each) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    constexpr int DPT = 5;
+    const char* p0 = img + img_off(c, g);                 // (row tiles are 16 rows = 2 KB apart: the swizzle repeats every 8 rows)
+    const char* p1 = img + img_off(c, 4 + g);
+    u32x4 r0[DPT], r1[DPT];
+#pragma unroll
+    for (int t = 0; t < DPT; ++t) { r0[t] = *(const u32x4*)(p0 + t * 16 * ROWB); r1[t] = *(const u32x4*)(p1 + t * 16 * ROWB); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        PrecBF16::mma(acc, r0[t % DPT], vec[0]);
+        PrecBF16::mma(acc, r1[t % DPT], vec[1]);
+        if (t + DPT < CT) { r0[t % DPT] = *(const u32x4*)(p0 + (t + DPT) * 16 * ROWB); r1[t % DPT] = *(const u32x4*)(p1 + (t + DPT) * 16 * ROWB); }
+        each(t, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// out[dt] += Img^T . X over all CT/2 row pairs; x(t2, x0, x1) supplies the pair's two accumulator tiles
+template <class F>
+__device__ __forceinline__ void prod_T_full(f32x4 (&out)[4], const char* img, F&& x) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, q = c >> 2, p = c & 3;
+    constexpr int NS = (CT / 2) * 4, DPT = 6;             // (row pair, d tile) steps
+    const char* b0[2];                                    // per-lane address of d tiles 0 / 1 chunk parity (ch = dt*2 + (p>>1))
+    const int r0 = 4 * g + q;
+    auto addr = [&](int st, int hi) { const int t2 = st >> 2, dt = st & 3; return img + img_off(32 * t2 + r0 + 16 * hi, dt * 2 + (p >> 1)) + (p & 1) * 8; };
+    (void)b0;
+    s16x4 lo[DPT], hi[DPT];
+#pragma unroll
+    for (int st = 0; st < DPT; ++st) {
+        lo[st] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)addr(st, 0));
+        hi[st] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)addr(st, 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 b = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const int t2 = st >> 2, dt = st & 3;
+        if (dt == 0) {
+            f32x4 x0, x1;
+            x(t2, x0, x1);
+            float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            b = PrecBF16::pack(xv);
+        }
+        s16x8 t = {lo[st % DPT][0], lo[st % DPT][1], lo[st % DPT][2], lo[st % DPT][3], hi[st % DPT][0], hi[st % DPT][1], hi[st % DPT][2], hi[st % DPT][3]};
+        PrecBF16::mma(out[dt], __builtin_bit_cast(u32x4, t), b);
+        if (st + DPT < NS) {
+            lo[st % DPT] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)addr(st + DPT, 0));
+            hi[st % DPT] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS_ s16x4*)addr(st + DPT, 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // this lane's token row (64 bf16) as two MFMA fragments: chunk kb*4 + (lane>>4)
 __device__ __forceinline__ void load_vec(const uint16_t* __restrict__ row, u32x4 (&f)[2]) {
     const int g = (threadIdx.x & 63) >> 4;
@@ -117,6 +176,18 @@ attn16_fwd_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ out, uin
         __syncthreads();
         f32x4 s[CT];
         float tmax = NEG_BIG;
+        const bool full = nt == CT;                                // wave-uniform
+        if (full) {
+            prod_rows_full(kimg, qf, [&](int t, f32x4 acc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + 4 * g + r;
+                    acc[r] = key < nkeys ? acc[r] * scale : NEG_BIG;
+                    tmax = fmaxf(tmax, acc[r]);
+                }
+                s[t] = acc;
+            });
+        } else
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             if (t < nt) {
@@ -143,9 +214,13 @@ attn16_fwd_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ out, uin
         m = mn;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+        if (full) {
+            prod_T_full(o, vimg, [&](int t2, f32x4& x0, f32x4& x1) { x0 = s[2 * t2]; x1 = s[2 * t2 + 1]; });
+        } else {
 #pragma unroll
-        for (int t2 = 0; t2 < CT / 2; ++t2)
-            if (2 * t2 < nt) prod_T(o, s[2 * t2], s[2 * t2 + 1], vimg, 32 * t2);
+            for (int t2 = 0; t2 < CT / 2; ++t2)
+                if (2 * t2 < nt) prod_T(o, s[2 * t2], s[2 * t2 + 1], vimg, 32 * t2);
+        }
     }
     if (q < L) {
         const float inv = 1.f / l;
@@ -205,6 +280,22 @@ attn16_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restric
         stage_img<NT>(vb, rs, k0, L, rows, vimg);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (nt == CT) {                                                // full chunk (wave-uniform): pipelined straight lines
+            f32x4 dsf[CT];
+            prod_rows_full(kimg, qf, [&](int t, f32x4 acc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + 4 * g + r;
+                    acc[r] = key < nkeys ? __expf(acc[r] * scale - lq) : 0.f;
+                }
+                dsf[t] = acc;                                          // p
+            });
+            prod_rows_full(vimg, dof, [&](int t, f32x4 dp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsf[t][r] *= dp[r] - dq_;
+            });
+            prod_T_full(dq, kimg, [&](int t2, f32x4& x0, f32x4& x1) { x0 = dsf[2 * t2]; x1 = dsf[2 * t2 + 1]; });
+        } else
 #pragma unroll
         for (int t2 = 0; t2 < CT / 2; ++t2) {
             if (2 * t2 >= nt) break;
@@ -274,6 +365,22 @@ attn16_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (nt == CT) {                                                // full chunk (wave-uniform): pipelined straight lines
+            f32x4 pf[CT], dsf[CT];
+            prod_rows_full(qimg, kf, [&](int t, f32x4 acc) {
+                const f32x4 l4 = *(const f32x4*)(lse_t + t * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = __expf(acc[r] * scale - l4[r]);
+                pf[t] = acc;
+            });
+            prod_rows_full(doimg, vf, [&](int t, f32x4 dp) {
+                const f32x4 d4 = *(const f32x4*)(del_t + t * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsf[t][r] = pf[t][r] * (dp[r] - d4[r]);
+            });
+            prod_T_full(dv, doimg, [&](int t2, f32x4& x0, f32x4& x1) { x0 = pf[2 * t2]; x1 = pf[2 * t2 + 1]; });
+            prod_T_full(dk, qimg, [&](int t2, f32x4& x0, f32x4& x1) { x0 = dsf[2 * t2]; x1 = dsf[2 * t2 + 1]; });
+        } else
 #pragma unroll
         for (int t2 = 0; t2 < CT / 2; ++t2) {
             if (2 * t2 >= nt) break;
