@@ -2,6 +2,8 @@
 same state_dict, same seeded synthetic volume -> logits, enc4, Dice/CE terms and parameter gradients.
 north_star tolerance: 1e-3 relative fp32 on logits and Dice (fp32 mode).  bf16 mode is reported with its own
 looser bound (bf16 operands, fp32 accumulate, 12 residual blocks)."""
+import os
+
 import pytest
 import torch
 
@@ -575,6 +577,45 @@ def test_staged_backward_equals_single_pass(pkg, dev):
     assert torch.equal(res["single"][0], res["staged_graph"][0])
     assert res["single"][1] == res["staged_graph"][1]
     assert relerr(res["staged_bf16comm"][0], res["single"][0]) < 1e-2       # bf16-rounded gradients: close, not equal
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_rank_data_parallel_step(pkg, dev, tmp_path, mode):
+    """The data-parallel TrainStep with a REAL 2-rank all-reduce, on one GPU: two processes (gloo carries the CUDA gradient
+    pieces -- RCCL refuses two ranks on one device), each with its shard of a batch of 4, against one process stepping on the
+    whole batch.  Both ranks must end with bit-identical parameters, and the averaged-gradient update must be the update of
+    the batch-4 step (DiceCE is a mean over batch items, InstanceNorm is per item: equal up to summation order)."""
+    import socket
+    import subprocess
+    import sys
+    from oracle.unetr_oracle import synthetic_volume
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), str(tmp_path), mode], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert torch.equal(r0["param"], r1["param"])
+    # the same job in one process: batch 4, single-graph step (warm-up steps count as steps: compare equal step counts)
+    x, y = synthetic_volume(4, 1, 32, 2, seed=77)
+    torch.manual_seed(11)
+    m = pkg.UNETRLogits(**C1).to(dev)
+    m.precision = "bf16"
+    flat = m.use_flat_buffers()
+    p0 = flat["param"].clone()
+    opt = pkg.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, flat=flat)
+    step = pkg.TrainStep(m, pkg.DiceCELoss(to_onehot_y=True, softmax=True), opt, x.to(dev), y.to(dev), use_graph=False, warmup=1)
+    while step.eager_steps < r0["steps"] + (2 if mode == "graph" else 0):
+        step.run()
+    torch.cuda.synchronize()
+    upd_dp, upd_1 = r0["param"].to(dev) - p0, flat["param"] - p0
+    cos = torch.nn.functional.cosine_similarity(upd_dp.double(), upd_1.double(), dim=0)
+    assert cos > 0.98, float(cos)
+    assert relerr(r0["param"].to(dev), flat["param"]) < 5e-3
+    flat["state"].clear()
 
 
 def test_two_models_and_failed_backward(pkg, dev):
