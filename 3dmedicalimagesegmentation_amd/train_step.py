@@ -164,19 +164,23 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------------ graphs
     def _capture(self):
+        # thread-local capture mode: with a process group alive, its watchdog thread polls the events of the warm-up collectives
+        # (hipEventQuery) -- under the default global mode such a call from another thread during capture is an error and aborts
+        # the process (seen once in six 1-rank RCCL runs)
+        mode = "thread_local"
         if not self.dp:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 self._single_step()
             self.graphs = [g]
             return
         graphs = [torch.cuda.CUDAGraph()]
-        with torch.cuda.graph(graphs[0]):
+        with torch.cuda.graph(graphs[0], capture_error_mode=mode):
             self._pass0()
         pool = graphs[0].pool()
         for k in (1, 2, 3):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                 self._pass(k)
             graphs.append(g)
         self.graphs = graphs

@@ -209,7 +209,7 @@ def encoder_forward_rate(pkg, model, x_in, precision, iters=10):
     fwd()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         fwd()
     g.replay()
     torch.cuda.synchronize()
