@@ -143,5 +143,10 @@ __device__ __forceinline__ u32x4 act_chunk(const typename ActOf<P>::type* p, boo
     const u32x4 w = *(const u32x4*)p;
     return ok ? w : (u32x4){0u, 0u, 0u, 0u};
 }
+// LayerNorm backward whose dy arrives as split-K partial slabs (norm_misc.hip; used by unetr_gemm_bf16_ln_bwd in gemm_bf16.hip)
+int unetr_layernorm_bwd_partials(const float* dy, int splits, long slab, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
+                                 float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream);
+
 // run CALL with `AT` bound to the activation storage type selected by the run-time flag act16
 #define ACT_DISPATCH(act16, ...) do { if (act16) { typedef uint16_t AT; __VA_ARGS__; } else { typedef float AT; __VA_ARGS__; } } while (0)

@@ -237,7 +237,7 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
 
 template <int WM, int WN, int WVM, int WVN, bool BKN, int NS>
 int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep,
-                float* ws, size_t ws_bytes, hipStream_t st) {
+                float* ws, size_t ws_bytes, hipStream_t st, int* partial_splits = nullptr) {
     constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN;
     const int mt = cdiv(M, BM), nt = cdiv(N, BN), ksteps = K / 64;
     const long tiles = (long)mt * nt;
@@ -253,7 +253,9 @@ int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t
     const int per = cdiv(tiles, 8);
     hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WVM, WVN, BKN, NS>), dim3(per * 8, splits), dim3(64 * WVM * WVN), 0, st,
                        M, N, K, mt, nt, splits, kper, A, lda, B, ldb, ep, ws);
-    if (splits > 1)
+    // partial_splits: the caller consumes the split partials itself (unetr_gemm_bf16_ln_bwd): no reduce launch
+    if (partial_splits) *partial_splits = splits;
+    if (splits > 1 && !partial_splits)
         hipLaunchKernelGGL((splitk_reduce_kernel<EpBf, false>), dim3(cdiv(N, 64), cdiv(M, 4), 1), dim3(256), 0, st, M, N, splits, ws, ep);
     return unetr_check_launch();
 }
@@ -377,8 +379,8 @@ __global__ void __launch_bounds__(256) cast_bf16_tail_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
-                               float* ws, size_t ws_bytes, void* stream) {
+static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
+                          float* ws, size_t ws_bytes, void* stream, int* psp) {
     if (!d || !A || !B || (!C && !Cb)) return UNETR_ERR_ARG;
     const int M = d->M, N = d->N, K = d->K;
     if (M <= 0 || N <= 0 || K <= 0) return UNETR_ERR_ARG;
@@ -399,7 +401,7 @@ extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, con
     const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hooks
     const int env_ns = getenv("UNETR_GEMM_STAGES") ? atoi(getenv("UNETR_GEMM_STAGES")) : 0;
     const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
-#define BF16_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st)
+#define BF16_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st, psp)
     // Small token counts (batch 2: M = 432).  Measured per launch on MI355X (tools/probe_encoder.py, us incl. launch boundary):
     //   forward, K = 768:   N = 768: 64x32 5.6 < 32x64 5.7 < 64x64 7.1;  N = 2304: 64x64 6.6 < 64x96 7.5 < 64x128 9.1;
     //                       N = 3072: 64x64 10.5 < 64x96 11.2 < 64x128 13.7
@@ -433,6 +435,27 @@ extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, con
     if (env_ns == 8) BF16_GO(2, 2, true, 8);
     BF16_GO(2, 2, true, 4);
 #undef BF16_GO
+}
+
+extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
+                               float* ws, size_t ws_bytes, void* stream) {
+    return gemm_bf16_impl(d, A, B, C, Cb, ws, ws_bytes, stream, nullptr);
+}
+
+// dx = LayerNorm backward of dy = A . B (a plain product: alpha 1, no bias / activation / residual) in two launches: when the
+// GEMM is cut into K slabs (the batch-2 data gradients with K = 2304 / 3072) the LayerNorm kernel sums the slabs itself, in the
+// order the separate reduce launch would; otherwise the product lands in the scratch matrix C [M, N] first.
+extern "C" int unetr_gemm_bf16_ln_bwd(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C,
+                                      const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      float* dx, void* dx_bf16, const float* dres, float* dgamma, float* dbeta,
+                                      float* ln_ws, size_t ln_ws_bytes, float* ws, size_t ws_bytes, void* stream) {
+    if (!d || !C) return UNETR_ERR_ARG;
+    if (d->bias || d->res || d->pre || d->act || d->accumulate || d->alpha != 1.f || d->ldc != d->N) return UNETR_ERR_UNSUPPORTED;
+    int splits = 1;
+    if (int e = gemm_bf16_impl(d, A, B, C, nullptr, ws, ws_bytes, stream, &splits)) return e;
+    const float* dy = splits > 1 ? ws : C;
+    return unetr_layernorm_bwd_partials(dy, splits, (long)d->M * d->N, x, gamma, mean, rstd, dx, dx_bf16, dres, dgamma, dbeta,
+                                        d->M, d->N, ln_ws, ln_ws_bytes, stream);
 }
 
 // fp32 -> bf16 (round to nearest even), the weight shadow / activation cast

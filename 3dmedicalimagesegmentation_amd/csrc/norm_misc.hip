@@ -56,9 +56,11 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
 constexpr int LN_RPB = 4;   // rows per block in backward (one per wave): 108 workgroups at M = 432 instead of 27
 template <int LN_MAXV>
 __global__ void __launch_bounds__(256)
-layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+layernorm_bwd_kernel(const float* __restrict__ dy, int splits, long slab, const float* __restrict__ x, const float* __restrict__ gamma,
                      const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
                      uint16_t* __restrict__ dxb, const float* __restrict__ dres, float* __restrict__ part, int M, int H) {
+    // dy may arrive as `splits` split-K partial slabs of the GEMM that produced it (slab = elements between slabs): they are
+    // summed here in slab order from 0.f -- the arithmetic of splitk_reduce_kernel, whose launch this saves
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][H]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = H >> 2;
@@ -77,7 +79,9 @@ layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, 
         for (int j = 0; j < LN_MAXV; ++j) {
             int i = lane + 64 * j;
             if (i < nv) {
-                f32x4 xv = xr[i], dv = dyr[i], gm = ((const f32x4*)gamma)[i];
+                f32x4 xv = xr[i], dv = {0.f, 0.f, 0.f, 0.f}, gm = ((const f32x4*)gamma)[i];
+                if (splits <= 1) dv = dyr[i];
+                else for (int sp = 0; sp < splits; ++sp) dv += ((const f32x4*)(dy + sp * slab + (long)row * H))[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float h = (xv[e] - mu) * rs;
@@ -854,20 +858,27 @@ extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const flo
     return unetr_check_launch();
 }
 
-extern "C" int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
-                                   float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream) {
+// dy as `splits` partial slabs (see the kernel); declared in common.hpp for unetr_gemm_bf16_ln_bwd
+int unetr_layernorm_bwd_partials(const float* dy, int splits, long slab, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
+                                 float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || ((dgamma == nullptr) != (dbeta == nullptr)) || M <= 0) return UNETR_ERR_ARG;
     if ((H & 3) || H > LN_MAXV_MAX * 256) return UNETR_ERR_UNSUPPORTED;
     int nblk = cdiv(M, LN_RPB);
     if ((size_t)nblk * 2 * H * sizeof(float) > ws_bytes || !ws) return UNETR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-#define LN_BWD(V_) hipLaunchKernelGGL(layernorm_bwd_kernel<V_>, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, x, gamma, mean, \
+#define LN_BWD(V_) hipLaunchKernelGGL(layernorm_bwd_kernel<V_>, dim3(nblk), dim3(256), 4 * 2 * H * sizeof(float), st, dy, splits, slab, x, gamma, mean, \
                                       rstd, dx, (uint16_t*)dx_bf16, dres, ws, M, H)
     if (H <= 768) LN_BWD(3); else if (H <= 1024) LN_BWD(4); else LN_BWD(8);
     // dgamma == dbeta == NULL: the caller reduces the [nblk][2][H] partials left in ws itself (grouped, off the critical path)
     if (dgamma) hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, ws, nblk, H, dgamma, dbeta);
     return unetr_check_launch();
+}
+
+extern "C" int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
+                                   float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream) {
+    return unetr_layernorm_bwd_partials(dy, 1, 0, x, gamma, mean, rstd, dx, dx_bf16, dres, dgamma, dbeta, M, H, ws, ws_bytes, stream);
 }
 
 extern "C" int unetr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate,

@@ -565,6 +565,39 @@ def layernorm_bwd_params(dy, x, w, b, mean, rstd, dres=None, dx_bf16=None):
     return dx, _ret(w, ow, deferred=True), _ret(b, ob, deferred=True)
 
 
+def gemm_ln_bwd_params(A, Bw, M, N, K, x, w, b, mean, rstd, dres=None, dx_bf16=None):
+    """(dx, grad_w, grad_b) of a LayerNorm whose output gradient is dy = A[M,K] @ Bw[K,N] (the data gradient of the Linear
+    layer behind it, bf16-stored operands, Bw read as the [K, N] operand): unetr_gemm_bf16_ln_bwd -- when the GEMM is cut into K
+    slabs the LayerNorm kernel sums them itself, so the separate split-K reduce launch disappears (bit-identical)."""
+    assert A.dtype == torch.bfloat16 and Bw.dtype == torch.bfloat16
+    d = GemmBf16Desc()
+    d.M, d.N, d.K, d.b_kn = M, N, K, 1
+    d.lda, d.ldb, d.ldc, d.ldcb = K, N, N, N
+    d.alpha = 1.0
+    scratch = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    ws = workspace(x.device)
+    ow, ob = _gout(w), _gout(b)
+    nblk = (M + 3) // 4
+    if ow is None or ob is None:
+        dw = ow if ow is not None else torch.empty(N, dtype=torch.float32, device=x.device)
+        db = ob if ob is not None else torch.empty(N, dtype=torch.float32, device=x.device)
+        lnws = torch.empty(nblk * 2 * N, dtype=torch.float32, device=x.device)
+        call("unetr_gemm_bf16_ln_bwd", ctypes.byref(d), A.data_ptr(), Bw.data_ptr(), scratch.data_ptr(), x.data_ptr(), w.data_ptr(),
+             mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dx_bf16), _p(dres), dw.data_ptr(), db.data_ptr(),
+             lnws.data_ptr(), lnws.numel() * 4, ws.data_ptr(), ws.numel() * 4, _stream())
+        return dx, _ret(w, dw), _ret(b, db)
+    part = torch.empty(nblk * 2 * N, dtype=torch.float32, device=x.device)
+    call("unetr_gemm_bf16_ln_bwd", ctypes.byref(d), A.data_ptr(), Bw.data_ptr(), scratch.data_ptr(), x.data_ptr(), w.data_ptr(),
+         mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dx_bf16), _p(dres), None, None,
+         part.data_ptr(), part.numel() * 4, ws.data_ptr(), ws.numel() * 4, _stream())
+    st = _GRAD_SINK[w.data_ptr()]
+    st.defer["colsum"].append((part, ow, nblk, N, 2 * N))
+    st.defer["colsum"].append((part[N:], ob, nblk, N, 2 * N))
+    _arm_flush(st)
+    return dx, _ret(w, ow, deferred=True), _ret(b, ob, deferred=True)
+
+
 def attention_fwd(qkv, B, L, heads, dh, prec, out_bf16=None):
     out = torch.empty(B * L, heads * dh, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, L, dtype=torch.float32, device=qkv.device)
@@ -994,13 +1027,12 @@ class TransformerBlockFn(torch.autograd.Function):
         dw1 = wgrad_or_defer(du, y2, prec, w1, dub, y2b)
         db1 = colsum_or_defer(du, M, du.shape[1], du.shape[1], b1)
         if fast:
-            dy2 = torch.empty(M, hid, **f32)
-            gemm_bf16(dub, weight_bf16(w1), M, hid, mlp, b_kn=True, C=dy2)
             dx1b = bf16_like(x)
+            dx1, dn2w, dn2b = gemm_ln_bwd_params(dub, weight_bf16(w1), M, hid, mlp, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
         else:
             dy2 = linear_dgrad(du, w1, prec)
             dx1b = None
-        dx1, dn2w, dn2b = layernorm_bwd_params(dy2, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
+            dx1, dn2w, dn2b = layernorm_bwd_params(dy2, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
         # attention
         b16att = fast and qkv.dtype == torch.bfloat16
         if b16att:
@@ -1021,13 +1053,12 @@ class TransformerBlockFn(torch.autograd.Function):
             dqkv = attention_bwd(qkv, att, datt, lse, B, L, heads, dh, prec, dqkv_bf16=dqkvb)
         dwqkv = wgrad_or_defer(dqkv, y1, prec, wqkv, dqkvb, y1b)
         if fast:
-            dy1 = torch.empty(M, hid, **f32)
-            gemm_bf16(dqkvb, weight_bf16(wqkv), M, hid, 3 * hid, b_kn=True, C=dy1)
             dxb = bf16_like(x)
+            dx, dn1w, dn1b = gemm_ln_bwd_params(dqkvb, weight_bf16(wqkv), M, hid, 3 * hid, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         else:
             dy1 = linear_dgrad(dqkv, wqkv, prec)
             dxb = None
-        dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
+            dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         if fast:
             _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
         return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None, None)

@@ -172,6 +172,16 @@ int unetr_layernorm_bwd(const float* dy, const float* x, const float* gamma, con
                         const float* dres /* optional, added to dx */, float* dgamma, float* dbeta,
                         int M, int H, float* ws, size_t ws_bytes, void* stream);
 
+/* nn.LayerNorm backward (norm1 / norm2 of MONAI TransformerBlock) applied to dy = A . B, the data gradient of the Linear layer
+ * that consumed the LayerNorm output (SABlock.qkv / MLPBlock.linear1): when that GEMM is cut into K slabs the LayerNorm kernel
+ * sums the slabs itself (same order as the separate reduce launch: bit-identical), saving one launch per LayerNorm.  `d` must
+ * describe a plain product (alpha 1, no bias / activation / residual / accumulate, ldc == N); C [M, N] is scratch; the remaining
+ * arguments are those of unetr_layernorm_bwd (ln_ws = its ws). */
+int unetr_gemm_bf16_ln_bwd(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C,
+                           const float* x, const float* gamma, const float* mean, const float* rstd,
+                           float* dx, void* dx_bf16, const float* dres, float* dgamma, float* dbeta,
+                           float* ln_ws, size_t ln_ws_bytes, float* ws, size_t ws_bytes, void* stream);
+
 /* ---- multi-head self-attention core (MONAI SABlock.forward between qkv and out_proj) ----------------
  * qkv: [B*L, 3*Hd] with feature = which*Hd + head*dh + j;  out: [B*L, Hd] ("b h l d -> b l (h d)");
  * lse: [B, heads, L] log-sum-exp of the scaled scores (saved for backward). */

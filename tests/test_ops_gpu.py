@@ -671,3 +671,25 @@ def test_conv3_long_tile_walks(pkg, dev, monkeypatch, cin, cout, dims3):
     if f1 is not None:
         st = Fn.instnorm_stats(f1[0], cout, B, D * H * W, cout)
         assert relerr(f1[1].cpu(), st.cpu()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(432, 768, 3072), (432, 768, 2304), (1000, 768, 3072), (64, 128, 256)])
+def test_gemm_ln_bwd_fused_equals_two_steps(pkg, dev, M, N, K):
+    """unetr_gemm_bf16_ln_bwd (LayerNorm backward summing the split-K slabs of the GEMM that produced its dy) against the two
+    separate entry points: bit-identical dx, bf16 twin and gamma / beta gradients, whether the GEMM is split (batch-2 shapes)
+    or not."""
+    Fn = pkg.functional
+    A = g(M, K, seed=1).to(dev).bfloat16()
+    Wt = (g(K, N, seed=2) * 0.05).to(dev).bfloat16()                 # read as the [K, N] operand
+    x, gam, bet = g(M, N, seed=3).to(dev), (1 + 0.1 * g(N, seed=4)).to(dev), (0.1 * g(N, seed=5)).to(dev)
+    dres = g(M, N, seed=6).to(dev)
+    y, mean, rstd = Fn.layernorm_fwd(x, gam, bet)
+    dy = torch.empty(M, N, device=dev)
+    Fn.gemm_bf16(A, Wt, M, N, K, b_kn=True, C=dy)
+    dxb_ref = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    dx_ref, dw_ref, db_ref = Fn.layernorm_bwd(dy, x, gam, mean, rstd, dres=dres, dx_bf16=dxb_ref)
+    dxb = torch.empty_like(dxb_ref)
+    dx, dw, db = Fn.gemm_ln_bwd_params(A, Wt, M, N, K, x, gam, bet, mean, rstd, dres=dres, dx_bf16=dxb)
+    assert torch.equal(dx, dx_ref) and torch.equal(dxb, dxb_ref)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
