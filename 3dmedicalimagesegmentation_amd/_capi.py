@@ -67,6 +67,7 @@ _SIGNATURES = {
     "unetr_gemm": [ctypes.POINTER(GemmDesc), P, P, P, P, c_size_t, P],
     "unetr_gemm_bf16": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_size_t, P],
     "unetr_gemm_bf16_ln_bwd": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P, c_size_t, P],
+    "unetr_gemm_bf16_ln_fwd": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_float, P, P, P, P, P, c_size_t, P],
     "unetr_cast_bf16": [P, P, c_long, P],
     "unetr_ln_gemm_bf16": [ctypes.POINTER(LnGemmDesc), P],
     "unetr_attention_bf16_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],

@@ -148,5 +148,10 @@ int unetr_layernorm_bwd_partials(const float* dy, int splits, long slab, const f
                                  const float* rstd, float* dx, void* dx_bf16, const float* dres, float* dgamma,
                                  float* dbeta, int M, int H, float* ws, size_t ws_bytes, void* stream);
 
+// LayerNorm forward whose rows arrive as split-K partial slabs + (bias, residual) epilogue (norm_misc.hip; unetr_gemm_bf16_ln_fwd)
+int unetr_layernorm_fwd_partials(const float* partials, int splits, long slab, const float* bias, const float* res, long ldr, int res_mod,
+                                 float* xout, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd,
+                                 int M, int H, float eps, void* stream);
+
 // run CALL with `AT` bound to the activation storage type selected by the run-time flag act16
 #define ACT_DISPATCH(act16, ...) do { if (act16) { typedef uint16_t AT; __VA_ARGS__; } else { typedef float AT; __VA_ARGS__; } } while (0)

@@ -458,6 +458,22 @@ extern "C" int unetr_gemm_bf16_ln_bwd(const unetr_gemm_bf16_desc* d, const void*
                                         d->M, d->N, ln_ws, ln_ws_bytes, stream);
 }
 
+// C = A . B + bias + res (the residual-stream output of a block's last Linear) AND the LayerNorm of C that the next layer starts
+// with, in two launches: when the GEMM is cut into K slabs the LayerNorm kernel sums the slabs, applies bias and residual, writes
+// C and normalises the row it has just formed; otherwise the GEMM writes C through its own epilogue and the plain LayerNorm runs.
+extern "C" int unetr_gemm_bf16_ln_fwd(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C,
+                                      const float* gamma, const float* beta, float eps, float* y, void* y_bf16, float* mean, float* rstd,
+                                      float* ws, size_t ws_bytes, void* stream) {
+    if (!d || !C) return UNETR_ERR_ARG;
+    if (d->pre || d->act || d->accumulate || d->alpha != 1.f || d->ldc != d->N) return UNETR_ERR_UNSUPPORTED;
+    int splits = 1;
+    if (int e = gemm_bf16_impl(d, A, B, C, nullptr, ws, ws_bytes, stream, &splits)) return e;
+    if (splits > 1)
+        return unetr_layernorm_fwd_partials(ws, splits, (long)d->M * d->N, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : d->M,
+                                            C, gamma, beta, y, y_bf16, mean, rstd, d->M, d->N, eps, stream);
+    return unetr_layernorm_fwd(C, gamma, beta, y, y_bf16, mean, rstd, d->M, d->N, eps, stream);
+}
+
 // fp32 -> bf16 (round to nearest even), the weight shadow / activation cast
 extern "C" int unetr_cast_bf16(const float* src, void* dst, long n, void* stream) {
     if (!src || !dst || n < 0) return UNETR_ERR_ARG;

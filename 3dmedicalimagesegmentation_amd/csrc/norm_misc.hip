@@ -10,11 +10,14 @@ namespace {
 constexpr int LN_MAXV_MAX = 8;  // float4 per lane -> H <= 2048; kernels are instantiated for 3 (H <= 768), 4 and 8
 
 // --------------------------------------------------------------------------------------- LayerNorm
+// where layernorm_fwd_kernel takes its rows from: memory (splits <= 1), or the split-K partial slabs of a GEMM + its epilogue
+struct LnFwdSrc { int splits; long slab; const float* bias; const float* res; long ldr; int res_mod; float* xout; };
+
 template <int LN_MAXV>
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                      float* __restrict__ y, uint16_t* __restrict__ yb, float* __restrict__ mean, float* __restrict__ rstd,
-                     int M, int H, float eps) {
+                     int M, int H, float eps, LnFwdSrc src) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nv = H >> 2;
@@ -24,7 +27,20 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
         int i = lane + 64 * j;
-        v[j] = i < nv ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (src.splits > 1) {
+            // the row arrives as split-K partial slabs of the GEMM that produces it: summed from 0.f in slab order, + bias,
+            // + residual -- the arithmetic of splitk_reduce_kernel + EpBf::store, whose launch this saves -- and written out
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (i < nv) {
+                for (int sp = 0; sp < src.splits; ++sp) t += ((const f32x4*)(x + sp * src.slab + (long)row * H))[i];
+                if (src.bias) t += ((const f32x4*)src.bias)[i];
+                if (src.res) t += ((const f32x4*)(src.res + (long)(row % src.res_mod) * src.ldr))[i];
+                ((f32x4*)(src.xout + (long)row * H))[i] = t;
+            }
+            v[j] = t;
+        } else {
+            v[j] = i < nv ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
     }
     const float mu = wave_sum(s) / (float)H;
@@ -852,9 +868,26 @@ extern "C" int unetr_layernorm_fwd(const float* x, const float* gamma, const flo
                                    float* mean, float* rstd, int M, int H, float eps, void* stream) {
     if (!x || !gamma || !beta || (!y && !y_bf16) || !mean || !rstd || M <= 0) return UNETR_ERR_ARG;
     if ((H & 3) || H > LN_MAXV_MAX * 256) return UNETR_ERR_UNSUPPORTED;
+    const LnFwdSrc src{1, 0, nullptr, nullptr, 0, 1, nullptr};
 #define LN_FWD(V_) hipLaunchKernelGGL(layernorm_fwd_kernel<V_>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, \
-                                      (uint16_t*)y_bf16, mean, rstd, M, H, eps)
+                                      (uint16_t*)y_bf16, mean, rstd, M, H, eps, src)
     if (H <= 768) LN_FWD(3); else if (H <= 1024) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
+    return unetr_check_launch();
+}
+
+// rows = split-K partial slabs + epilogue (see LnFwdSrc); declared in common.hpp for unetr_gemm_bf16_ln_fwd
+int unetr_layernorm_fwd_partials(const float* partials, int splits, long slab, const float* bias, const float* res, long ldr, int res_mod,
+                                 float* xout, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd,
+                                 int M, int H, float eps, void* stream) {
+    if (!partials || splits < 2 || !xout || !gamma || !beta || (!y && !y_bf16) || !mean || !rstd || M <= 0) return UNETR_ERR_ARG;
+    if ((H & 3) || H > LN_MAXV_MAX * 256 || (res && (ldr & 3))) return UNETR_ERR_UNSUPPORTED;
+    const LnFwdSrc src{splits, slab, bias, res, ldr, res_mod > 0 ? res_mod : M, xout};
+    const float* x = partials;
+#define LN_FWD(V_) hipLaunchKernelGGL(layernorm_fwd_kernel<V_>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, \
+                                      (uint16_t*)y_bf16, mean, rstd, M, H, eps, src)
+    if (H <= 768) LN_FWD(3); else if (H <= 1024) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
     return unetr_check_launch();
 }
 

@@ -565,6 +565,46 @@ def layernorm_bwd_params(dy, x, w, b, mean, rstd, dres=None, dx_bf16=None):
     return dx, _ret(w, ow, deferred=True), _ret(b, ob, deferred=True)
 
 
+def gemm_bf16_ln_fwd(A, B, M, N, K, C, gamma, beta, y_bf16, bias=None, res=None, ldr=0):
+    """C[M,N] = A[M,K] @ B[N,K]^T + bias + res, and y_bf16 = LayerNorm(C) (gamma, beta) with its (mean, rstd):
+    unetr_gemm_bf16_ln_fwd -- the LayerNorm of the NEXT layer rides on the split-K reduction of this GEMM"""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
+    d = GemmBf16Desc()
+    d.M, d.N, d.K, d.b_kn = M, N, K, 0
+    d.lda, d.ldb, d.ldc, d.ldcb = K, K, N, N
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.ldr, d.alpha = ldr, 1.0
+    mean = torch.empty(M, dtype=torch.float32, device=C.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=C.device)
+    ws = workspace(C.device)
+    call("unetr_gemm_bf16_ln_fwd", ctypes.byref(d), A.data_ptr(), B.data_ptr(), C.data_ptr(), gamma.data_ptr(), beta.data_ptr(), LN_EPS,
+         None, y_bf16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
+    return mean, rstd
+
+
+def ln_ride_enabled():
+    """UNETR_AMD_LN_RIDE=1: norm1 of block i+1 is formed by the kernel that sums block i's last split-K GEMM
+    (unetr_gemm_bf16_ln_fwd) instead of its own launch.  Bit-identical and one launch less per block, but measured NEUTRAL
+    on MI355X at batch 2 (same box: 5.19-5.23 vs 5.19-5.20 ms/step): the row-owning reduce (108 workgroups, one wave per
+    row) is as much slower than the wide reduce (1296 workgroups) as the LayerNorm launch it saves.  Off by default; the
+    backward counterpart (unetr_gemm_bf16_ln_bwd), where the row-owning kernel existed anyway, is always on (-0.06 ms)."""
+    return os.environ.get("UNETR_AMD_LN_RIDE", "0") == "1"
+
+
+def _stash_ln(x, gamma, beta, xn, mean, rstd):
+    """remember on the residual-stream tensor x that LayerNorm(x; gamma, beta) already exists (computed by the kernel that
+    produced x): the consumer that would launch exactly that LayerNorm takes it from here (_stashed_ln)"""
+    x._unetr_ln = (xn, mean, rstd, gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, x._version)
+
+
+def _stashed_ln(x, gamma, beta):
+    st = getattr(x, "_unetr_ln", None)
+    if st is None or st[3:] != (gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, x._version) or st[0].shape != x.shape:
+        return None
+    return st[0], st[1], st[2]
+
+
 def gemm_ln_bwd_params(A, Bw, M, N, K, x, w, b, mean, rstd, dres=None, dx_bf16=None):
     """(dx, grad_w, grad_b) of a LayerNorm whose output gradient is dy = A[M,K] @ Bw[K,N] (the data gradient of the Linear
     layer behind it, bf16-stored operands, Bw read as the [K, N] operand): unetr_gemm_bf16_ln_bwd -- when the GEMM is cut into K
@@ -920,8 +960,9 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, dw, db, dpos, None, None
 
 
-def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, train):
-    """kernels of one transformer block; returns (x2, tensors backward needs, bf16 twins or None)"""
+def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, train, next_ln=None):
+    """kernels of one transformer block; returns (x2, tensors backward needs, bf16 twins or None).  next_ln = (gamma, beta) of
+    the LayerNorm the next layer starts with: computed by the kernel that forms x2 and left on x2 (_stash_ln)"""
     hid = x.shape[1]
     dh = hid // heads
     M, mlp = x.shape[0], w1.shape[0]
@@ -939,8 +980,12 @@ def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, h
             r1 = torch.empty(M, **f32) if train else None
             ln_gemm_bf16(x, n1w, n1b, weight_bf16(wqkv), C=None if b16att else qkv, Cb=qkv if b16att else None, xn=y1b, mean=m1, rstd=r1)
         else:
-            y1b = bf16_like(x)
-            _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
+            pre = _stashed_ln(x, n1w, n1b)       # norm1(x) may have been formed by the kernel that produced x
+            if pre is not None:
+                y1b, m1, r1 = pre
+            else:
+                y1b = bf16_like(x)
+                _, m1, r1 = layernorm_fwd(x, n1w, n1b, bf16_out=y1b, want_fp32=False)
             gemm_bf16(y1b, weight_bf16(wqkv), M, 3 * hid, hid, C=None if b16att else qkv, Cb=qkv if b16att else None)
         attb = bf16_like(x)
         if b16att:
@@ -964,7 +1009,12 @@ def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, h
         if not train:
             u = m1 = r1 = m2 = r2 = y1b = y2b = x.new_empty(0)
         x2 = torch.empty(M, hid, **f32)
-        gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
+        if next_ln is not None and not fused:
+            xn = bf16_like(x)
+            mn, rn = gemm_bf16_ln_fwd(ab, weight_bf16(w2), M, hid, mlp, x2, next_ln[0], next_ln[1], xn, bias=b2, res=x1, ldr=hid)
+            _stash_ln(x2, next_ln[0], next_ln[1], xn, mn, rn)
+        else:
+            gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
         twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs
     else:
         twins = None
@@ -984,12 +1034,17 @@ class TransformerBlockFn(torch.autograd.Function):
     (BASELINE.json config[3]): only the block input is kept and backward recomputes the block's forward kernels first."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, ckpt=False):
+    def forward(ctx, x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, ckpt=False, next_n1w=None, next_n1b=None):
+        """next_n1w / next_n1b: weight and bias of the LayerNorm the NEXT block starts with (not differentiated here: that block
+        owns its backward) -- its forward is formed by this block's last kernel"""
         _require_gpu(x)
-        x = x.contiguous()
-        train = any(ctx.needs_input_grad)
+        xc = x.contiguous()
+        if xc is not x and hasattr(x, "_unetr_ln"):
+            xc._unetr_ln = x._unetr_ln
+        x = xc
+        train = any(ctx.needs_input_grad[:12])
         x2, acts, twins = _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec,
-                                          train and not ckpt)
+                                          train and not ckpt, None if next_n1w is None else (next_n1w, next_n1b))
         ctx.ckpt = bool(ckpt) and train
         if ctx.ckpt:
             acts, twins = (), None
@@ -1061,7 +1116,7 @@ class TransformerBlockFn(torch.autograd.Function):
             dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         if fast:
             _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
-        return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None, None)
+        return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):

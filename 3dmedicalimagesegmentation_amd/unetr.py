@@ -320,17 +320,22 @@ class UNETR(nn.Module):
             if stages is None:
                 return t
             leaf = t.detach().requires_grad_(True)
+            if hasattr(t, "_unetr_ln"):
+                leaf._unetr_ln = t._unetr_ln       # (the next block's LayerNorm formed by the kernel that produced t)
             stages[k].append((t, leaf))
             return leaf
 
         ckpt = self.encoder_checkpointing and torch.is_grad_enabled()
         x = Fn.PatchEmbedFn.apply(x_in, lin.weight, lin.bias, pe.position_embeddings, self.patch_size[0], prec)
         hidden_states_out = []
+        nblk = len(self.vit.blocks)
         for i, blk in enumerate(self.vit.blocks):
+            nxt = self.vit.blocks[i + 1].norm1 if i + 1 < nblk and Fn.ln_ride_enabled() else None   # its forward rides on this block's last kernel
             x = Fn.TransformerBlockFn.apply(
                 x, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
                 blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
-                blk.mlp.linear2.bias, B, L, self.num_heads, prec, ckpt)
+                blk.mlp.linear2.bias, B, L, self.num_heads, prec, ckpt,
+                None if nxt is None else nxt.weight.detach(), None if nxt is None else nxt.bias.detach())
             if i == 3:
                 x = cut(x, 2)              # one leaf for both consumers of hidden state 3 (block 4 and encoder2)
                 hidden_states_out.append(x)

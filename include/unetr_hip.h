@@ -182,6 +182,14 @@ int unetr_gemm_bf16_ln_bwd(const unetr_gemm_bf16_desc* d, const void* A, const v
                            float* dx, void* dx_bf16, const float* dres, float* dgamma, float* dbeta,
                            float* ln_ws, size_t ln_ws_bytes, float* ws, size_t ws_bytes, void* stream);
 
+/* The forward counterpart: C = A . B + bias + res (MLPBlock.linear2 + the block's residual add) and nn.LayerNorm of C (norm1 of
+ * the NEXT TransformerBlock) -- when the GEMM is cut into K slabs the LayerNorm kernel sums them, applies bias and residual,
+ * writes C and normalises the row (bit-identical to the three separate launches).  `d`: bias / res allowed, no activation / pre /
+ * accumulate, alpha 1, ldc == N.  y (fp32) and / or y_bf16 receive the normalised rows. */
+int unetr_gemm_bf16_ln_fwd(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C,
+                           const float* gamma, const float* beta, float eps, float* y, void* y_bf16, float* mean, float* rstd,
+                           float* ws, size_t ws_bytes, void* stream);
+
 /* ---- multi-head self-attention core (MONAI SABlock.forward between qkv and out_proj) ----------------
  * qkv: [B*L, 3*Hd] with feature = which*Hd + head*dh + j;  out: [B*L, Hd] ("b h l d -> b l (h d)");
  * lse: [B, heads, L] log-sum-exp of the scaled scores (saved for backward). */

@@ -618,6 +618,28 @@ def test_two_rank_data_parallel_step(pkg, dev, tmp_path, mode):
     flat["state"].clear()
 
 
+def test_next_block_layernorm_ride_is_exact(pkg, dev, monkeypatch):
+    """UNETR_AMD_LN_RIDE=1 (norm1 of block i+1 formed by block i's last split-K reduction): logits, loss and every gradient
+    bit-identical to the default launch form."""
+    from oracle.unetr_oracle import synthetic_volume
+    x, y = synthetic_volume(2, 1, 96, 4, seed=5)
+    xd, yd = x.to(dev), y.to(dev)
+    res = []
+    for ride in ("0", "1"):
+        monkeypatch.setenv("UNETR_AMD_LN_RIDE", ride)
+        torch.manual_seed(3)
+        m = pkg.UNETRLogits(**C2).to(dev)
+        m.precision = "bf16"
+        logits = m(xd)
+        loss = pkg.DiceCELoss(to_onehot_y=True, softmax=True)(logits, yd)
+        loss.backward()
+        res.append([logits.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None])
+        del m
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_two_models_and_failed_backward(pkg, dev):
     """Re-entrancy of the arena fast path: two models with flat arenas in one process keep separate deferred
     weight-gradient queues (interleaved forward / backward of A and B give each the gradients it gets alone), and a

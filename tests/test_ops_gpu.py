@@ -693,3 +693,24 @@ def test_gemm_ln_bwd_fused_equals_two_steps(pkg, dev, M, N, K):
     dx, dw, db = Fn.gemm_ln_bwd_params(A, Wt, M, N, K, x, gam, bet, mean, rstd, dres=dres, dx_bf16=dxb)
     assert torch.equal(dx, dx_ref) and torch.equal(dxb, dxb_ref)
     assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(432, 768, 3072), (1000, 768, 3072), (64, 128, 256)])
+def test_gemm_ln_fwd_fused_equals_three_steps(pkg, dev, M, N, K):
+    """unetr_gemm_bf16_ln_fwd (the next block's LayerNorm formed by the kernel that sums this GEMM's split-K slabs, adds bias
+    and residual and writes the residual stream) against GEMM (+ reduce) followed by LayerNorm: bit-identical C, normalised
+    rows, mean and rstd, split or not."""
+    Fn = pkg.functional
+    A = g(M, K, seed=1).to(dev).bfloat16()
+    W = (g(N, K, seed=2) * 0.05).to(dev).bfloat16()
+    bias, res = g(N, seed=3).to(dev), g(M, N, seed=4).to(dev)
+    gam, bet = (1 + 0.1 * g(N, seed=5)).to(dev), (0.1 * g(N, seed=6)).to(dev)
+    c_ref = torch.empty(M, N, device=dev)
+    Fn.gemm_bf16(A, W, M, N, K, C=c_ref, bias=bias, res=res, ldr=N)
+    yb_ref = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    _, mean_ref, rstd_ref = Fn.layernorm_fwd(c_ref, gam, bet, bf16_out=yb_ref, want_fp32=False)
+    c, yb = torch.empty_like(c_ref), torch.empty_like(yb_ref)
+    mean, rstd = Fn.gemm_bf16_ln_fwd(A, W, M, N, K, c, gam, bet, yb, bias=bias, res=res, ldr=N)
+    assert torch.equal(c, c_ref) and torch.equal(yb, yb_ref)
+    assert torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)

@@ -102,11 +102,14 @@ def main():
         def fn():
             with torch.no_grad():
                 z = Fn.PatchEmbedFn.apply(xin, pe.patch_embeddings[1].weight, pe.patch_embeddings[1].bias, pe.position_embeddings, 16, prec)
-                for blk in model.vit.blocks:
+                blocks = list(model.vit.blocks)
+                for i, blk in enumerate(blocks):
+                    nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else None
                     z = Fn.TransformerBlockFn.apply(
                         z, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
                         blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
-                        blk.mlp.linear2.bias, B, 216, 12, prec)
+                        blk.mlp.linear2.bias, B, 216, 12, prec, False,
+                        None if nxt is None else nxt.weight.detach(), None if nxt is None else nxt.bias.detach())
                 return Fn.LayerNormFn.apply(z, model.vit.norm.weight, model.vit.norm.bias)
         flops = 39.771e9 * B       # encoder forward per volume
         nbytes = 4.0 * 88341504    # fp32 encoder weights streamed once

@@ -200,11 +200,14 @@ def encoder_forward_rate(pkg, model, x_in, precision, iters=10):
         with torch.no_grad():
             z = Fn.PatchEmbedFn.apply(x_in, pe.patch_embeddings[1].weight, pe.patch_embeddings[1].bias, pe.position_embeddings,
                                       model.patch_size[0], prec)
-            for blk in model.vit.blocks:
+            blocks = list(model.vit.blocks)
+            for i, blk in enumerate(blocks):           # (as UNETR._encode: the next block's norm1 rides on this block's last kernel)
+                nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else None
                 z = Fn.TransformerBlockFn.apply(
                     z, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
                     blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
-                    blk.mlp.linear2.bias, B, L, model.num_heads, prec)
+                    blk.mlp.linear2.bias, B, L, model.num_heads, prec, False,
+                    None if nxt is None else nxt.weight.detach(), None if nxt is None else nxt.bias.detach())
             return Fn.LayerNormFn.apply(z, model.vit.norm.weight, model.vit.norm.bias)
     fwd()
     torch.cuda.synchronize()
