@@ -199,20 +199,10 @@ tconv2_reduce_kernel(const float* __restrict__ part, int G, long n, float* __res
 
 // ------------------------------------------------------------------------------------------------------ forward
 // weight repack: wr[n = tap*Cout + co][k = ci] (MFMA operand type, k contiguous, rows padded to KP elements)
-template <class T>
-__global__ void tconv2_pack_kernel(const float* __restrict__ w, T* __restrict__ wr, int Cin, int Cout, int KP) {
-    const int total = 8 * Cout * KP;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int k = i % KP, nn = i / KP, tap = nn / Cout, co = nn - tap * Cout;
-        const float v = k < Cin ? w[((long)k * Cout + co) * 8 + tap] : 0.f;
-        if constexpr (sizeof(T) == 2) { __bf16 h = (__bf16)v; wr[i] = __builtin_bit_cast(uint16_t, h); } else wr[i] = v;
-    }
-}
-
 // KB = k-blocks of 4 chunks (64 bytes) per row; NT = 16-column tiles (= 8*Cout/16).  Each wave: 16 voxels x all columns.
 template <class P, int KB, int NT>
 __global__ void __launch_bounds__(256)
-tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const char* __restrict__ wr, typename Elem<P>::type* __restrict__ y, long ldy,
+tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const float* __restrict__ w, typename Elem<P>::type* __restrict__ y, long ldy,
                   int M, int D, int H, int W, int Cin, int Cout, int ntiles) {
     typedef typename Elem<P>::type T;
     constexpr int CH = P::CH, RB = KB * 64;              // bytes per operand row
@@ -223,10 +213,18 @@ tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const 
     int* tab = (int*)(lds + NT * 16 * PA + TV * PA);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const int H2 = 2 * H, W2 = 2 * W;
-    // weights: resident for the whole launch
+    // weights: resident for the whole launch, packed here from torch's [Cin, Cout, 2,2,2] (row = tap*Cout + co, k = ci; the
+    // separate pack launch per call cost more than these few strided L2 reads per workgroup)
     for (int id = threadIdx.x; id < NT * 16 * KB * 4; id += 256) {
         const int row = id / (KB * 4), q = id - row * (KB * 4);
-        *(u32x4*)(wimg + row * PA + q * 16) = *(const u32x4*)(wr + (long)row * RB + q * 16);
+        const int tap = row / Cout, co = row - tap * Cout;
+        float v[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const int k = q * CH + e;
+            v[e] = k < Cin ? w[((long)k * Cout + co) * 8 + tap] : 0.f;
+        }
+        *(u32x4*)(wimg + row * PA + q * 16) = P::pack(v);
     }
     // the x tile of the NEXT tile is in flight in registers while this tile's MFMAs and stores run (one 64-voxel tile is only
     // one 16-byte piece per thread per k-block: unpipelined, every tile paid a full global-load round trip)
@@ -299,19 +297,9 @@ tconv2_fwd_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, const 
 // ------------------------------------------------------------------------------------------------ data gradient
 // dx[m, ci] = sum_{tap,co} dy[out(m,tap), co] * w[ci,co,tap]: [64 voxels, K = 8*Cout] x [K, Cin].  The gathered dy tile is
 // row-major in k (plain b128 fragment reads); wd[ci][k] is resident in LDS.  NT = Cin/16 column tiles per wave.
-template <class T>
-__global__ void tconv2_pack_d_kernel(const float* __restrict__ w, T* __restrict__ wd, int Cin, int Cout) {
-    const int K = 8 * Cout, total = Cin * K;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int k = i % K, ci = i / K, tap = k / Cout, co = k - tap * Cout;
-        const float v = w[((long)ci * Cout + co) * 8 + tap];
-        if constexpr (sizeof(T) == 2) { __bf16 h = (__bf16)v; wd[i] = __builtin_bit_cast(uint16_t, h); } else wd[i] = v;
-    }
-}
-
 template <class P, int NT>
 __global__ void __launch_bounds__(256)
-tconv2_dgrad_kernel(const typename Elem<P>::type* __restrict__ dy, long lddy, const char* __restrict__ wd, typename Elem<P>::type* __restrict__ dx, long ldx,
+tconv2_dgrad_kernel(const typename Elem<P>::type* __restrict__ dy, long lddy, const float* __restrict__ w, typename Elem<P>::type* __restrict__ dx, long ldx,
                     int M, int D, int H, int W, int Cin, int Cout, int ntiles) {
     typedef typename Elem<P>::type T;
     constexpr int ES = sizeof(T), CH = P::CH;
@@ -322,9 +310,16 @@ tconv2_dgrad_kernel(const typename Elem<P>::type* __restrict__ dy, long lddy, co
     int* tab = (int*)(yimg + TV * PA);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const int H2 = 2 * H, W2 = 2 * W;
+    // weights wd[ci][k = tap*Cout + co] packed here from torch's [Cin, Cout, 2,2,2] (no separate pack launch)
     for (int id = threadIdx.x; id < NT * 16 * (RB / 16); id += 256) {
         const int row = id / (RB / 16), q = id - row * (RB / 16);
-        *(u32x4*)(wimg + row * PA + q * 16) = row < Cin ? *(const u32x4*)(wd + (long)row * RB + q * 16) : (u32x4){0u, 0u, 0u, 0u};
+        float v[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const int k = q * CH + e, tap = k / Cout, co = k - tap * Cout;
+            v[e] = row < Cin ? w[((long)row * Cout + co) * 8 + tap] : 0.f;
+        }
+        *(u32x4*)(wimg + row * PA + q * 16) = P::pack(v);
     }
     // the gathered dy tile of the NEXT voxel tile travels in registers while this tile's MFMAs and stores run (Cout <= 32: at
     // most 8 pieces of 16 bytes per thread with bf16 storage, 16 with fp32)
@@ -410,9 +405,9 @@ int wgrad2(const typename Elem<P>::type* x, long ldx, const typename Elem<P>::ty
 }
 
 template <class P, int KB, int NT>
-void launch_fwd(int G, const typename Elem<P>::type* x, long ldx, const char* wr, typename Elem<P>::type* y, long ldy, int M, int D, int H, int W, int Cin, int Cout,
+void launch_fwd(int G, const typename Elem<P>::type* x, long ldx, const float* w, typename Elem<P>::type* y, long ldy, int M, int D, int H, int W, int Cin, int Cout,
                 int ntiles, hipStream_t st) {
-    hipLaunchKernelGGL((tconv2_fwd_kernel<P, KB, NT>), dim3(G), dim3(256), 0, st, x, ldx, wr, y, ldy, M, D, H, W, Cin, Cout, ntiles);
+    hipLaunchKernelGGL((tconv2_fwd_kernel<P, KB, NT>), dim3(G), dim3(256), 0, st, x, ldx, w, y, ldy, M, D, H, W, Cin, Cout, ntiles);
 }
 
 template <class P>
@@ -421,11 +416,9 @@ int fwd2(const typename Elem<P>::type* x, long ldx, const float* w, typename Ele
     typedef typename Elem<P>::type T;
     const int M = (int)((long)B * D * H * W), ntiles = cdiv(M, TV), N = 8 * Cout, NT = N / 16;
     const int SK = 4 * P::CH, KB = cdiv(Cin, SK), KP = KB * SK;      // k-block = 4 chunks = 64 bytes per operand row
-    if (!ws || (size_t)N * KP * sizeof(T) > ws_bytes) return UNETR_ERR_WORKSPACE;
-    hipLaunchKernelGGL((tconv2_pack_kernel<T>), dim3(cdiv(N * KP, 256)), dim3(256), 0, st, w, (T*)ws, Cin, Cout, KP);
+    (void)ws; (void)ws_bytes; (void)KP;
     const int G = std::min(ntiles, 768);
-    const char* wr = (const char*)ws;
-#define TC_FW(KB_, NT_) launch_fwd<P, KB_, NT_>(G, x, ldx, wr, y, ldy, M, D, H, W, Cin, Cout, ntiles, st)
+#define TC_FW(KB_, NT_) launch_fwd<P, KB_, NT_>(G, x, ldx, w, y, ldy, M, D, H, W, Cin, Cout, ntiles, st)
 #define TC_FW_NT(KB_) \
     switch (NT) { case 4: TC_FW(KB_, 4); break; case 8: TC_FW(KB_, 8); break; case 16: TC_FW(KB_, 16); break; default: return UNETR_ERR_UNSUPPORTED; }
     if (KB == 1) { TC_FW_NT(1) } else if (KB == 2) { TC_FW_NT(2) } else if (KB == 4) { TC_FW_NT(4) } else return UNETR_ERR_UNSUPPORTED;
@@ -440,14 +433,13 @@ int dgrad2(const typename Elem<P>::type* dy, long lddy, const float* w, typename
     const int RB = K * (int)sizeof(T), PA = RB + 16;
     const size_t lds = (size_t)NT * 16 * PA + (size_t)TV * PA + TV * 4;
     if (lds > 150 * 1024 || RB % 64) return UNETR_ERR_UNSUPPORTED;
-    if (!ws || (size_t)Cin * K * sizeof(T) > ws_bytes) return UNETR_ERR_WORKSPACE;
-    hipLaunchKernelGGL((tconv2_pack_d_kernel<T>), dim3(cdiv(Cin * K, 256)), dim3(256), 0, st, w, (T*)ws, Cin, Cout);
+    (void)ws; (void)ws_bytes;
     const int G = std::min(ntiles, lds > 64 * 1024 ? 256 : 768);
 #define TC_DG(NT_)                                                                                                      \
     do {                                                                                                                \
         if (lds > 64 * 1024)                                                                                            \
             (void)hipFuncSetAttribute((const void*)tconv2_dgrad_kernel<P, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((tconv2_dgrad_kernel<P, NT_>), dim3(G), dim3(256), lds, st, dy, lddy, (const char*)ws, dx, ldx, M, D, H, W, \
+        hipLaunchKernelGGL((tconv2_dgrad_kernel<P, NT_>), dim3(G), dim3(256), lds, st, dy, lddy, w, dx, ldx, M, D, H, W, \
                            Cin, Cout, ntiles);                                                                          \
     } while (0)
     switch (NT) { case 1: TC_DG(1); break; case 2: TC_DG(2); break; case 3: TC_DG(3); break; case 4: TC_DG(4); break; default: return UNETR_ERR_UNSUPPORTED; }
