@@ -277,7 +277,8 @@ def run_c5(args, pkg, dev, rank, world):
     cfg = dict(CFG, out_channels=2)                     # Task09 spleen: n_classes = 2 (:303)
     model = pkg.UNETR(**cfg).to(dev)
     model.precision = args.precision
-    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    flat = None if args.no_flat else model.use_flat_buffers()      # arena gradients: AdamW per contiguous run, grouped ViT weight gradients
+    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
     x, _ = synthetic_volume(4, 1, 96, 2, seed=1234 + rank)
     x = x.to(dev)
 
