@@ -153,5 +153,8 @@ int unetr_layernorm_fwd_partials(const float* partials, int splits, long slab, c
                                  float* xout, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd,
                                  int M, int H, float eps, void* stream);
 
+int unetr_instnorm_stats_finalize2(const float* part, const float* part_b, int nchunk, int B, long V, int C, float eps,
+                                   float* stats, float* stats_b, void* stream);
+
 // run CALL with `AT` bound to the activation storage type selected by the run-time flag act16
 #define ACT_DISPATCH(act16, ...) do { if (act16) { typedef uint16_t AT; __VA_ARGS__; } else { typedef float AT; __VA_ARGS__; } } while (0)

@@ -1355,10 +1355,14 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
 // dw[i] = sum_g part[g][i]: 32 outputs x 8 g-phases per workgroup, fixed summation order (reproducible); eight loads of
 // a phase are in flight together (the slabs sit in L2: the pass is latency-, not bandwidth-bound)
 __global__ void __launch_bounds__(256)
-conv3_wgrad_reduce_kernel(const float* __restrict__ part, int G, long n, float* __restrict__ dw) {
+conv3_wgrad_reduce_kernel(const float* __restrict__ part, int G, long n, float* __restrict__ dw, int nb1,
+                          const float* __restrict__ part_b, long n_b, float* __restrict__ dw_b) {
+    // workgroups >= nb1: the second problem of the same launch (the 1x1x1 weight gradient of a fused residual-block front)
+    int bx = blockIdx.x, nbx = nb1;
+    if (bx >= nb1) { bx -= nb1; nbx = gridDim.x - nb1; part = part_b; n = n_b; dw = dw_b; }
     __shared__ float sm[8][33];
     const int o = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    for (long i0 = (long)blockIdx.x * 32; i0 < n; i0 += (long)gridDim.x * 32) {
+    for (long i0 = (long)bx * 32; i0 < n; i0 += (long)nbx * 32) {
         const long i = i0 + o;
         float s = 0.f;
         if (i < n) {
@@ -1626,9 +1630,10 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
         else if (vy) LAUNCH_WG(0, true);
         else LAUNCH_WG(0, false);
     }
-    int blocks = (int)std::min<long>((n + 31) / 32, 16384);
-    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, (int)G, n, dw);
-    if (dy3) hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((int)std::min<long>((n3 + 31) / 32, 16384)), dim3(256), 0, st, ws3, (int)G, n3, dw3);
+    const int blocks = (int)std::min<long>((n + 31) / 32, 16384);
+    const int blocks3 = dy3 ? (int)std::min<long>((n3 + 31) / 32, 16384) : 0;
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)G, n, dw, blocks,
+                       (const float*)ws3, n3, dw3);
     return unetr_check_launch();
 }
 
@@ -1676,8 +1681,8 @@ extern "C" int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack,
     else return UNETR_ERR_ARG;
     if (rc) return rc;
     const long V = (long)D * H * W;
-    rc = unetr_instnorm_stats_finalize(ws, fz.rows, B, V, Cout, eps, stats, stream);
-    if (rc == UNETR_OK && w3pack) rc = unetr_instnorm_stats_finalize(ws + per, fz.rows, B, V, Cout, eps, stats3, stream);
+    if (w3pack) rc = unetr_instnorm_stats_finalize2(ws, ws + per, fz.rows, B, V, Cout, eps, stats, stats3, stream);      // one launch for both sets
+    else rc = unetr_instnorm_stats_finalize(ws, fz.rows, B, V, Cout, eps, stats, stream);
     return rc;
 }
 

@@ -963,7 +963,10 @@ extern "C" int unetr_instnorm_stats(const void* x, long ld, int B, long V, int C
 
 // statistics from partial sums produced elsewhere (the fused conv forward): part [B][nchunk][2][C]
 __global__ void __launch_bounds__(256)
-in_stats_final_block_kernel(const float* __restrict__ part, int nchunk, long V, int C, float eps, float* __restrict__ stats) {
+in_stats_final_block_kernel(const float* __restrict__ part, int nchunk, long V, int C, float eps, float* __restrict__ stats,
+                            const float* __restrict__ part_b, float* __restrict__ stats_b) {
+    // blockIdx.y == 1: the second statistics set of the same launch (the 1x1x1 branch of a fused residual-block front)
+    if (blockIdx.y) { part = part_b; stats = stats_b; }
     __shared__ double sm[2][4];
     const int i = blockIdx.x, b = i / C, c = i - b * C, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
@@ -989,7 +992,17 @@ in_stats_final_block_kernel(const float* __restrict__ part, int nchunk, long V, 
 extern "C" int unetr_instnorm_stats_finalize(const float* part, int nchunk, int B, long V, int C, float eps, float* stats,
                                              void* stream) {
     if (!part || !stats || nchunk <= 0 || B <= 0 || C <= 0 || V <= 0) return UNETR_ERR_ARG;
-    hipLaunchKernelGGL(in_stats_final_block_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, part, nchunk, V, C, eps, stats);
+    hipLaunchKernelGGL(in_stats_final_block_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, part, nchunk, V, C, eps, stats,
+                       (const float*)nullptr, (float*)nullptr);
+    return unetr_check_launch();
+}
+
+// two statistics sets with the same geometry in ONE launch (declared in common.hpp; conv3.hip: conv + 1x1x1 branch)
+int unetr_instnorm_stats_finalize2(const float* part, const float* part_b, int nchunk, int B, long V, int C, float eps,
+                                   float* stats, float* stats_b, void* stream) {
+    if (!part || !stats || !part_b || !stats_b || nchunk <= 0 || B <= 0 || C <= 0 || V <= 0) return UNETR_ERR_ARG;
+    hipLaunchKernelGGL(in_stats_final_block_kernel, dim3(B * C, 2), dim3(256), 0, (hipStream_t)stream, part, nchunk, V, C, eps, stats,
+                       part_b, stats_b);
     return unetr_check_launch();
 }
 
