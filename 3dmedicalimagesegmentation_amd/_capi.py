@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
+ABI_VERSION = 3        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -137,6 +138,11 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `make -C {os.path.join(_HERE, 'csrc')}`. There is no CPU/PyTorch fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.unetr_abi_version.restype = c_int
+    got = lib.unetr_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports C-ABI version {got}, this binding was written against {ABI_VERSION}: the "
+                           f"library is stale -- rebuild the extension (`make -C {os.path.join(_HERE, 'csrc')}`).")
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes

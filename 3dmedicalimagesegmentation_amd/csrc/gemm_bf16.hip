@@ -350,18 +350,18 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) PrecBF16::mma(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < 4; ++j) PrecBF16::mma(acc[i][j], b[j], a[i]);    // swapped operands: the accumulator tile is dW^T
         }
     }
+    // lane (cc, g) holds dW[n = tile row cc][k = 4g .. 4g+3]: ONE 16-byte store per tile (was four 4-byte stores whose 16 lanes
+    // covered 64 bytes each); dW is written once and next read by AdamW after 350 MB of other gradients: non-temporal
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + (wm * 4 + i) * 16 + 4 * g + r, k = k0 + (wn * 4 + j) * 16 + cc;
-                if (n < pr.N && k < pr.K) pr.dw[(long)n * pr.K + k] = acc[i][j][r];
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + (wm * 4 + i) * 16 + cc, k = k0 + (wn * 4 + j) * 16 + 4 * g;
+            if (n < pr.N && k < pr.K) __builtin_nontemporal_store(acc[i][j], (f32x4*)(pr.dw + (long)n * pr.K + k));
+        }
 }
 
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n8) {
@@ -497,7 +497,7 @@ extern "C" int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs,
         for (int i = 0; i < ga.n; ++i) {
             const unetr_grouped_problem& q = probs[base + i];
             if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N < 8 || q.K < 8) return UNETR_ERR_ARG;
-            if (q.M % 8 || q.N % 8 || q.K % 8 || ((uintptr_t)q.dy & 15) || ((uintptr_t)q.x & 15)) return UNETR_ERR_UNSUPPORTED;
+            if (q.M % 8 || q.N % 8 || q.K % 8 || ((uintptr_t)q.dy & 15) || ((uintptr_t)q.x & 15) || ((uintptr_t)q.dw & 15)) return UNETR_ERR_UNSUPPORTED;
             GwProblem& g = ga.p[i];
             g.dy = (const uint16_t*)q.dy; g.x = (const uint16_t*)q.x; g.dw = q.dw; g.M = q.M; g.N = q.N; g.K = q.K;
             g.tile0 = tiles; g.ntn = cdiv(q.N, 128);

@@ -1,7 +1,7 @@
 // unetr_gemm: Linear fwd / dgrad / wgrad and the 1x1x1 conv through the MFMA GEMM family (gemm_kernel.hpp).
 #include "gemm_kernel.hpp"
 
-extern "C" int unetr_abi_version(void) { return 1; }
+extern "C" int unetr_abi_version(void) { return UNETR_ABI_VERSION; }
 
 extern "C" int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float* B, float* C,
                           float* ws, size_t ws_bytes, void* stream) {

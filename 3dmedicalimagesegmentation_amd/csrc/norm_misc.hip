@@ -796,6 +796,61 @@ outconv_bwd_small_kernel(const float* __restrict__ dl, const float* __restrict__
     }
 }
 
+// Larger heads (Cout > 4 or Cin > 16; the reference's default is 14 BTCV classes, unetr_segmentation_3d.py:303): weight-gradient
+// partials part[blk][Cout*Cin], dw[co,ci] = sum_vox dl[b,co,v] * x[vox,ci], on fp32- or bf16-stored feature maps.  A workgroup
+// stages 128 voxels of dl (all classes) and of x (all channels) in LDS as fp32; thread t owns the (co, ci) pairs t, t+256, ...
+// (<= 4 of them: Cout <= 16, Cin <= 64), so the dl value is a broadcast read and the x row a conflict-free one.
+constexpr int OCW_VT = 128;
+template <class T>
+__global__ void __launch_bounds__(256)
+outconv_wgrad_generic_kernel(const float* __restrict__ dl, const T* __restrict__ x, long ldx, float* __restrict__ part,
+                             int B, long V, int Cin, int Cout) {
+    __shared__ float sdl[OC_MAXCO][OCW_VT];
+    __shared__ float sx[OCW_VT][OC_MAXCI + 1];
+    const int np = Cout * Cin;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int pco[4], pci[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = threadIdx.x + k * 256;
+        pco[k] = p < np ? p / Cin : 0;
+        pci[k] = p < np ? p - pco[k] * Cin : 0;
+    }
+    const long total = (long)B * V;
+    const long ntile = (total + OCW_VT - 1) / OCW_VT;
+    for (long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long v0 = t * OCW_VT;
+        for (int i = threadIdx.x; i < Cout * OCW_VT; i += 256) {
+            const int co = i / OCW_VT, j = i - co * OCW_VT;
+            const long vox = v0 + j;
+            float g = 0.f;
+            if (vox < total) { const int b = (int)(vox / V); const long v = vox - (long)b * V; g = dl[((long)b * Cout + co) * V + v]; }
+            sdl[co][j] = g;
+        }
+        const int c4n = Cin >> 2;
+        for (int i = threadIdx.x; i < c4n * OCW_VT; i += 256) {
+            const int j = i / c4n, c4 = (i - j * c4n) * 4;
+            const long vox = v0 + j;
+            f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (vox < total) xv = Io<T>::ld4(x + vox * ldx + c4);
+            sx[j][c4] = xv[0]; sx[j][c4 + 1] = xv[1]; sx[j][c4 + 2] = xv[2]; sx[j][c4 + 3] = xv[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((int)threadIdx.x + k * 256 < np) {
+                float s = acc[k];
+                for (int j = 0; j < OCW_VT; ++j) s = fmaf(sdl[pco[k]][j], sx[j][pci[k]], s);
+                acc[k] = s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((int)threadIdx.x + k * 256 < np) part[(long)blockIdx.x * np + threadIdx.x + k * 256] = acc[k];
+}
+
 // out0[n] = sum_r part[r][n] for n < n0, out1[n - n0] for the rest (bias gradient, then weight gradient)
 __global__ void outconv_final_kernel(const float* __restrict__ part, int R, int N, int n0, float* __restrict__ out0, float* __restrict__ out1) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1121,7 +1176,6 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, 
     const bool wg = Cout <= 4 && Cin <= 16 && ((uintptr_t)x & 15) == 0;      // weight gradient from the same pass
     const int Wd = act16 ? 8 : 4;
     const bool small = wg && (Cin == Wd || Cin == 2 * Wd || Cin == 4 * Wd) && (ldx % Wd) == 0 && (lddx % Wd) == 0 && ((uintptr_t)dx & 15) == 0;
-    if (!wg && act16) return UNETR_ERR_UNSUPPORTED;                          // (the generic GEMM below reads fp32 x)
     const int np = Cout + (wg ? Cout * Cin : 0);
     size_t part_bytes = (size_t)nblk * np * sizeof(float);
     size_t part_al = (part_bytes + 255) & ~(size_t)255;
@@ -1140,15 +1194,21 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, 
         hipLaunchKernelGGL(outconv_final_kernel, dim3(cdiv(np, 256)), dim3(256), 0, st, ws2, RB, np, Cout, dbias, dw);
     }
     if (wg) return unetr_check_launch();
-    // larger heads: dw[Cout, Cin] = sum_b dl_b[Cout, V] * x_b[V, Cin]   (exact-fp32 MFMA, split-K over voxels)
-    for (int b = 0; b < B; ++b) {
-        unetr_gemm_desc d{};
-        d.M = Cout; d.N = Cin; d.K = (int)V; d.batch = 1; d.a_trans = 0; d.b_trans = 1;
-        d.lda = V; d.ldb = ldx; d.ldc = Cin; d.res_mod = Cout; d.alpha = 1.f; d.accumulate = b > 0; d.prec = UNETR_PREC_F32;
-        int e = unetr_gemm(&d, dlogits + (long)b * Cout * V, (const float*)x + (long)b * V * ldx, dw, ws2, ws2_bytes, stream);
-        if (e) return e;
+    // larger heads (the reference's default is 14 classes): per-workgroup partials of dw from fp32- or bf16-stored x, then the
+    // same column-sum pair.  `ws` is free again: the launches that read the bias partials are ahead of these in the stream.
+    {
+        const int npw = Cout * Cin;
+        const long ntile = ((long)B * V + OCW_VT - 1) / OCW_VT;
+        const int nb2 = (int)std::min<long>(ntile, 1024);
+        const size_t p2 = ((size_t)nb2 * npw * sizeof(float) + 255) & ~(size_t)255;
+        const int RB = std::max(1, std::min(cdiv(nb2, 64), 256));
+        if (p2 + (size_t)RB * npw * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+        float* wsb = (float*)((char*)ws + p2);
+        ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_wgrad_generic_kernel<AT>), dim3(nb2), dim3(256), 0, st, dlogits, (const AT*)x, ldx, ws, B, V, Cin, Cout));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(npw, 64), RB), dim3(256), 0, st, ws, (long)npw, nb2, npw, wsb, RB);
+        hipLaunchKernelGGL(outconv_final_kernel, dim3(cdiv(npw, 256)), dim3(256), 0, st, wsb, RB, npw, 0, dbias, dw);
     }
-    return UNETR_OK;
+    return unetr_check_launch();
 }
 
 static int adamw_launch(float* p, const void* g, int g_bf16, float gscale, float* m, float* v, long n, float lr, float beta1,

@@ -48,6 +48,7 @@ class ArenaState:
         self.sinks = {}            # data_ptr -> (weakref(param), arena view)
         self.ready_cb = []         # data-parallel reducers: called with a parameter once its arena gradient is final
         self.defer = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0}
+        self.unmaintained = 0      # arena shadows of THIS model re-derived since its flat optimizer last vouched for them
 
     def reset_deferred(self):
         """Drop whatever a backward pass that raised left queued (its end-of-pass callback never ran): without this the
@@ -336,19 +337,22 @@ def bf16_attention_enabled():
 # Under hipGraph capture a non-maintained shadow is always re-cast, so the cast is part of the captured step.
 _SHADOW = {}
 _WEIGHT_EPOCH = [0]
-_UNMAINTAINED = [0]     # how many arena shadows have been re-derived since the flat optimizer last vouched for them
 
 
-def mark_flat_maintained(params):
+def mark_flat_maintained(params, state=None):
     """flat-arena AdamW has just rewritten the whole bf16 shadow arena together with the masters: every registered shadow
-    of these parameters is in step again (only walks the table after something had to be re-derived)"""
-    if not _UNMAINTAINED[0]:
+    of these parameters is in step again.  Only walks the table after something of THIS model had to be re-derived: the
+    count lives in the model's ArenaState (a process-wide one let model A's step clear what model B still had to redo)."""
+    if state is None and params:
+        state = _GRAD_SINK.get(params[0].data_ptr())
+    if state is not None and not state.unmaintained:
         return
     for w in params:
         ent = _SHADOW.get(id(w))
         if ent is not None and ent[4]() is w and ent[5] == w.data_ptr():
             ent[1], ent[3] = w._version, True
-    _UNMAINTAINED[0] = 0
+    if state is not None:
+        state.unmaintained = 0
 
 
 def bf16_storage_enabled():
@@ -398,7 +402,9 @@ def weight_bf16(w):
         # re-derived here = somebody other than this package's optimizer changed the weight (or may have): the copy is no
         # longer optimizer-maintained until that optimizer steps again (shadow_ptr_for_update / mark_flat_maintained)
         ent[1], ent[2], ent[5], ent[3] = w._version, _WEIGHT_EPOCH[0], w.data_ptr(), False
-        _UNMAINTAINED[0] += 1
+        st = _GRAD_SINK.get(w.data_ptr())
+        if st is not None:
+            st.unmaintained += 1
     return ent[0]
 
 

@@ -122,7 +122,7 @@ class AdamW(torch.optim.Optimizer):
         for run in self._flat_runs(params, pattern):
             self._launch_run(group, run, steps, gbase, False, 1.0, stream)
         if flat.get("shadow") is not None:           # the kernel rewrote the bf16 shadow slices of every parameter that stepped
-            Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has])
+            Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has], flat.get("state"))
         return True
 
     # ---- data-parallel arena update: all-reduce pieces overlap the optimizer kernels of the pieces before them ----
@@ -156,7 +156,7 @@ class AdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def end_reduced_step(self, plan):
         if self._flat.get("shadow") is not None:
-            Fn.mark_flat_maintained([p for p, has in zip(self.param_groups[0]["params"], plan["pattern"]) if has])
+            Fn.mark_flat_maintained([p for p, has in zip(self.param_groups[0]["params"], plan["pattern"]) if has], self._flat.get("state"))
         Fn.refresh_conv_packs()
 
     @torch.no_grad()
@@ -181,5 +181,5 @@ class AdamW(torch.optim.Optimizer):
                 before_run(k, run[2], run[3])
             self._launch_run(group, run, steps, gsrc.data_ptr(), g_bf16, gscale, stream)
         if self._flat.get("shadow") is not None:
-            Fn.mark_flat_maintained([p for p, has in zip(params, plan["pattern"]) if has])
+            Fn.mark_flat_maintained([p for p, has in zip(params, plan["pattern"]) if has], self._flat.get("state"))
         Fn.refresh_conv_packs()

@@ -4,12 +4,12 @@ AdamW step -> zero_grad) as ONE object that owns how it is launched on an MI355X
 * single GPU: the whole step -- forward, loss, backward, AdamW -- is captured into one hipGraph and replayed (no per-step
   host work, no host sync: AdamW's step counters live on the device, the loss stays a device scalar).
 * data parallel (one process per GPU, RCCL over xGMI; new capability, the reference is single-GPU): backward runs in the
-  four passes of ``UNETR.forward_staged`` and the sum-all-reduce of each pass's gradient range (``UNETR.stage_ranges``)
+  five passes of ``UNETR.forward_staged`` and the sum-all-reduce of each pass's gradient range (``UNETR.stage_ranges``)
   is issued on a side HIP stream as soon as that pass has been launched, so it runs underneath the passes that follow
   (conv-side gradients under ViT blocks 11..8, those under blocks 7..4, ...).  What is left when backward ends -- the
-  last range, cut into ``tail_pieces`` -- overlaps with the AdamW kernels of the ranges already reduced: the optimizer
+  last range (block 0 + patch embedding, 41 MB of the 370 MB), cut into ``tail_pieces`` -- overlaps with the AdamW kernels of the ranges already reduced: the optimizer
   kernel reads the summed gradients straight from the communication buffer and averages on the fly, so there is no copy
-  back and no scaling pass.  Pass 0 (with forward and loss) and passes 1-3 are separate hipGraphs sharing one memory pool;
+  back and no scaling pass.  Pass 0 (with forward and loss) and passes 1-4 are separate hipGraphs sharing one memory pool;
   the collectives are ordinary eager RCCL calls between graph launches, nothing depends on capturing a collective.
   Gradients travel in fp32 by default (the same sum the single-GPU arithmetic would do), bf16 on request.
 
@@ -18,6 +18,20 @@ AdamW step -> zero_grad) as ONE object that owns how it is launched on an MI355X
 import torch
 
 from . import functional as Fn
+
+
+_SIDE = {}
+
+
+def side_stream(device=None):
+    """ONE side stream per device for every TrainStep of the process: eager warm-up and graph capture both run on it, so the
+    scratch workspace of that stream (functional.workspace: 256 MB per (device, stream)) is allocated once, during the eager
+    warm-up -- i.e. OUTSIDE any graph's private memory pool -- and shared by all steps and graphs."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _SIDE.get(idx)
+    if st is None:
+        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+    return st
 
 
 def split_range(flat, lo, hi, pieces):
@@ -33,7 +47,7 @@ def split_range(flat, lo, hi, pieces):
 
 class TrainStep:
     def __init__(self, model, criterion, optimizer, x, y, *, use_graph=True, data_parallel=False, process_group=None,
-                 comm_dtype=torch.float32, tail_pieces=3, warmup=2):
+                 comm_dtype=torch.float32, tail_pieces=2, warmup=2):
         flat = getattr(model, "_flat", None)
         self.model, self.crit, self.opt, self.x, self.y = model, criterion, optimizer, x, y
         self.flat = flat
@@ -62,14 +76,16 @@ class TrainStep:
             # per backward pass.  The conv side's 16 MB wait for pass 1 and travel with its range: one hand-over to the
             # communication stream less per step (each costs the main stream ~70 us), nothing lost in overlap
             self.pieces = [[], [ranges[0], ranges[1]]] + [[r] for r in ranges[2:-1]] + [split_range(flat, *ranges[-1], tail_pieces)]
+            self.npass = len(self.pieces)
             self._first_k = next(k for k, st in enumerate(self.pieces) if st)
             self.cuts = sorted({lo for st in self.pieces for lo, _ in st} | {hi for st in self.pieces for _, hi in st})
             self._plan = None         # the AdamW launches: planned from the gradient pattern of the first (eager) step
             self._steps = None
         # eager warm-up: allocates workspaces, optimizer state, RCCL communicators -- all of which must exist before capture
-        side = torch.cuda.Stream()
+        self.side = side = side_stream(x.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            Fn.workspace(x.device)                      # exists before any capture on this stream
             for _ in range(max(1, warmup)):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
@@ -115,12 +131,21 @@ class TrainStep:
         with torch.cuda.stream(self.comm_stream):
             if k == self._first_k:
                 self._steps = self.opt.begin_reduced_step(self._plan)
+            # every piece's collective is ISSUED first (async_op=True: c10d enqueues it on the process group's own stream
+            # behind an event recorded on the current = communication stream, and hands back a Work), so the collectives of
+            # one pass run back to back; then, piece by piece, Work.wait() makes the communication stream wait for that
+            # collective's end event (ProcessGroupNCCL::WorkNCCL::synchronizeStream: a stream wait, no host block) and AdamW
+            # on the piece follows in stream order -- underneath the next piece's collective.
+            works = []
             for lo, hi in self.pieces[k]:
                 buf = src[lo:hi]
                 if not self.in_place:
                     Fn.cast_bf16(g[lo:hi], out=buf)
-                if self.dist is not None:
-                    self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+                works.append(self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                             if self.dist is not None else None)
+            for (lo, hi), work in zip(self.pieces[k], works):
+                if work is not None:
+                    work.wait()
                 self.opt.step_runs(self._plan, self._runs_of[(lo, hi)], self._steps, src, 1.0 / self.world)
             if k == len(self.pieces) - 1:
                 self.opt.end_reduced_step(self._plan)
@@ -141,13 +166,13 @@ class TrainStep:
         self._pass0()
         if not first:
             self._reduce_and_update(0)
-        for k in (1, 2, 3):
+        for k in range(1, self.npass):
             self._pass(k)
             if not first:
                 self._reduce_and_update(k)
         if first:                         # the pattern is only known once every pass has run: this one step is not overlapped
             self._make_plan()
-            for k in range(4):
+            for k in range(self.npass):
                 self._reduce_and_update(k)
         elif tuple(p.grad is not None for p in self.opt.param_groups[0]["params"]) != self._plan["pattern"]:
             raise RuntimeError("data-parallel step: the set of parameters that receive gradients changed between steps")
@@ -170,17 +195,17 @@ class TrainStep:
         mode = "thread_local"
         if not self.dp:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=mode):
+            with torch.cuda.graph(g, stream=self.side, capture_error_mode=mode):
                 self._single_step()
             self.graphs = [g]
             return
         graphs = [torch.cuda.CUDAGraph()]
-        with torch.cuda.graph(graphs[0], capture_error_mode=mode):
+        with torch.cuda.graph(graphs[0], stream=self.side, capture_error_mode=mode):
             self._pass0()
         pool = graphs[0].pool()
-        for k in (1, 2, 3):
+        for k in range(1, self.npass):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+            with torch.cuda.graph(g, pool=pool, stream=self.side, capture_error_mode=mode):
                 self._pass(k)
             graphs.append(g)
         self.graphs = graphs
@@ -202,4 +227,5 @@ class TrainStep:
             return "eager"
         if not self.dp:
             return "hipGraph(fwd+loss+bwd+AdamW)"
-        return "4 hipGraphs (fwd+loss+bwd pass 0 | ViT passes 1-3), per-pass all-reduce on a side stream, AdamW per reduced piece"
+        return (f"{self.npass} hipGraphs (fwd+loss+bwd pass 0 | ViT passes 1-{self.npass - 1}), per-pass all-reduce on a side stream, "
+                "AdamW per reduced piece")

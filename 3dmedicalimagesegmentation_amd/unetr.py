@@ -271,18 +271,28 @@ class UNETR(nn.Module):
                           state=self._arena_state)
         return self._flat
 
+    # first block of each ViT backward pass after the first, in execution order of backward (see forward_staged): passes run
+    # blocks 11..8 (+ vit.norm), 7..4, 3..1, and last block 0 + patch embedding -- the last pass is kept SHORT because its
+    # gradients are the only ones whose all-reduce cannot hide under later backward work (41 MB fp32 instead of 126 MB)
+    backward_stage_starts = (8, 4, 1)
+
+    def _pass_of_block(self, j):
+        """index (1-based; 0 is the conv side) of the backward pass that runs transformer block j"""
+        return 1 + sum(1 for s in self.backward_stage_starts if s > j)
+
     def stage_ranges(self):
         """Arena ranges [lo, hi) of the gradients each backward stage of ``forward_staged`` completes, in completion
-        order: the conv side (encoder1-4, decoder5-2, out), ViT blocks 8-11 + vit.norm, blocks 4-7, patch embedding +
-        blocks 0-3.  These are the data-parallel buckets (reverse execution order)."""
+        order: the conv side (encoder1-4, decoder5-2, out), ViT blocks 8-11 + vit.norm, blocks 4-7, blocks 1-3, patch
+        embedding + block 0.  These are the data-parallel buckets (reverse execution order)."""
         flat = getattr(self, "_flat", None)
         if flat is None:
             raise RuntimeError("stage_ranges() needs use_flat_buffers()")
         index = {id(p): i for i, p in enumerate(flat["params"])}
         offs = flat["offsets"]
         first = lambda m: offs[index[id(next(m.parameters()))]]
-        b4, b8, conv = first(self.vit.blocks[4]), first(self.vit.blocks[8]), first(self.encoder1)
-        return [(conv, flat["total"]), (b8, conv), (b4, b8), (0, b4)]
+        conv = first(self.encoder1)
+        bounds = [conv] + [first(self.vit.blocks[s]) for s in sorted(self.backward_stage_starts, reverse=True)] + [0]
+        return [(conv, flat["total"])] + [(lo, hi) for hi, lo in zip(bounds[:-1], bounds[1:])]
 
     def _prec(self) -> int:
         try:
@@ -329,6 +339,7 @@ class UNETR(nn.Module):
         x = Fn.PatchEmbedFn.apply(x_in, lin.weight, lin.bias, pe.position_embeddings, self.patch_size[0], prec)
         hidden_states_out = []
         nblk = len(self.vit.blocks)
+        starts = set(self.backward_stage_starts)
         for i, blk in enumerate(self.vit.blocks):
             nxt = self.vit.blocks[i + 1].norm1 if i + 1 < nblk and Fn.ln_ride_enabled() else None   # its forward rides on this block's last kernel
             x = Fn.TransformerBlockFn.apply(
@@ -336,14 +347,13 @@ class UNETR(nn.Module):
                 blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
                 blk.mlp.linear2.bias, B, L, self.num_heads, prec, ckpt,
                 None if nxt is None else nxt.weight.detach(), None if nxt is None else nxt.bias.detach())
-            if i == 3:
-                x = cut(x, 2)              # one leaf for both consumers of hidden state 3 (block 4 and encoder2)
-                hidden_states_out.append(x)
-            elif i == 7:
-                hidden_states_out.append(x)
-                x = cut(x, 1)
-            elif i in (6, 9):
-                hidden_states_out.append(cut(x, 1 if i == 6 else 0))
+            # a pass boundary behind block i (block i+1 starts a pass) or a hidden state the conv side consumes (unetr.py:197-201:
+            # 3, 6, 9): ONE leaf per hidden state collects the gradients of all its consumers and starts block i's own pass
+            if (i + 1) in starts or i in (3, 6, 9):
+                x_leaf = cut(x, self._pass_of_block(i) - 1)
+                hidden_states_out.append(x_leaf)
+                if (i + 1) in starts:
+                    x = x_leaf
             else:
                 hidden_states_out.append(x)
         x = Fn.LayerNormFn.apply(x, self.vit.norm.weight, self.vit.norm.bias,
@@ -388,22 +398,22 @@ class UNETR(nn.Module):
     # ---- staged backward: what lets the data-parallel all-reduce overlap with backward ---------------------------
     def forward_staged(self, x_in):
         """Same arithmetic as ``forward(x_in)`` (the values are bit-identical), but the autograd graph is cut so that
-        backward runs as FOUR consecutive passes whose parameter gradients are complete when each pass ends:
+        backward runs as FIVE consecutive passes whose parameter gradients are complete when each pass ends:
         0: loss -> conv side (encoder1-4, decoder5-2, out), 1: vit.norm + blocks 11..8, 2: blocks 7..4,
-        3: blocks 3..0 + patch embedding.  ``backward_staged`` drives them; between two passes the caller may start the
+        3: blocks 3..1, 4: block 0 + patch embedding (``backward_stage_starts``).  ``backward_staged`` drives them; between two passes the caller may start the
         all-reduce of the arena range that just became final (``stage_ranges``) on a side stream.
         Returns (enc4, logits, stages)."""
         prec = self._prec()
         Fn._require_gpu(x_in)
         Fn.begin_forward(getattr(self, "_arena_state", None))
-        stages = [[], [], []]
+        stages = [[] for _ in range(len(self.backward_stage_starts) + 1)]
         x, enc1, enc2, enc3, enc4 = self._encode(x_in, prec, stages)
         enc4_out, logits = self._decode(x_in, x, enc1, enc2, enc3, enc4, prec)
         return enc4_out, logits, stages
 
     @staticmethod
     def backward_staged(loss, stages, after_stage=None):
-        """``loss.backward()`` in four passes (see forward_staged); ``after_stage(k)`` runs after pass k, k = 0..3."""
+        """``loss.backward()`` in passes (see forward_staged); ``after_stage(k)`` runs after pass k, k = 0..len(stages)."""
         loss.backward()
         if after_stage is not None:
             after_stage(0)

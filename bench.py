@@ -153,6 +153,8 @@ def main():
     if dist_on:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
 
     pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
     from tools.synthetic import synthetic_volume
@@ -163,6 +165,8 @@ def main():
     else:
         out = run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume)
     out["rccl_world"] = dist.get_world_size() if dist_on else 1
+    if out["rccl_world"] != out["n_gpus"]:
+        raise SystemExit(f"bench.py: the JSON line would report n_gpus {out['n_gpus']} over an RCCL world of {out['rccl_world']}")
     names = [torch.cuda.get_device_name(dev)]
     if dist_on:
         gathered = [None] * world
@@ -216,8 +220,9 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
             flat["state"].reset_deferred()              # a failed capture may have left deferred weight-gradient work queued
         opt.zero_grad(set_to_none=True)
         step = pkg.TrainStep(model, crit, opt, x, y, use_graph=False, data_parallel=ddp_on, comm_dtype=comm_dtype)
-    first_loss = float(step.first_loss.item())
-    log(f"{step.launch}; first-step loss {first_loss:.5f}")
+    # (after a failed capture the weights have already stepped: this step's first loss is NOT the loss at the initial weights)
+    first_loss = float(step.first_loss.item()) if graph_err is None else None
+    log(f"{step.launch}; first-step loss {first_loss}")
     for _ in range(args.warmup):
         step.run()
 
@@ -344,7 +349,8 @@ def cpu_baseline(args, cfg, batch, gpu_first_loss):
     return {"value": round(batch * steps / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"{steps} fwd+DiceCE+bwd+AdamW steps of the same {size}^3 UNETR at batch {batch} (1 warm-up), torch fp32, "
                       f"{cores} threads",
-            "first_step_loss": l0, "first_step_loss_rel_diff_vs_gpu": abs(l0 - gpu_first_loss) / abs(l0)}
+            "first_step_loss": l0,
+            "first_step_loss_rel_diff_vs_gpu": None if gpu_first_loss is None else abs(l0 - gpu_first_loss) / abs(l0)}
 
 
 if __name__ == "__main__":

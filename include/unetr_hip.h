@@ -30,6 +30,10 @@
 extern "C" {
 #endif
 
+/* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
+ * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
+ * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
+#define UNETR_ABI_VERSION 3
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------

@@ -235,13 +235,14 @@ def test_stage_ranges_and_piece_plan():
         n += (p.numel() + 7) // 8 * 8
     m._flat = dict(param=torch.zeros(n), grad=torch.zeros(n), offsets=offs, params=params, total=n, shadow=None)
     r = m.stage_ranges()
-    assert r[0][1] == n and r[3][0] == 0 and [a[0] for a in r[:3]] == [b[1] for b in r[1:]]      # contiguous, reverse order
+    assert len(r) == 5 and r[0][1] == n and r[4][0] == 0 and [a[0] for a in r[:4]] == [b[1] for b in r[1:]]      # contiguous, reverse order
     names = [k for k, _ in m.named_parameters()]
     first_conv = offs[names.index("encoder1.layer.conv1.conv.weight")]
     assert r[0][0] == first_conv and r[1][0] == offs[names.index("vit.blocks.8.mlp.linear1.weight")]
     assert r[2][0] == offs[names.index("vit.blocks.4.mlp.linear1.weight")]
-    tail = ts.split_range(m._flat, *r[3], 3)
-    assert tail[0][0] == 0 and tail[-1][1] == r[3][1] and all(a[1] == b[0] for a, b in zip(tail, tail[1:])) and len(tail) == 3
+    assert r[3][0] == offs[names.index("vit.blocks.1.mlp.linear1.weight")]        # the last pass is block 0 + patch embedding only
+    tail = ts.split_range(m._flat, *r[4], 2)
+    assert tail[0][0] == 0 and tail[-1][1] == r[4][1] and all(a[1] == b[0] for a, b in zip(tail, tail[1:])) and len(tail) == 2
     assert all(lo in offs for lo, _ in tail)
     opt = pkg.AdamW(params, lr=1e-3, flat=m._flat)
     for i, p in enumerate(params):

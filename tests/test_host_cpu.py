@@ -18,6 +18,19 @@ def _header_symbols():
     return sorted(set(re.findall(r"\b(unetr_[a-z0-9_]+)\s*\(", txt)))
 
 
+def _header_abi_version():
+    txt = open(os.path.join(ROOT, "include", "unetr_hip.h")).read()
+    return int(re.search(r"#define\s+UNETR_ABI_VERSION\s+(\d+)", txt).group(1))
+
+
+def test_stale_library_is_refused(pkg, monkeypatch):
+    """a .so built against another header version (shifted arguments would otherwise reach raw-pointer kernels) is refused at load"""
+    monkeypatch.setattr(pkg._capi, "_lib", None)
+    monkeypatch.setattr(pkg._capi, "ABI_VERSION", pkg._capi.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="rebuild the extension"):
+        pkg._capi.load()
+
+
 def test_library_exports_every_declared_symbol(pkg):
     import ctypes
     lib = ctypes.CDLL(pkg._capi.LIB_PATH)
@@ -26,7 +39,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/unetr_hip.h but not exported"
     assert set(pkg._capi.EXPORTED_SYMBOLS) == set(syms), "ctypes signature table and header disagree"
-    assert pkg._capi.load().unetr_abi_version() == 1
+    assert pkg._capi.load().unetr_abi_version() == pkg._capi.ABI_VERSION == _header_abi_version()
 
 
 def test_no_cpu_fallback(pkg):

@@ -81,6 +81,23 @@ def test_c1_bf16_bounded(pkg, dev):
         assert c > 0.97, (k, c)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_c1_fourteen_classes(pkg, dev, precision):
+    """The reference's DEFAULT head -- n_classes = 14 (BTCV, unetr_segmentation_3d.py:303) -- forward + DiceCE + backward in both
+    precision modes: the out conv's weight gradient for more than 4 classes takes the generic kernel, on bf16-stored feature
+    maps in bf16 mode."""
+    outs, gr, gh = _run(pkg, dev, dict(C1, out_channels=14), 1, precision)
+    tol = 1e-3 if precision == "fp32" else 5e-2
+    for k, (a, b) in outs.items():
+        assert relerr(a, b) < tol, k
+    assert gh["out.conv.conv.weight"].grad.shape == (14, 16, 1, 1, 1)
+    for k in ("out.conv.conv.weight", "out.conv.conv.bias", "decoder2.conv_block.conv2.conv.weight", "vit.blocks.11.mlp.linear2.weight"):
+        if precision == "fp32":
+            assert relerr(gh[k].grad, gr[k].grad) < 5e-3, k
+        else:
+            assert cosine(gh[k].grad, gr[k].grad) > 0.97, k
+
+
 def test_freeze_encoder(pkg, dev):
     outs, gr, gh = _run(pkg, dev, C1, 1, "fp32", freeze=True)
     for k, (a, b) in outs.items():
@@ -547,73 +564,88 @@ def test_c2_bench_path_bf16_parity(pkg, dev):
     flat["state"].clear()
 
 
-def test_staged_backward_equals_single_pass(pkg, dev):
-    """The data-parallel launch form (forward_staged + 4 backward passes, per-pass reduce slots, AdamW per reduced piece,
-    4 hipGraphs) must give the SAME parameters as the single-graph step: same kernels, same order of every floating-point
-    sum (the only fan-out sums have two terms).  Run on one rank (the all-reduce of a 1-rank job is the identity)."""
+@pytest.mark.parametrize("size", ["c1", "c2"])
+def test_staged_backward_equals_single_pass(pkg, dev, size):
+    """The data-parallel launch form (forward_staged + 5 backward passes, per-pass reduce slots, AdamW per reduced piece,
+    5 hipGraphs) must give the SAME parameters as the single-graph step: same kernels, same order of every floating-point
+    sum (the only fan-out sums have two terms).  Run on one rank (the all-reduce of a 1-rank job is the identity).
+    size c2 = BASELINE configs[2]'s per-rank workload exactly (96^3, hidden 768, 4 classes, bf16, batch 2, fp32 gradient
+    communication): the launch form the 8-GPU bench runs, held bit for bit to the single-GPU step of configs[1]."""
     from oracle.unetr_oracle import synthetic_volume
-    x, y = synthetic_volume(2, 1, 32, 2, seed=41)
+    cfg, S, ncls, lr = (C2, 96, 4, 1e-4) if size == "c2" else (C1, 32, 2, 1e-3)
+    x, y = synthetic_volume(2, 1, S, ncls, seed=41)
     xd, yd = x.to(dev), y.to(dev)
     res = {}
-    for mode in ("single", "staged_eager", "staged_graph", "staged_bf16comm"):
+    modes = ("single", "staged_eager", "staged_graph", "staged_bf16comm") if size == "c1" else ("single", "staged_graph")
+    for mode in modes:
         torch.manual_seed(11)
-        m = pkg.UNETRLogits(**C1).to(dev)
+        m = pkg.UNETRLogits(**cfg).to(dev)
         m.precision = "bf16"
         flat = m.use_flat_buffers()
-        opt = pkg.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, flat=flat)
+        opt = pkg.AdamW(m.parameters(), lr=lr, weight_decay=1e-5, flat=flat)
         crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
         step = pkg.TrainStep(m, crit, opt, xd, yd, use_graph=mode != "staged_eager", data_parallel=mode != "single",
                              comm_dtype=torch.bfloat16 if mode == "staged_bf16comm" else torch.float32, warmup=1)
         if mode.startswith("staged"):
-            assert len(step.pieces) == 4 and len(step.pieces[3]) == 3
+            assert len(step.pieces) == 5 and len(step.pieces[4]) == 2
+            if size == "c2":        # the tail that cannot overlap with backward: block 0 + patch embedding, 41 MB of 370 MB
+                tail = sum(hi - lo for lo, hi in step.pieces[4]) * 4
+                assert tail < 45e6 and sum(hi - lo for st in step.pieces for lo, hi in st) * 4 > 365e6
             if mode != "staged_eager":
-                assert len(step.graphs) == 4
+                assert len(step.graphs) == 5
         for _ in range(3):
             step.run()
         torch.cuda.synchronize()
         res[mode] = (flat["param"].clone(), float(step.loss))
         flat["state"].clear()
-    assert torch.equal(res["single"][0], res["staged_eager"][0])
+        del step, opt, m, flat
+    if "staged_eager" in res:
+        assert torch.equal(res["single"][0], res["staged_eager"][0])
     assert torch.equal(res["single"][0], res["staged_graph"][0])
     assert res["single"][1] == res["staged_graph"][1]
-    assert relerr(res["staged_bf16comm"][0], res["single"][0]) < 1e-2       # bf16-rounded gradients: close, not equal
+    if "staged_bf16comm" in res:
+        assert relerr(res["staged_bf16comm"][0], res["single"][0]) < 1e-2       # bf16-rounded gradients: close, not equal
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph"])
-def test_two_rank_data_parallel_step(pkg, dev, tmp_path, mode):
+@pytest.mark.parametrize("mode,size", [("eager", "c1"), ("graph", "c1"), ("graph", "c2")])
+def test_two_rank_data_parallel_step(pkg, dev, tmp_path, mode, size):
     """The data-parallel TrainStep with a REAL 2-rank all-reduce, on one GPU: two processes (gloo carries the CUDA gradient
     pieces -- RCCL refuses two ranks on one device), each with its shard of a batch of 4, against one process stepping on the
     whole batch.  Both ranks must end with bit-identical parameters, and the averaged-gradient update must be the update of
-    the batch-4 step (DiceCE is a mean over batch items, InstanceNorm is per item: equal up to summation order)."""
+    the batch-4 step (DiceCE is a mean over batch items, InstanceNorm is per item: equal up to summation order).
+    size c2 = two ranks of BASELINE configs[2] at its own workload (96^3, hidden 768, bf16, batch 2 per rank, 5 captured passes)."""
     import socket
     import subprocess
     import sys
     from oracle.unetr_oracle import synthetic_volume
+    cfg, S, ncls, lr = (C2, 96, 4, 1e-4) if size == "c2" else (C1, 32, 2, 1e-3)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), str(tmp_path), mode], stdout=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), str(tmp_path), mode, size], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
     assert torch.equal(r0["param"], r1["param"])
     # the same job in one process: batch 4, single-graph step (warm-up steps count as steps: compare equal step counts)
-    x, y = synthetic_volume(4, 1, 32, 2, seed=77)
+    x, y = synthetic_volume(4, 1, S, ncls, seed=77)
     torch.manual_seed(11)
-    m = pkg.UNETRLogits(**C1).to(dev)
+    m = pkg.UNETRLogits(**cfg).to(dev)
     m.precision = "bf16"
     flat = m.use_flat_buffers()
     p0 = flat["param"].clone()
-    opt = pkg.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, flat=flat)
+    opt = pkg.AdamW(m.parameters(), lr=lr, weight_decay=1e-5, flat=flat)
     step = pkg.TrainStep(m, pkg.DiceCELoss(to_onehot_y=True, softmax=True), opt, x.to(dev), y.to(dev), use_graph=False, warmup=1)
     while step.eager_steps < r0["steps"] + (2 if mode == "graph" else 0):
         step.run()
     torch.cuda.synchronize()
     upd_dp, upd_1 = r0["param"].to(dev) - p0, flat["param"] - p0
     cos = torch.nn.functional.cosine_similarity(upd_dp.double(), upd_1.double(), dim=0)
-    assert cos > 0.98, float(cos)
+    # (Adam's first steps are ~ lr * sign(g): at 92 M parameters many gradients sit near zero, where bf16 rounding of a different
+    # batch split flips signs -- the full-size bound is looser than the 32^3 one)
+    assert cos > (0.98 if size == "c1" else 0.90), float(cos)
     assert relerr(r0["param"].to(dev), flat["param"]) < 5e-3
     flat["state"].clear()
 

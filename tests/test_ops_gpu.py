@@ -353,9 +353,12 @@ def test_instnorm(pkg, dev, prec, B, S, C):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-def test_outconv_and_layout(pkg, dev, prec):
+@pytest.mark.parametrize("cin,cout", [(16, 4), (16, 14), (32, 3), (16, 2)])
+def test_outconv_and_layout(pkg, dev, prec, cin, cout):
+    """UnetOutBlock forward + backward; (16, 14) is the reference's default head (14 BTCV classes,
+    unetr_segmentation_3d.py:303): its weight gradient takes the generic kernel on fp32- and bf16-stored feature maps"""
     Fn = pkg.functional
-    B, S, cin, cout = 2, 10, 16, 4
+    B, S = 2, 10
     x, w, b, dl = rq(g(B, cin, S, S, S, seed=1), prec), g(cout, cin, 1, 1, 1, seed=2), g(cout, seed=3), g(B, cout, S, S, S, seed=4)
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yr = F.conv3d(xr, wr, br)

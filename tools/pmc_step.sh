@@ -4,7 +4,9 @@
 #   hbm read = FETCH_SIZE x 1024 x 2 (gfx950 reports half the bytes of wide coalesced streams), write = WRITE_SIZE x 1024.
 # Usage (on the GPU box, from the repo root):  bash tools/pmc_step.sh
 set -e
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+[ -f bench.py ] || { echo "pmc_step.sh: bench.py not found in $ROOT" >&2; exit 1; }
 OUT=gpurun_out/pmc_step
 rm -rf $OUT && mkdir -p $OUT
 CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
