@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
-ABI_VERSION = 3        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 4        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -108,7 +108,9 @@ _SIGNATURES = {
     "unetr_instnorm_bwd": [P, c_long, P, c_long, P, P, c_long, P, P, c_long, P, c_long, c_int, c_long, c_int, c_int, P, c_size_t, c_int, P],
     "unetr_nchw_to_nhwc": [P, P, c_long, c_int, c_int, c_long, c_int, P],
     "unetr_nhwc_to_nchw": [P, c_long, P, c_int, c_int, c_long, c_int, c_int, P],
-    "unetr_patch_gather": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_patch_gather": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_counter_add": [P, P, c_int, P],
+    "unetr_add_cast_bf16": [P, P, P, P, c_long, P],
     "unetr_copy_rows": [P, c_long, P, c_long, c_long, c_int, c_int, c_int, P],
     "unetr_outconv_fwd": [P, c_long, P, P, P, c_int, c_long, c_int, c_int, c_int, P],
     "unetr_outconv_bwd": [P, P, c_long, P, P, c_long, P, P, c_int, c_long, c_int, c_int, P, c_size_t, c_int, P],

@@ -260,6 +260,240 @@ int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t
     return unetr_check_launch();
 }
 
+// ---- the large-tile form (M >= 1024 rows: batch >= 8 at 96^3, 160^3 at batch >= 2) -------------------------------------------
+// 256 x 256 output tile, 64-deep K tiles, 8 waves as 2 (M) x 4 (N): a wave owns 128 x 64 = 8 x 4 MFMA tiles (128 accumulator
+// registers).  LDS = two K-tile buffers of 64 KB, each four half-tiles of 128 rows x 128 B (A rows 0-127 / 128-255, B rows
+// likewise) in the swizzled image of the kernel above, filled by LDS-DMA.
+//
+// Schedule ("ping-pong"): the waves of M-half 0 (group 0: waves 0-3) and of M-half 1 (group 1: waves 4-7) share the four SIMDs
+// pairwise and run ONE barrier interval apart: while a group issues the 32 MFMAs of a 64 x 64 half of its tile (512 matrix
+// pipe cycles), its SIMD partners read the fragments of their next half out of LDS and issue their share of the DMA -- the
+// matrix pipe of every SIMD always has one wave in an MFMA segment.  Per K tile T a wave runs two phases, each
+// {mem: ds_reads, two half-tiles of DMA, lgkmcnt(0), s_barrier} {compute: 32 MFMAs, s_barrier}:
+//     P0: all 64 B columns (8 reads) + A rows 0-63 of its half (8 reads) -> rows 0-63;    DMA: both A halves of tile T+1
+//     P1: A rows 64-127 (8 reads)                                        -> rows 64-127;  DMA: both B halves of tile T+2
+// Intervals (one per barrier): group 0 runs mem(p) in interval 2p and compute(p) in 2p+1, group 1 one later (4 intervals per K
+// tile; a four-phase variant with 16-MFMA quadrants -- twice the barriers -- measured 2-4 % slower).
+// Why the DMA targets are free (write-after-read): B of buffer T%2 is last read in P0 of tile T (group 1: interval 4T+1, retired
+// by its lgkmcnt(0) before that interval's barrier) and B of tile T+2 is issued from interval 4T+2 on; A half 0 (read by group 0
+// only) is last read in interval 4(T-1)+2 and rewritten from 4T on, A half 1 (group 1) in 4(T-1)+3 / 4T.
+// Why the reads see the data (read-after-write): at the end of P1's mem segment of tile T every wave waits until all its DMA
+// older than the two B halves of tile T+2 has landed -- vmcnt(4): everything tile T+1 needs -- and the barrier that follows
+// (interval 4T+3 ends) precedes the first read of tile T+1 (interval 4T+4).  Nothing in the loop drains to vmcnt(0) except the
+// last two K tiles.
+// Measured (MI355X, 6912 rows): steady state 1.72 us per K tile of 243 workgroups = 1.25 PFLOP/s (MFMA + DMA alone: 1.28 us --
+// the matrix pipe at the clock the chip holds under this load); [6912 x 2304 x 768] bf16 out 30-32 us = 0.8 PFLOP/s, of which
+// ~10 us is the 32 MB output burst of 243 workgroups finishing together (HBM write rate, whatever the store shape).
+template <int BUF>
+struct BufC { static constexpr int value = BUF; };
+
+__global__ void __launch_bounds__(512, 2)
+gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
+                     const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep) {
+    constexpr int NT = 512, HALF = 128 * 128, BUFB = 4 * HALF;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUFB];
+
+    // tile order: workgroup L runs on XCD L % 8; an XCD gets a contiguous run of tiles, fastest along the operand whose re-use
+    // saves more traffic (n_fast: the run shares A rows and walks the weight columns; else the other way round)
+    int tm, tn;
+    {
+        const int T = mt * nt, per = (T + 7) >> 3, L = blockIdx.x;
+        const int t = (L & 7) * per + (L >> 3);
+        if ((L >> 3) >= per || t >= T) return;
+        if (n_fast) { tn = t % nt; tm = t / nt; } else { tm = t % mt; tn = t / mt; }
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = K / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
+
+    // DMA sources: piece i (0, 1) of half-tile h covers rows (tid + i * 512) >> 3 of the half, chunk (id & 7) ^ ((r >> 1) & 7)
+    const uint16_t* asrc[2][2];
+    const uint16_t* bsrc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * NT, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
+            asrc[h][i] = A + (long)min(m0 + h * 128 + r, M - 1) * lda + c * 8;
+            bsrc[h][i] = B + (long)min(n0 + h * 128 + r, N - 1) * ldb + c * 8;
+        }
+    auto dma = [&](const uint16_t* const (&src)[2], int T, char* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + (long)T * 64), (lds_void_t*)(dst + (wave * 64 + i * NT) * 16), 16, 0, 0);
+    };
+    // fragment read offsets inside a half-tile: row (tile * 16 + lane & 15), 16-byte chunk kh * 4 + (lane >> 4), swizzled; the
+    // swizzle term does not depend on the tile index, so a tile is a constant 2048-byte step
+    int off[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) off[kh] = lds_tile_off(lane & 15, kh * 4 + (lane >> 4));
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 af[4][2], bf[4][2];
+    // prologue: tile 0 whole, B of tile 1; tile 0 must have landed (and be published by the barrier) before the first read
+    dma(asrc[0], 0, lds);
+    dma(asrc[1], 0, lds + HALF);
+    dma(bsrc[0], 0, lds + 2 * HALF);
+    dma(bsrc[1], 0, lds + 3 * HALF);
+    if (nk > 1) {
+        dma(bsrc[0], 1, lds + BUFB + 2 * HALF);
+        dma(bsrc[1], 1, lds + BUFB + 3 * HALF);
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");        // group 1 runs one interval behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+#define BIG_MEM_END() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BIG_CMP_END(last_) do { __builtin_amdgcn_sched_barrier(0); if (!(last_)) asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BIG_QUAD(qa_, qb_) do {                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
+                    PrecBF16::mma(acc[(qa_) * 4 + i][(qb_) * 2 + j], bf[(qb_) * 2 + j][kh], af[i][kh]); \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+    } while (0)
+
+    auto ktile = [&](int T, auto bufc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bufc)::value;
+        char* const cur = lds + b * BUFB;
+        char* const oth = lds + (b ^ 1) * BUFB;
+        const char* la = cur + wr * HALF;                                    // this wave's 128 A rows
+        const char* lb = cur + (2 + (wc >> 1)) * HALF + (wc & 1) * 64 * 128;   // this wave's 64 B rows
+        const bool n1 = T + 1 < nk, n2 = T + 2 < nk;
+        {
+            // two phases of 32 MFMAs (half the barriers): P0 reads all of B and A rows 0-63 and issues both A halves of tile T+1,
+            // P1 reads A rows 64-127 and issues both B halves of tile T+2 (B of buffer T%2 was last read in P0 of this tile)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j][kh] = *(const u32x4*)(lb + off[kh] + j * 2048);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i][kh] = *(const u32x4*)(la + off[kh] + i * 2048);
+            }
+            if (n1) { dma(asrc[0], T + 1, oth); dma(asrc[1], T + 1, oth + HALF); }
+            BIG_MEM_END();
+            BIG_QUAD(0, 0);
+            BIG_QUAD(0, 1);
+            BIG_CMP_END(false);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i][kh] = *(const u32x4*)(la + off[kh] + (4 + i) * 2048);
+            }
+            if (n2) {
+                dma(bsrc[0], T + 2, cur + 2 * HALF);
+                dma(bsrc[1], T + 2, cur + 3 * HALF);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if (n1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            BIG_MEM_END();
+            BIG_QUAD(1, 0);
+            BIG_QUAD(1, 1);
+            BIG_CMP_END(!n1 && wr == 1);        // group 1 skips its very last barrier: both groups execute the same number
+        }
+    };
+    for (int T = 0; T < nk; T += 2) {
+        ktile(T, BufC<0>{});
+        if (T + 1 < nk) ktile(T + 1, BufC<1>{});
+    }
+#undef BIG_MEM_END
+#undef BIG_CMP_END
+#undef BIG_QUAD
+
+    // accumulator tile = C^T (swapped MFMA operands): lane (c, g) holds C[m = tile row c][n = 4g .. 4g+3].  The epilogue kind is
+    // chosen ONCE (a 32-tile loop over the general store4 is too large to unroll: the accumulators would go through scratch)
+    const int mb = m0 + wr * 128 + (lane & 15), nb = n0 + wc * 64 + 4 * (lane >> 4);
+    if (!ep.vec_ok) {
+        for (int t = 0; t < 32; ++t) {
+            const int i = t >> 2, j = t & 3, m = mb + i * 16, n = nb + j * 16;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(full)
+            for (int ii = 0; ii < 8; ++ii)
+#pragma clang loop unroll(full)
+                for (int jj = 0; jj < 4; ++jj) v = (ii == i && jj == j) ? acc[ii][jj] : v;
+            if (m < M)
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) ep.store(0, m, n + r, v[r]);
+        }
+        return;
+    }
+    // Row-coalesced epilogue through LDS.  In the accumulator layout a store instruction covers 16 rows x 64 B (32 B for bf16):
+    // partial lines, 32 instructions per wave -- measured 11.6 us of a 32.7 us launch at [6912 x 2304] bf16 out.  Instead each wave
+    // stages 64 rows x 64 columns of alpha * acc + bias (fp32) in its OWN 16 KB of the (now idle) K-tile buffers -- no workgroup
+    // barrier: nobody reads the buffers any more (group 1's last fragment reads were retired before the barrier group 0 passed
+    // last) and every DMA has landed (vmcnt(0) of the last K tile but one) -- and reads it back as whole rows: lane (l >> 4,
+    // l & 15) owns 16 bytes of row 4 * it + (l >> 4), so pre / aux / residual / C are 256-byte and Cb 128-byte row segments.
+    // Image: 256-byte rows, 16-byte chunk c of row r at slot c ^ (r & 7) (conflict-free ds_write_b128 of the accumulator layout).
+    const int kind = (ep.act == 1 ? 1 : ep.act == 2 ? 2 : 0);
+    char* const stg = lds + wave * 16384;
+    const int rr = lane >> 4, rc = lane & 15;                 // read-back: row within a group of 4, 16-byte chunk
+    const int ncol = n0 + wc * 64 + rc * 4;
+    f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ep.bias && ncol < N) bias4 = *(const f32x4*)(ep.bias + ncol);
+    auto half = [&](auto kc, auto hc) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kc)::value, h = decltype(hc)::value;
+#pragma clang loop unroll(full)
+        for (int i = 0; i < 4; ++i)
+#pragma clang loop unroll(full)
+            for (int j = 0; j < 4; ++j) {
+                const int r = i * 16 + (lane & 15), ch = j * 4 + (lane >> 4);
+                *(f32x4*)(stg + r * 256 + ((ch ^ (r & 7)) << 4)) = acc[h * 4 + i][j] * ep.alpha;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma clang loop unroll(full)
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + rr, m = m0 + wr * 128 + h * 64 + r;
+            f32x4 v = *(const f32x4*)(stg + r * 256 + ((rc ^ (r & 7)) << 4)) + bias4;
+            if (m < M && ncol < N) {
+                if (ep.pre) *(f32x4*)(ep.pre + (long)m * ep.ldc + ncol) = v;
+                if constexpr (KIND == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+                } else if constexpr (KIND == 2) {
+                    const f32x4 a = *(const f32x4*)(ep.aux + (long)m * ep.ldaux + ncol);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(a[e]);
+                }
+                if (ep.res) v += *(const f32x4*)(ep.res + (long)(m % ep.res_mod) * ep.ldr + ncol);
+                if (ep.C) {
+                    if (ep.accumulate) v += *(const f32x4*)(ep.C + (long)m * ep.ldc + ncol);
+                    *(f32x4*)(ep.C + (long)m * ep.ldc + ncol) = v;
+                }
+                if (ep.Cb) *(bf16x4*)(ep.Cb + (long)m * ep.ldcb + ncol) = __builtin_convertvector(v, bf16x4);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the second half overwrites the staging image)
+    };
+    if (kind == 1) { half(BufC<1>{}, BufC<0>{}); half(BufC<1>{}, BufC<1>{}); }
+    else if (kind == 2) { half(BufC<2>{}, BufC<0>{}); half(BufC<2>{}, BufC<1>{}); }
+    else { half(BufC<0>{}, BufC<0>{}); half(BufC<0>{}, BufC<1>{}); }
+}
+
+static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep, hipStream_t st) {
+    const int mt = cdiv(M, 256), nt = cdiv(N, 256);
+    const long tiles = (long)mt * nt;
+    // traffic of the two tile orders, in rows of K elements fetched per XCD pass: m fastest re-reads A for every weight column
+    // tile an XCD touches (up to 8 XCDs share the grid), n fastest re-reads the weights
+    const long cost_m = (long)M * std::min(8, nt) + N, cost_n = M + (long)N * std::min(8, mt);
+    const int n_fast = cost_n < cost_m;
+    const int per = cdiv(tiles, 8);
+    hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3(per * 8), dim3(512), 0, st, M, N, K, mt, nt, n_fast, A, lda, B, ldb, ep);
+    return unetr_check_launch();
+}
+
 // ---- grouped weight-gradient GEMM on bf16-stored operands: dW_i[N_i, K_i] = dY_i[M, N_i]^T * X_i[M, K_i] ------------------
 // Both operands are reduction-major ([token][feature]), i.e. the b_kn layout on BOTH sides: a stage is 64 tokens x 128
 // features of dY and of X, staged by LDS-DMA into two swizzled images (bkn_x<16>), and all MFMA fragments (k = token) come
@@ -372,6 +606,18 @@ __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict_
     }
 }
 
+// out[i] = a[i] + b[i] (fp32) and its bf16 copy: the gradient of a hidden state with two consumers (the next transformer
+// block and a skip-path transposed conv, unetr.py:197-201) as ONE launch -- autograd's own sum was an elementwise add kernel
+// followed by a cast kernel for the bf16 operand of the block's backward GEMMs
+__global__ void __launch_bounds__(256) add_cast_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                            uint16_t* __restrict__ out16, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+        ((f32x4*)out)[i] = v;
+        if (out16) ((bf16x4*)out16)[i] = __builtin_convertvector(v, bf16x4);
+    }
+}
+
 __global__ void __launch_bounds__(256) cast_bf16_tail_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long beg, long n) {
     const long i = beg + blockIdx.x * 256L + threadIdx.x;
     if (i < n) { __bf16 h = (__bf16)src[i]; dst[i] = __builtin_bit_cast(uint16_t, h); }
@@ -401,6 +647,10 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
     const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hooks
     const int env_ns = getenv("UNETR_GEMM_STAGES") ? atoi(getenv("UNETR_GEMM_STAGES")) : 0;
     const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
+    // the 256 x 256 ping-pong kernel: many rows, weights as stored ([N, K]); K tiles of 64 (checked above).  Narrow outputs
+    // (N = 768 at 6912 rows: 81 tiles for 256 CUs) keep the 128 x 128 tile, which fills the chip
+    if (!d->b_kn && (env_cfg == 256 || (env_cfg == 0 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 256) >= 160)))
+        return launch_bf16_big(M, N, K, a, d->lda, b, d->ldb, ep, st);
 #define BF16_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st, psp)
     // Small token counts (batch 2: M = 432).  Measured per launch on MI355X (tools/probe_encoder.py, us incl. launch boundary):
     //   forward, K = 768:   N = 768: 64x32 5.6 < 32x64 5.7 < 64x64 7.1;  N = 2304: 64x64 6.6 < 64x96 7.5 < 64x128 9.1;
@@ -483,6 +733,14 @@ extern "C" int unetr_cast_bf16(const float* src, void* dst, long n, void* stream
     const long n8 = al ? n / 8 : 0;
     if (n8) hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(n8, 256), 4096)), dim3(256), 0, st, src, (uint16_t*)dst, n8);
     if (n8 * 8 < n) hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3(cdiv(n - n8 * 8, 256)), dim3(256), 0, st, src, (uint16_t*)dst, n8 * 8, n);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_add_cast_bf16(const float* a, const float* b, float* out, void* out_bf16, long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return UNETR_ERR_ARG;
+    if ((n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) || ((uintptr_t)out_bf16 & 7)) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(add_cast_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(n / 4, 256), 2048)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                       (uint16_t*)out_bf16, n / 4);
     return unetr_check_launch();
 }
 

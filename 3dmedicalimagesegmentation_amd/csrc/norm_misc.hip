@@ -596,7 +596,8 @@ transpose_kernel(const TS* __restrict__ src, long ld_s, long bs_s, TD* __restric
     }
 }
 
-__global__ void patch_gather_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int D, int H, int W, int P) {
+// out (fp32) and / or out16 (bf16: the GEMM operand of the bf16-storage path -- no fp32 patches + cast pass in between)
+__global__ void patch_gather_kernel(const float* __restrict__ x, float* __restrict__ out, uint16_t* __restrict__ out16, int B, int C, int D, int H, int W, int P) {
     const int gd = D / P, gh = H / P, gw = W / P;
     const long pd = (long)P * P * P * C;
     const long total = (long)B * gd * gh * gw * pd;
@@ -604,8 +605,17 @@ __global__ void patch_gather_kernel(const float* __restrict__ x, float* __restri
         long f = i % pd; long tok = i / pd;
         int c = (int)(f % C); long t = f / C; int p3 = (int)(t % P); t /= P; int p2 = (int)(t % P); int p1 = (int)(t / P);
         int w3 = (int)(tok % gw); t = tok / gw; int w2 = (int)(t % gh); t /= gh; int w1 = (int)(t % gd); int b = (int)(t / gd);
-        out[i] = x[((((long)b * C + c) * D + w1 * P + p1) * H + w2 * P + p2) * W + w3 * P + p3];
+        const float v = x[((((long)b * C + c) * D + w1 * P + p1) * H + w2 * P + p2) * W + w3 * P + p3];
+        if (out) out[i] = v;
+        if (out16) { __bf16 h = (__bf16)v; out16[i] = __builtin_bit_cast(uint16_t, h); }
     }
+}
+
+// y[i] += inc[i] (i < n): the per-parameter AdamW step counters advanced by the 0/1 "has a gradient" mask (one tiny launch
+// that is part of the captured step; a torch elementwise add did this before)
+__global__ void counter_add_kernel(float* __restrict__ y, const float* __restrict__ inc, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += inc[i];
 }
 
 template <class T>
@@ -1142,10 +1152,16 @@ extern "C" int unetr_nhwc_to_nchw(const void* x, long ldx, float* y, int B, int 
     return unetr_check_launch();
 }
 
-extern "C" int unetr_patch_gather(const float* x, float* patches, int B, int C, int D, int H, int W, int P, void* stream) {
-    if (!x || !patches || P <= 0 || D % P || H % P || W % P) return UNETR_ERR_ARG;
+extern "C" int unetr_patch_gather(const float* x, float* patches, void* patches_bf16, int B, int C, int D, int H, int W, int P, void* stream) {
+    if (!x || (!patches && !patches_bf16) || P <= 0 || D % P || H % P || W % P) return UNETR_ERR_ARG;
     long total = (long)B * C * D * H * W;
-    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, B, C, D, H, W, P);
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, (uint16_t*)patches_bf16, B, C, D, H, W, P);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_counter_add(float* y, const float* inc, int n, void* stream) {
+    if (!y || !inc || n <= 0) return UNETR_ERR_ARG;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, y, inc, n);
     return unetr_check_launch();
 }
 

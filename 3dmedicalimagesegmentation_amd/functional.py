@@ -477,13 +477,59 @@ def _twin(t):
     if t.dtype == torch.bfloat16:
         return t
     tw = getattr(t, "_unetr_bf16", None)
-    if tw is not None and tw[0].shape == t.shape and tw[1] == t._version:   # autograd may accumulate into t in place
-        return tw[0]
+    if tw is not None and tw[0].numel() == t.numel() and tw[1] == t._version and t.is_contiguous():   # autograd may accumulate into t in place
+        return tw[0].view(t.shape)
     return cast_bf16(t)
 
 
 def _attach_twin(t, tb):
     t._unetr_bf16 = (tb, t._version)
+
+
+def carry_twin(src, dst):
+    """dst is the same values as src under another tensor object (a detached leaf, an alias returned by a Function): the bf16
+    twin and the stashed LayerNorm of src describe dst too"""
+    tw = getattr(src, "_unetr_bf16", None)
+    if tw is not None and tw[1] == src._version:
+        dst._unetr_bf16 = (tw[0], dst._version)
+    if hasattr(src, "_unetr_ln"):
+        dst._unetr_ln = src._unetr_ln
+    return dst
+
+
+def add_cast(a, b, want_bf16=True):
+    """a + b (fp32) and its bf16 twin in one launch (csrc: add_cast_bf16_kernel)"""
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    ok16 = want_bf16 and a.numel() % 4 == 0
+    ob = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if ok16 else None
+    if a.numel() % 4 or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise RuntimeError("add_cast needs fp32 tensors with a multiple of 4 elements")
+    call("unetr_add_cast_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(ob), a.numel(), _stream())
+    if ob is not None:
+        _attach_twin(out, ob)
+    return out
+
+
+class TapFn(torch.autograd.Function):
+    """A hidden state with TWO consumers (unetr.py:197-201: z3 / z6 / z9 feed the next transformer block and encoder2-4):
+    forward hands out two aliases, backward sums the two gradients AND forms the bf16 operand of the producing block's backward
+    GEMMs in one HIP launch -- autograd's own fan-in was an elementwise add kernel, and the twin-less sum then cost a cast."""
+
+    @staticmethod
+    def forward(ctx, x, want_bf16):
+        ctx.want_bf16 = bool(want_bf16)
+        a, b = x.view_as(x), x.view_as(x)
+        carry_twin(x, a)
+        carry_twin(x, b)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return (ga if gb is None else gb), None
+        _require_gpu(ga)
+        return add_cast(ga, gb, ctx.want_bf16), None
 
 
 def linear_fwd(x, w, bias, prec, res=None, res_mod=0, act=0, pre=None):
@@ -942,14 +988,17 @@ class PatchEmbedFn(torch.autograd.Function):
         L = (D // patch) * (H // patch) * (W // patch)
         pd = C * patch ** 3
         hid = w.shape[0]
-        patches = torch.empty(B * L, pd, dtype=torch.float32, device=x_in.device)
-        call("unetr_patch_gather", x_in.data_ptr(), patches.data_ptr(), B, C, D, H, W, patch, _stream())
         ctx.pb = None
         if _bf16_path(prec, pd):
+            # the bf16 GEMM operand straight from the gather kernel (no fp32 patch matrix, no cast pass)
             z = torch.empty(B * L, hid, dtype=torch.float32, device=x_in.device)
-            ctx.pb = cast_bf16(patches)
+            ctx.pb = torch.empty(B * L, pd, dtype=torch.bfloat16, device=x_in.device)
+            patches = x_in.new_empty(0)
+            call("unetr_patch_gather", x_in.data_ptr(), None, ctx.pb.data_ptr(), B, C, D, H, W, patch, _stream())
             gemm_bf16(ctx.pb, weight_bf16(w), B * L, hid, pd, C=z, bias=b, res=pos, ldr=hid, res_mod=L)
         else:
+            patches = torch.empty(B * L, pd, dtype=torch.float32, device=x_in.device)
+            call("unetr_patch_gather", x_in.data_ptr(), patches.data_ptr(), None, B, C, D, H, W, patch, _stream())
             z = linear_fwd(patches, w, b, prec, res=pos, res_mod=L)
         ctx.save_for_backward(patches, w, b, pos)
         ctx.meta = (B, L, hid, prec)
@@ -966,7 +1015,7 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, dw, db, dpos, None, None
 
 
-def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, train, next_ln=None):
+def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, train, next_ln=None, emit_twin=False):
     """kernels of one transformer block; returns (x2, tensors backward needs, bf16 twins or None).  next_ln = (gamma, beta) of
     the LayerNorm the next layer starts with: computed by the kernel that forms x2 and left on x2 (_stash_ln)"""
     hid = x.shape[1]
@@ -1020,7 +1069,12 @@ def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, h
             mn, rn = gemm_bf16_ln_fwd(ab, weight_bf16(w2), M, hid, mlp, x2, next_ln[0], next_ln[1], xn, bias=b2, res=x1, ldr=hid)
             _stash_ln(x2, next_ln[0], next_ln[1], xn, mn, rn)
         else:
-            gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, bias=b2, res=x1, ldr=hid)
+            # emit_twin: this block's output also feeds a skip-path transposed conv that reads bf16 tokens (its GEMM form):
+            # the epilogue writes the bf16 copy next to the fp32 residual stream (was a separate cast launch)
+            x2b = bf16_like(x) if emit_twin else None
+            gemm_bf16(ab, weight_bf16(w2), M, hid, mlp, C=x2, Cb=x2b, bias=b2, res=x1, ldr=hid)
+            if x2b is not None:
+                _attach_twin(x2, x2b)
         twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs
     else:
         twins = None
@@ -1040,7 +1094,8 @@ class TransformerBlockFn(torch.autograd.Function):
     (BASELINE.json config[3]): only the block input is kept and backward recomputes the block's forward kernels first."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, ckpt=False, next_n1w=None, next_n1b=None):
+    def forward(ctx, x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec, ckpt=False, next_n1w=None, next_n1b=None,
+                emit_twin=False):
         """next_n1w / next_n1b: weight and bias of the LayerNorm the NEXT block starts with (not differentiated here: that block
         owns its backward) -- its forward is formed by this block's last kernel"""
         _require_gpu(x)
@@ -1050,7 +1105,7 @@ class TransformerBlockFn(torch.autograd.Function):
         x = xc
         train = any(ctx.needs_input_grad[:12])
         x2, acts, twins = _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, heads, prec,
-                                          train and not ckpt, None if next_n1w is None else (next_n1w, next_n1b))
+                                          train and not ckpt, None if next_n1w is None else (next_n1w, next_n1b), bool(emit_twin))
         ctx.ckpt = bool(ckpt) and train
         if ctx.ckpt:
             acts, twins = (), None
@@ -1122,7 +1177,7 @@ class TransformerBlockFn(torch.autograd.Function):
             dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         if fast:
             _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
-        return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None, None, None, None)
+        return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None, None, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -1130,7 +1185,10 @@ class LayerNormFn(torch.autograd.Function):
     def forward(ctx, x, w, b, twin=False):
         _require_gpu(x)
         x = x.contiguous()
-        y, mean, rstd = layernorm_fwd(x, w, b)
+        yb = bf16_like(x) if twin else None       # (twin: decoder5's transposed conv reads bf16 tokens in its GEMM form)
+        y, mean, rstd = layernorm_fwd(x, w, b, bf16_out=yb)
+        if yb is not None:
+            _attach_twin(y, yb)
         ctx.save_for_backward(x, w, mean, rstd, b)
         ctx.twin = bool(twin)
         return y
@@ -1383,7 +1441,9 @@ class DiceCEFn(torch.autograd.Function):
     (unetr_segmentation_3d.py:404); multilabel=True: DiceCELoss(to_onehot_y=False, sigmoid=True) (:477-482)."""
 
     @staticmethod
-    def forward(ctx, logits, label, smooth_nr, smooth_dr, multilabel=False):
+    def forward(ctx, logits, label, smooth_nr, smooth_dr, multilabel=False, scalar=False):
+        """scalar=True: returns the 0-dim loss itself (what DiceCELoss.forward hands to backward()): selecting element 0 of the
+        3-vector through autograd cost a fill, a zero and a copy launch in every backward pass"""
         _require_gpu(logits)
         logits = logits.contiguous()
         label = label.contiguous().to(torch.float32)
@@ -1400,15 +1460,17 @@ class DiceCEFn(torch.autograd.Function):
              coef.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
         ctx.save_for_backward(logits, label, coef)
         ctx.meta = (B, C, V, int(multilabel))
-        return out
+        ctx.scalar = bool(scalar)
+        return out[0] if scalar else out
 
     @staticmethod
     def backward(ctx, dout):
         logits, label, coef = ctx.saved_tensors
         B, C, V, ml = ctx.meta
         # only out[0] (= dice + ce) is differentiable; out[1], out[2] are reporting copies
-        dloss = dout[0:1].contiguous()
+        dloss = dout.reshape(1) if ctx.scalar else dout[0:1]
+        dloss = dloss.contiguous()
         dlogits = torch.empty_like(logits)
         call("unetr_dicece_bwd", logits.data_ptr(), label.data_ptr(), coef.data_ptr(), dloss.data_ptr(), dlogits.data_ptr(), B, C, V,
              ml, _stream())
-        return dlogits, None, None, None, None
+        return dlogits, None, None, None, None, None

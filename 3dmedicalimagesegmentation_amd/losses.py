@@ -32,15 +32,19 @@ class DiceCELoss(nn.Module):
 
     def terms(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """3-vector (loss, dice term, ce term); only element 0 carries gradient."""
+        self._check(input, target)
+        return Fn.DiceCEFn.apply(input, target, self.smooth_nr, self.smooth_dr, self.multilabel)
+
+    def _check(self, input, target):
         if self.multilabel:
             if target.shape != input.shape:
                 raise ValueError("sigmoid=True needs a multi-label target shaped like the logits [B,C,*spatial]")
         elif target.shape[1] != 1:
             raise ValueError("target must be [B,1,*spatial] class indices (to_onehot_y=True)")
-        return Fn.DiceCEFn.apply(input, target, self.smooth_nr, self.smooth_dr, self.multilabel)
 
     def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        return self.terms(input, target)[0]
+        self._check(input, target)
+        return Fn.DiceCEFn.apply(input, target, self.smooth_nr, self.smooth_dr, self.multilabel, True)
 
 
 class _RankingLossFn(torch.autograd.Function):

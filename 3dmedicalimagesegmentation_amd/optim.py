@@ -37,7 +37,7 @@ class AdamW(torch.optim.Optimizer):
         if mask is None:
             mask = torch.tensor([1.0 if f else 0.0 for f in pattern], dtype=torch.float32, device=dev)
             self._masks[(gi, pattern)] = mask
-        steps += mask
+        call("unetr_counter_add", steps.data_ptr(), mask.data_ptr(), steps.numel(), torch.cuda.current_stream().cuda_stream)
         return steps
 
     @torch.no_grad()

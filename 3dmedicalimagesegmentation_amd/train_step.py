@@ -65,6 +65,7 @@ class TrainStep:
         self.comm_dtype = comm_dtype
         self.in_place = comm_dtype == torch.float32
         self.loss = None
+        self._one = torch.ones((), dtype=torch.float32, device=x.device)
         self.graphs = None
         self.stages = None
         self.eager_steps = 0
@@ -99,9 +100,15 @@ class TrainStep:
         logits = out[1] if isinstance(out, tuple) else out
         return self.crit(logits, self.y)
 
+    def _backward(self):
+        # (the seed gradient is a persistent device scalar: loss.backward() alone launches a fill for it every step)
+        if self._one is None or self._one.device != self.loss.device:
+            self._one = torch.ones((), dtype=self.loss.dtype, device=self.loss.device)
+        self.loss.backward(self._one)
+
     def _single_step(self):
         self.loss = self._fwd_loss()
-        self.loss.backward()
+        self._backward()
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
 
@@ -109,7 +116,7 @@ class TrainStep:
     def _pass0(self):
         _, logits, self.stages = self.model.forward_staged(self.x)
         self.loss = self.crit(logits, self.y)
-        self.loss.backward()
+        self._backward()
 
     def _pass(self, k):
         st = self.stages[k - 1]

@@ -309,7 +309,7 @@ class UNETR(nn.Module):
 
     def _tokens_cl(self, tok, B):
         g = self.feat_size
-        return tok.view(B, g[0], g[1], g[2], self.hidden_size)
+        return Fn.carry_twin(tok, tok.view(B, g[0], g[1], g[2], self.hidden_size))
 
     def _res_w(self, blk):
         return blk.conv1.conv.weight, blk.conv2.conv.weight, blk.conv3.conv.weight
@@ -329,9 +329,7 @@ class UNETR(nn.Module):
         def cut(t, k):
             if stages is None:
                 return t
-            leaf = t.detach().requires_grad_(True)
-            if hasattr(t, "_unetr_ln"):
-                leaf._unetr_ln = t._unetr_ln       # (the next block's LayerNorm formed by the kernel that produced t)
+            leaf = Fn.carry_twin(t, t.detach().requires_grad_(True))   # (bf16 twin / stashed LayerNorm formed by t's producer)
             stages[k].append((t, leaf))
             return leaf
 
@@ -340,21 +338,27 @@ class UNETR(nn.Module):
         hidden_states_out = []
         nblk = len(self.vit.blocks)
         starts = set(self.backward_stage_starts)
+        b16 = Fn._bf16_path(prec, self.hidden_size, self.vit.blocks[0].mlp.linear1.weight.shape[0])
+        taps = (3, 6, 9)                       # hidden states the conv side consumes (unetr.py:197-201)
         for i, blk in enumerate(self.vit.blocks):
             nxt = self.vit.blocks[i + 1].norm1 if i + 1 < nblk and Fn.ln_ride_enabled() else None   # its forward rides on this block's last kernel
             x = Fn.TransformerBlockFn.apply(
                 x, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
                 blk.norm2.weight, blk.norm2.bias, blk.mlp.linear1.weight, blk.mlp.linear1.bias, blk.mlp.linear2.weight,
                 blk.mlp.linear2.bias, B, L, self.num_heads, prec, ckpt,
-                None if nxt is None else nxt.weight.detach(), None if nxt is None else nxt.bias.detach())
-            # a pass boundary behind block i (block i+1 starts a pass) or a hidden state the conv side consumes (unetr.py:197-201:
-            # 3, 6, 9): ONE leaf per hidden state collects the gradients of all its consumers and starts block i's own pass
-            if (i + 1) in starts or i in (3, 6, 9):
-                x_leaf = cut(x, self._pass_of_block(i) - 1)
-                hidden_states_out.append(x_leaf)
-                if (i + 1) in starts:
-                    x = x_leaf
+                None if nxt is None else nxt.weight.detach(), None if nxt is None else nxt.bias.detach(),
+                i in taps)                      # (a tapped block's last GEMM also writes the bf16 tokens the transposed conv reads)
+            k = self._pass_of_block(i) - 1      # staged mode: index of the pass that runs block i's backward
+            if i in taps:
+                # two consumers: the next block takes alias `xa`, the skip path alias `xb`; TapFn's backward forms the sum of
+                # their gradients (+ its bf16 twin) in one launch.  Staged mode: the skip path's gradient is parked on a leaf
+                # until block i's pass starts, and so is the next block's when a pass boundary lies behind block i
+                xa, xb = Fn.TapFn.apply(x, b16)
+                hidden_states_out.append(cut(xb, k))
+                x = cut(xa, k) if (i + 1) in starts else xa
             else:
+                if (i + 1) in starts:
+                    x = cut(x, k)
                 hidden_states_out.append(x)
         x = Fn.LayerNormFn.apply(x, self.vit.norm.weight, self.vit.norm.bias,
                                  Fn._bf16_path(prec, self.hidden_size, self.vit.blocks[0].mlp.linear1.weight.shape[0]))

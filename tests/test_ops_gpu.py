@@ -60,6 +60,41 @@ def test_gemm_bf16_storage(pkg, dev, M, N, K):
         assert relerr(dx, (dy.double() @ w.double()).float()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,force", [(6912, 2304, 768, False), (6912, 3072, 768, False), (1030, 520, 192, True), (1024, 512, 64, True),
+                                         (2100, 772, 128, True), (1500, 1026, 320, True), (300, 256, 3072, True)])
+def test_gemm_bf16_big_tile(pkg, dev, monkeypatch, M, N, K, force):
+    """The 256 x 256 ping-pong kernel (8 waves, two groups one barrier interval apart, LDS-DMA into half-tile regions): picked by
+    itself at encoder shapes of batch 32 (243 / 324 tiles), forced (UNETR_GEMM_CFG=256) on ragged shapes -- M / N tails, 1 / 2 / 3 /
+    5 / 48 K tiles (odd and even counts walk both LDS buffers), N % 4 != 0 (scalar epilogue) -- with every epilogue kind,
+    against fp64 products of the same bf16 inputs."""
+    Fn = pkg.functional
+    if force:
+        monkeypatch.setenv("UNETR_GEMM_CFG", "256")
+    L = 206 if M == 1030 else M
+    x, w = g(M, K, seed=1).bfloat16(), g(N, K, seed=2, scale=0.1).bfloat16()
+    b, res, aux = g(N, seed=3), g(L, N, seed=4), g(M, N, seed=6)
+    xd, wd = x.to(dev), w.to(dev)
+    lin = (x.double() @ w.double().t()).float()
+    y = torch.full((M, N), float("nan"), device=dev)
+    yb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, Cb=yb)
+    assert relerr(y, lin) < 2e-5
+    assert torch.equal(yb.cpu(), y.cpu().bfloat16())
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, bias=b.to(dev), res=res.to(dev), ldr=N, res_mod=L)
+    assert relerr(y, lin + b + res.repeat(M // L, 1)) < 2e-5
+    pre = torch.empty(M, N, device=dev)
+    Fn.gemm_bf16(xd, wd, M, N, K, Cb=yb, bias=b.to(dev), act=1, pre=pre)
+    assert relerr(pre, lin + b) < 2e-5 and relerr(yb.float(), F.gelu(lin + b)) < 5e-3
+    auxr = aux.clone().requires_grad_(True)
+    F.gelu(auxr).sum().backward()
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, act=2, aux=aux.to(dev), ldaux=N)
+    assert relerr(y, lin * auxr.grad) < 2e-5
+    y0 = g(M, N, seed=7)
+    y = y0.to(dev)
+    Fn.gemm_bf16(xd, wd, M, N, K, C=y, accumulate=True, alpha=0.5)
+    assert relerr(y, y0 + 0.5 * lin) < 2e-5
+
+
 def test_gemm_bf16_grouped_wgrad(pkg, dev):
     """grouped dW_i = dY_i^T X_i on bf16-stored operands (both read through transposing LDS loads; 432 tokens = a ragged
     last 64-token stage; ragged N / K tiles) against fp64 products of the same bf16 inputs"""
