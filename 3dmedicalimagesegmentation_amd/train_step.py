@@ -47,11 +47,15 @@ def split_range(flat, lo, hi, pieces):
 
 class TrainStep:
     def __init__(self, model, criterion, optimizer, x, y, *, use_graph=True, data_parallel=False, process_group=None,
-                 comm_dtype=torch.float32, tail_pieces=2, warmup=2):
+                 comm_dtype=torch.float32, tail_pieces=2, warmup=2, overlap_update=False):
+        """overlap_update (single GPU): the data-parallel launch form without a process group -- backward in passes, AdamW on
+        each pass's arena range on the side stream underneath the passes that follow -- captured as ONE hipGraph in which the
+        side stream is a branch: the bandwidth-bound optimizer kernels hide under the latency-bound ViT backward chain."""
         flat = getattr(model, "_flat", None)
         self.model, self.crit, self.opt, self.x, self.y = model, criterion, optimizer, x, y
         self.flat = flat
-        self.dp = bool(data_parallel)
+        self.dp = bool(data_parallel) or bool(overlap_update)
+        self.overlap = bool(overlap_update) and not data_parallel
         self.group = process_group
         self.world = 1
         self.dist = None
@@ -64,6 +68,7 @@ class TrainStep:
                 self.world = dist.get_world_size(process_group)
         self.comm_dtype = comm_dtype
         self.in_place = comm_dtype == torch.float32
+        self.one_graph = False
         self.loss = None
         self._one = torch.ones((), dtype=torch.float32, device=x.device)
         self.graphs = None
@@ -206,6 +211,19 @@ class TrainStep:
                 self._single_step()
             self.graphs = [g]
             return
+        if self.overlap and self.dist is None:
+            # no collective between the passes: the whole step is one graph, the communication stream a branch of it (forked by
+            # comm_stream.wait_stream(main) after every pass, joined by main.wait_stream(comm_stream) after the last)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.side, capture_error_mode=mode):
+                self._pass0()
+                self._reduce_and_update(0)
+                for k in range(1, self.npass):
+                    self._pass(k)
+                    self._reduce_and_update(k)
+            self.graphs = [g]
+            self.one_graph = True
+            return
         graphs = [torch.cuda.CUDAGraph()]
         with torch.cuda.graph(graphs[0], stream=self.side, capture_error_mode=mode):
             self._pass0()
@@ -221,7 +239,7 @@ class TrainStep:
         """one training step; returns nothing (self.loss is the device scalar of this step)"""
         if self.graphs is None:
             self._eager_step()
-        elif not self.dp:
+        elif not self.dp or self.one_graph:
             self.graphs[0].replay()
         else:
             for k, g in enumerate(self.graphs):
@@ -234,5 +252,7 @@ class TrainStep:
             return "eager"
         if not self.dp:
             return "hipGraph(fwd+loss+bwd+AdamW)"
+        if self.one_graph:
+            return (f"hipGraph(fwd+loss+bwd in {self.npass} passes; AdamW per pass on a side-stream branch underneath the passes that follow)")
         return (f"{self.npass} hipGraphs (fwd+loss+bwd pass 0 | ViT passes 1-{self.npass - 1}), per-pass all-reduce on a side stream, "
                 "AdamW per reduced piece")

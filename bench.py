@@ -50,6 +50,8 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
     ap.add_argument("--no-flat", action="store_true", help="per-tensor grads/AdamW instead of the flat arenas (N=1 only)")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (staged backward + per-pass all-reduce slots) on one rank")
+    ap.add_argument("--overlap-update", type=int, default=0, help="N=1: AdamW per backward pass on a side-stream branch of the ONE captured graph "
+                    "(measured SLOWER on MI355X / ROCm 7.2: 5.46 vs 5.00 ms per step -- a branch in a hipGraph costs more than the optimizer kernels it hides)")
     ap.add_argument("--bf16-comm", action="store_true", help="all-reduce gradients in bf16 (default: fp32, the single-GPU arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -209,7 +211,8 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
     comm_dtype = torch.bfloat16 if (args.bf16_comm and args.precision == "bf16") else torch.float32
     graph_err = None
     try:
-        step = pkg.TrainStep(model, crit, opt, x, y, use_graph=not args.no_graph, data_parallel=ddp_on, comm_dtype=comm_dtype)
+        step = pkg.TrainStep(model, crit, opt, x, y, use_graph=not args.no_graph, data_parallel=ddp_on, comm_dtype=comm_dtype,
+                             overlap_update=bool(args.overlap_update) and flat is not None and not ddp_on)
     except Exception as e:  # noqa: BLE001
         if args.no_graph:
             raise

@@ -576,7 +576,7 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
     x, y = synthetic_volume(2, 1, S, ncls, seed=41)
     xd, yd = x.to(dev), y.to(dev)
     res = {}
-    modes = ("single", "staged_eager", "staged_graph", "staged_bf16comm") if size == "c1" else ("single", "staged_graph")
+    modes = ("single", "staged_eager", "staged_graph", "staged_bf16comm", "overlap_one_graph") if size == "c1" else ("single", "staged_graph")
     for mode in modes:
         torch.manual_seed(11)
         m = pkg.UNETRLogits(**cfg).to(dev)
@@ -584,8 +584,11 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         flat = m.use_flat_buffers()
         opt = pkg.AdamW(m.parameters(), lr=lr, weight_decay=1e-5, flat=flat)
         crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
-        step = pkg.TrainStep(m, crit, opt, xd, yd, use_graph=mode != "staged_eager", data_parallel=mode != "single",
-                             comm_dtype=torch.bfloat16 if mode == "staged_bf16comm" else torch.float32, warmup=1)
+        step = pkg.TrainStep(m, crit, opt, xd, yd, use_graph=mode != "staged_eager", data_parallel=mode.startswith("staged"),
+                             comm_dtype=torch.bfloat16 if mode == "staged_bf16comm" else torch.float32, warmup=1,
+                             overlap_update=mode == "overlap_one_graph")
+        if mode == "overlap_one_graph":      # the same passes + side-stream AdamW as ONE graph (the side stream is a branch of it)
+            assert step.one_graph and len(step.graphs) == 1
         if mode.startswith("staged"):
             assert len(step.pieces) == 5 and len(step.pieces[4]) == 2
             if size == "c2":        # the tail that cannot overlap with backward: block 0 + patch embedding, 41 MB of 370 MB
@@ -601,6 +604,7 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         del step, opt, m, flat
     if "staged_eager" in res:
         assert torch.equal(res["single"][0], res["staged_eager"][0])
+        assert torch.equal(res["single"][0], res["overlap_one_graph"][0])
     assert torch.equal(res["single"][0], res["staged_graph"][0])
     assert res["single"][1] == res["staged_graph"][1]
     if "staged_bf16comm" in res:
