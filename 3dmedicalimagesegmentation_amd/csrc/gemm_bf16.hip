@@ -503,10 +503,10 @@ constexpr int GW_MAX = 64;     // 12 blocks x 4 Linear layers + patch embedding 
 struct GwProblem { const uint16_t* dy; const uint16_t* x; float* dw; int M, N, K, tile0, ntn; };
 struct GwArgs { int n; GwProblem p[GW_MAX]; };
 
-template <int NS>
+template <int NS, int BKT>                                  // BKT = tokens per stage (64 or 32)
 __global__ void __launch_bounds__(256)
 gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
-    constexpr int BT = 128, BKT = 64;                      // output tile 128 x 128, 64 tokens per stage
+    constexpr int BT = 128;                                // output tile 128 x 128
     constexpr int IMG = BKT * BT * 2, STAGE = 2 * IMG, PCS = IMG / 16 / 256, G = 2 * PCS, CPR = 16;
     __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
     int pi = 0;
@@ -559,7 +559,7 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
         const char* la = lds + (kt % NS) * STAGE;
         const char* lb = la + IMG;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < BKT / 32; ++kb) {
             const int r0 = kb * 32 + 8 * g + q, r1 = r0 + 4;
             const int x0s = bkn_x<CPR>(r0), x1s = bkn_x<CPR>(r1);
             const bool live = kt * BKT + kb * 32 + 8 * g < M;          // this lane group's 8 tokens exist
@@ -761,7 +761,10 @@ extern "C" int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs,
             g.tile0 = tiles; g.ntn = cdiv(q.N, 128);
             tiles += g.ntn * cdiv(q.K, 128);
         }
-        hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2>), dim3(tiles), dim3(256), 0, st, ga);
+        // 32 tokens per stage, two stages: 32 KB of LDS per workgroup -> four workgroups per CU.  The launch is latency-bound per
+        // K step (7-14 short steps per tile, operands out of HBM / MALL); measured at 432 rows (tools/probe_gw.py, us):
+        // 64 tokens x 2 stages (two workgroups per CU) 201, 32 x 2 178, 32 x 3 190, 32 x 4 203, 64 x 3 268, 64 x 4 245
+        hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32>), dim3(tiles), dim3(256), 0, st, ga);
     }
     return unetr_check_launch();
 }
