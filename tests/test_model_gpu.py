@@ -364,15 +364,15 @@ def test_c5_pretraining_steps(pkg, dev):
 
 def test_sliding_window_inference_and_dice_metric(pkg, dev):
     """SURVEY 8(f) rank 2 -- the validation step (unetr_segmentation_3d.py:103-132): sliding-window inference with the
-    reference's arguments (roi = crop^3, sw_batch_size 4, default overlap 0.25) over volumes larger than, equal to and
-    smaller than the window, then argmax/one-hot post-processing and DiceMetric "mean" / "mean_batch" -- against the CPU
+    reference's arguments (roi = crop^3, sw_batch_size 4, default overlap 0.25, and the 0.8 of :694-695) over volumes larger
+    than, equal to and smaller than the window, then argmax/one-hot post-processing and DiceMetric "mean" / "mean_batch" -- against the CPU
     oracle running the oracle model."""
     from oracle.unetr_oracle import (oracle_dice_metric, oracle_post_label, oracle_post_pred,
                                      oracle_sliding_window_inference, synthetic_volume)
     ref, hip = _pair(pkg, dev, C1, seed=4, ref_dtype=torch.float32)
     hip.precision = "fp32"
     ref_pred = lambda w: ref(w)[1]
-    for size, overlap in ((48, 0.25), (40, 0.5), (32, 0.25), (24, 0.25)):
+    for size, overlap in ((48, 0.25), (40, 0.5), (48, 0.8), (32, 0.25), (24, 0.25)):      # 0.8: the plots' call, unetr_segmentation_3d.py:694-695
         x, y = synthetic_volume(2, 1, size, 2, seed=20 + size)
         with torch.no_grad():
             out_r = oracle_sliding_window_inference(x, (32, 32, 32), 4, ref_pred, overlap=overlap)
@@ -506,13 +506,21 @@ def test_derived_weight_copies_follow_every_update(pkg, dev):
     check(".data in-place + invalidate_weight_shadows()")
 
 
+# bounds of the benched configuration = 2x what was measured on MI355X (gpurun_out/r3_c2_parity.log; printed by the test with -s):
+# a regression that doubles any of these errors fails.  north_star's 1e-3 is met in fp32 mode (test_c2_full_size_fp32_parity),
+# not in this -- the benched -- bf16 mode.
+# measured (round 3): logits 1.91e-2, enc4 5.1e-3, Dice term 2.0e-5, CE term 8.7e-5, lowest gradient cosine 0.99365
+# (vit.patch_embedding.position_embeddings; next 0.9972), loss of optimizer steps 1 / 3 / 4 within 6e-5 / 9e-5 / 2e-5 of the oracle's.
+C2_BOUNDS = dict(logits=4e-2, enc4=1.1e-2, dice=1e-4, ce=2e-4, cosine=0.99, loss0=2e-4, loss_traj=2e-4)
+C2_COSINE_ALLOW = {}       # tensor name -> its own lower bound (none needed: the measured floor over all 164 tensors is above 0.99)
+
+
 def test_c2_bench_path_bf16_parity(pkg, dev):
     """BASELINE config[1] EXACTLY as bench.py runs it -- bf16 mode, batch 2, flat arenas, this package's AdamW, the whole
     step replayed as a captured hipGraph (train_step.TrainStep) -- against the fp32 CPU oracle with the same weights
     and the same synthetic volumes.  bf16 bounds (bf16 operands, fp32 accumulate, 12 residual blocks + 5 conv stages):
-    logits / enc4 within 5e-2 of their max, Dice and CE terms within 1e-2 relative, EVERY parameter gradient (164 tensors)
-    by cosine (>= 0.98; >= 0.90 for a few ill-conditioned tiny tensors, see below), and the loss of 3 further optimizer
-    steps within 2e-2 of the oracle's trajectory."""
+    logits / enc4 / Dice / CE terms within C2_BOUNDS (= 2x the measured errors), EVERY parameter gradient (164 tensors) by
+    cosine >= 0.99 (no exceptions needed), and the loss of optimizer steps 1, 3, 4 within 2e-4 of the oracle's trajectory."""
     from oracle.unetr_oracle import OracleUNETR, oracle_dice_ce_terms, oracle_train_step, synthetic_volume
     torch.manual_seed(1234)
     ref = OracleUNETR(**C2)
@@ -532,8 +540,10 @@ def test_c2_bench_path_bf16_parity(pkg, dev):
     enc4_r, logits_r = ref(x)
     d_r, c_r = oracle_dice_ce_terms(logits_r, y)
     (d_r + c_r).backward()
-    assert relerr(logits, logits_r) < 5e-2 and relerr(enc4, enc4_r) < 5e-2
-    assert relerr(terms[1], d_r) < 1e-2 and relerr(terms[2], c_r) < 1e-2
+    meas = dict(logits=relerr(logits, logits_r), enc4=relerr(enc4, enc4_r), dice=relerr(terms[1], d_r), ce=relerr(terms[2], c_r))
+    print("measured forward errors:", meas)
+    assert meas["logits"] < C2_BOUNDS["logits"] and meas["enc4"] < C2_BOUNDS["enc4"], meas
+    assert meas["dice"] < C2_BOUNDS["dice"] and meas["ce"] < C2_BOUNDS["ce"], meas
     gr, gh = dict(ref.named_parameters()), dict(hip.named_parameters())
     n, worst = 0, {}
     for k, p in gr.items():
@@ -544,9 +554,10 @@ def test_c2_bench_path_bf16_parity(pkg, dev):
         worst[k] = c
         n += 1
     assert n == 164
-    low = {k: c for k, c in worst.items() if c < 0.98}
     print("lowest cosines:", sorted(worst.items(), key=lambda kv: kv[1])[:8])
-    assert all(c > 0.90 for c in low.values()) and len(low) <= 8, low
+    low = {k: c for k, c in worst.items() if c < C2_BOUNDS["cosine"] and k not in C2_COSINE_ALLOW}
+    assert not low, low
+    assert all(worst[k] > v for k, v in C2_COSINE_ALLOW.items()), {k: worst[k] for k in C2_COSINE_ALLOW}
     ref.zero_grad()
     hip.zero_grad(set_to_none=True)
     # the benched step: AdamW on arenas, graph replay; losses of steps 1..4 against the oracle's
@@ -555,11 +566,13 @@ def test_c2_bench_path_bf16_parity(pkg, dev):
     step = pkg.TrainStep(hip, crit, opt, xd, yd, use_graph=True, warmup=2)       # 2 eager steps, then capture (1 more: capture runs nothing)
     assert step.graphs is not None and len(step.graphs) == 1
     l_ref = [float(oracle_train_step(ref, o_ref, x, y)) for _ in range(4)]
-    assert abs(float(step.first_loss) - l_ref[0]) < 1e-2 * l_ref[0]
+    traj = [abs(float(step.first_loss) - l_ref[0]) / l_ref[0]]
     step.run()                                                                     # optimizer step 3 (graph replay)
-    assert abs(float(step.loss) - l_ref[2]) < 2e-2 * l_ref[2], (float(step.loss), l_ref)
+    traj.append(abs(float(step.loss.detach()) - l_ref[2]) / l_ref[2])
     step.run()
-    assert abs(float(step.loss) - l_ref[3]) < 2e-2 * l_ref[3], (float(step.loss), l_ref)
+    traj.append(abs(float(step.loss.detach()) - l_ref[3]) / l_ref[3])
+    print("measured loss-trajectory errors (steps 1, 3, 4):", traj)
+    assert traj[0] < C2_BOUNDS["loss0"] and max(traj[1:]) < C2_BOUNDS["loss_traj"], (traj, l_ref)
     assert l_ref[3] < l_ref[0]
     flat["state"].clear()
 
@@ -842,3 +855,88 @@ def test_c5_ranking_pretraining_at_96(pkg, dev):
                 assert cosine(gh[k].grad, gr[k].grad) > 0.999, (stage, k, cosine(gh[k].grad, gr[k].grad))
             if stage == "recon":
                 assert gh["vit.blocks.0.attn.qkv.weight"].grad is None and gh["encoder1.layer.conv1.conv.weight"].grad is None
+
+
+def test_capture_mode_vs_foreign_thread_queries(pkg, dev, tmp_path):
+    """TrainStep captures its hipGraphs in ``thread_local`` capture mode because a live process group's watchdog thread polls
+    events (hipEventQuery) while the step is being captured.  Deterministic form of that situation: a second Python thread
+    hammers ``Event.query()`` / ``Stream.query()`` while this thread captures a graph of HIP-extension kernels.  Under
+    thread_local mode the capture must complete and replay correctly.  The same under the default ``global`` mode runs in a
+    child process (an invalidated capture can poison the context) and is only REPORTED (with -s): round 2 saw one abort in six
+    1-rank RCCL runs under global mode and no log of it survives; on MI355X / ROCm 7.2 / torch 2.10 this deterministic form
+    COMPLETES under global mode too (round 3), so foreign-thread event queries alone do not explain that abort -- the cause
+    stays unknown, thread_local stays as the conservative setting, and this test pins that it works."""
+    import subprocess
+    import sys
+    import threading
+    Fn = pkg.functional
+    x = torch.randn(432, 768, device=dev)
+    gam, bet = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+    ev = torch.cuda.Event()
+    ev.record()
+    stop, errs, polls = threading.Event(), [], [0]
+
+    def poll():
+        try:
+            while not stop.is_set():
+                ev.query()
+                torch.cuda.current_stream().query()
+                polls[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    t = threading.Thread(target=poll, daemon=True)
+    t.start()
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            Fn.layernorm_fwd(x, gam, bet)             # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            for _ in range(50):
+                y, _, _ = Fn.layernorm_fwd(x, gam, bet)
+        g.replay()
+        torch.cuda.synchronize()
+    finally:
+        stop.set()
+        t.join(timeout=10)
+    assert not errs, errs
+    assert polls[0] > 0
+    assert relerr(y, torch.nn.functional.layer_norm(x, (768,), gam, bet)) < 1e-5
+    # the same under global capture mode, in a child: outcome recorded, not asserted (it is timing dependent)
+    child = tmp_path / "global_mode.py"
+    child.write_text(f"""
+import importlib, sys, threading, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+pkg = importlib.import_module("3dmedicalimagesegmentation_amd"); Fn = pkg.functional
+dev = torch.device("cuda:0")
+x = torch.randn(432, 768, device=dev); gam, bet = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+ev = torch.cuda.Event(); ev.record()
+stop, errs = threading.Event(), []
+def poll():
+    try:
+        while not stop.is_set():
+            ev.query(); torch.cuda.current_stream().query()
+    except Exception as e:
+        errs.append(repr(e))
+t = threading.Thread(target=poll, daemon=True); t.start()
+out = "capture completed"
+try:
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        Fn.layernorm_fwd(x, gam, bet)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="global"):
+        for _ in range(50):
+            Fn.layernorm_fwd(x, gam, bet)
+    g.replay(); torch.cuda.synchronize()
+except Exception as e:
+    out = "capture failed: " + repr(e)[:300]
+stop.set(); t.join(timeout=10)
+print("GLOBAL MODE:", out, "| polling thread errors:", errs[:1])
+""")
+    r = subprocess.run([sys.executable, str(child)], capture_output=True, text=True, timeout=300)
+    print("global capture mode with a polling thread ->", (r.stdout.strip().splitlines() or ["<no output>"])[-1], "| rc", r.returncode)
