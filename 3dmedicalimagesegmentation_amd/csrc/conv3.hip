@@ -976,6 +976,141 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
     }
 }
 
+// ---- ONE input channel, 16 output channels (the image in front of encoder1: UnetrBasicBlock(in_channels, feature_size),
+// unetr.py:90-98), bf16 mode.  The generic pair-mode kernel treats the image as 16 zero-padded channels: 14 K=32 MFMAs per 16
+// voxels of which 27 of 448 products are not zero, and a window staged with scalar loads (60 us at 96^3 for 113 MB of output).
+// Here the contraction index IS the tap: [16 voxels, 27 taps (K = 32)] x [32, 16 channels] = one MFMA per 16 voxels.  A window of
+// 6 x 6 x 18 bf16 image values (1.3 KB) is staged per tile; lane (voxel r, tap group g) gathers its eight taps with ds_read_u16;
+// the 1x1x1 branch (UnetResBlock.conv3 on the same input) is x[v] * w3[co] on the VALU -- the exact product of the two bf16
+// values, as the MFMA formed it.  Weights are read from the pair-mode packs (element [tap >> 1][co][(tap & 1) * 16] of wp, element
+// [co][16] of wp3).  Same tile walk, output layout and InstanceNorm partial rows as conv3_fwd_pipe_kernel<..., PAIR, FUSE 2>.
+__global__ void __launch_bounds__(256, 4)
+conv3_c1_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wp, uint16_t* __restrict__ y, long ldy,
+                    int D, int H, int W, int ntx, int nty, int ntz, int ntiles, float* __restrict__ part,
+                    const uint16_t* __restrict__ wp3, uint16_t* __restrict__ y3, float* __restrict__ part3) {
+    constexpr int Cout = 16, NPT = (NHALO + 255) / 256;
+    __shared__ uint16_t win[NHALO + 8];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
+    const bool has3 = wp3 != nullptr;
+    // weight fragment (first MFMA operand: rows = channels): lane (co = r, g) holds taps 8g .. 8g+7 of channel r
+    u32x4 wfrag;
+    {
+        uint16_t wv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = 8 * g + j;
+            wv8[j] = tap < 27 ? wp[((long)(tap >> 1) * Cout + r) * 32 + (tap & 1) * 16] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wfrag[d] = (uint32_t)wv8[2 * d] | ((uint32_t)wv8[2 * d + 1] << 16);
+    }
+    float w3f[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w3f[e] = __builtin_bit_cast(float, (uint32_t)wp3[(long)(4 * g + e) * 32 + 16] << 16);
+    }
+    // window offsets (elements) of this lane's eight taps relative to voxel (plane wv, row 0, column r); taps 27..31 (zero weights)
+    // read the centre tap: any finite value
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int tap = 8 * g + j < 27 ? 8 * g + j : 13;
+        toff[j] = ((tap / 9) * HY + (tap % 9) / 3) * HX + tap % 3;
+    }
+    const int base0 = (wv * HY) * HX + r;
+    const int cen = (HY + 1) * HX + 1;                    // centre tap
+    // InstanceNorm partial sums (see stats_add / stats_flush)
+    f32x4 rs1[1] = {{0.f, 0.f, 0.f, 0.f}}, rs2[1] = {{0.f, 0.f, 0.f, 0.f}}, rt1[1] = {{0.f, 0.f, 0.f, 0.f}}, rt2[1] = {{0.f, 0.f, 0.f, 0.f}};
+    int cur_b = -1;
+    const long srows = (long)gridDim.x * 4;
+    {
+        const int nb = ntiles / (ntx * nty * ntz);
+        if (g == 0) {
+            for (int bb = 0; bb < nb; ++bb) {
+                float* p0 = part + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + r;
+                p0[0] = 0.f; p0[Cout] = 0.f;
+                if (has3) { float* p3 = part3 + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + r; p3[0] = 0.f; p3[Cout] = 0.f; }
+            }
+        }
+    }
+    const long item = (long)D * H * W;
+    // this thread's window pieces of tile (b_, z_, y_, x_): image values, 0 outside the volume
+    float nxt[NPT];
+    auto wload = [&](int b_, int z_, int y_, int x_) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int hz = id / (HY * HX), rem = id - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z_ - 1 + hz, gy = y_ - 1 + hy, gx = x_ - 1 + hx;
+            const bool ok = id < NHALO && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            float t = 0.f;
+            if (ok) t = x[b_ * item + ((long)gz * H + gy) * W + gx];
+            nxt[j] = t;
+        }
+    };
+    TileTable tt;
+    int kt = 0, tx = 0, ty = 0, tz = 0, b = 0;
+    if ((int)blockIdx.x < ntiles) {
+        tt.get(0, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        wload(b, tz * TZ, ty * TY, tx * TX);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++kt) {
+        int ax = tx, ay = ty, az = tz, ab = b;
+        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+        if (b != cur_b) {
+            if (cur_b >= 0) {
+                stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
+                if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
+            }
+            cur_b = b;
+        }
+        __syncthreads();                                     // every wave is done with the previous window
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            if (id < NHALO) win[id] = f2bf(nxt[j]);
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) {                // the next tile's window is in flight during this tile's work
+            tt.get(kt + 1, ntiles, ntx, nty, ntz, ax, ay, az, ab);
+            wload(ab, az * TZ, ay * TY, ax * TX);
+        }
+        const int zo = z0 + wv, xo = x0 + r;
+        f32x4 acc[4][1], acc3[4][1];
+        bool okv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint16_t* wb = win + base0 + i * HX;
+            uint16_t a8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a8[j] = wb[toff[j]];
+            u32x4 af;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) af[d] = (uint32_t)a8[2 * d] | ((uint32_t)a8[2 * d + 1] << 16);
+            acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            PrecBF16::mma(acc[i][0], wfrag, af);
+            const float xc = __builtin_bit_cast(float, (uint32_t)wb[cen] << 16);
+            acc3[i][0] = (f32x4){xc * w3f[0], xc * w3f[1], xc * w3f[2], xc * w3f[3]};
+            okv[i] = zo < D && y0 + i < H && xo < W;
+        }
+        const long tb = (((long)b * D + zo) * H + y0) * W + xo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (okv[i]) {
+                Io<uint16_t>::st4(y + (tb + (long)i * W) * ldy + 4 * g, acc[i][0]);
+                if (has3) Io<uint16_t>::st4(y3 + (tb + (long)i * W) * ldy + 4 * g, acc3[i][0]);
+            }
+        }
+        stats_add<1>(acc, okv, rs1, rs2);
+        if (has3) stats_add<1>(acc3, okv, rt1, rt2);
+        tx = ax; ty = ay; tz = az; b = ab;
+    }
+    if (cur_b >= 0) {
+        stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
+        if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
+    }
+}
+
 // 1x1x1 weights w3[Cout][Cin] in the B-fragment layout the fused kernel reads at the centre tap:
 // pair mode: wp3[n][32], k = 16 + ci (the tap-13 half of pair 6), zero elsewhere; slab mode: wp3[slab][n][SL], k = ci - slab*SL
 // transposed = 1 (data gradient): rows n are INPUT channels of the conv and k its output channels: element = w3[k][n]
@@ -1352,6 +1487,124 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     }
 }
 
+// Weight gradient of the same single-input-channel conv (+ its 1x1x1 branch): dw[co][tap] = sum_v dy[v, co] x[v + off(tap)],
+// dw3[co] = sum_v dy3[v, co] x[v].  The generic kernel contracts over voxels with the window zero-padded to 16 channels (70 us
+// at 96^3 for 114 MB of gradient maps); here the tap is the OUTPUT column: per 32-voxel k-block two MFMAs [16 co x 32 voxels] x
+// [32 voxels x 16 taps] (taps 0-15 and 16-31; column 27 = the centre voxel again, which the dy3 product reads its result from).
+// dy / dy3 tiles (256 voxels x 16 channels, bf16) are staged in the conflict-free transposing-read layout of conv3_wgrad_kernel
+// (lay_flip), the image window as bf16 scalars; each wave owns two of the eight k-blocks of a tile and keeps its sums in
+// registers across its workgroup's tile walk: partial rows part[workgroup * 4 + wave][16][27], part3[...][16].
+__global__ void __launch_bounds__(256, 4)
+conv3_c1_wgrad_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy, long lddy, const uint16_t* __restrict__ dy3, long lddy3,
+                      float* __restrict__ part, float* __restrict__ part3, int D, int H, int W, int ntx, int nty, int ntz, int ntiles) {
+    constexpr int PY = 32, NPT = (NHALO + 255) / 256, WINB = ((NHALO + 8) * 2 + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) char lds[WINB + 2 * NVOX * PY];
+    uint16_t* win = (uint16_t*)lds;
+    char* yimg = lds + WINB;
+    char* y3img = yimg + NVOX * PY;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, g = lane >> 4;
+    const bool has3 = dy3 != nullptr;
+    const int q = c >> 2, p = c & 3;
+    const int ylane0 = lay_flip(8 * g + q) * PY + 8 * p, ylane1 = lay_flip(8 * g + q + 4) * PY + 8 * p;
+    // window element offset of this lane's column (tap 16 tt + c; taps >= 27 alias the centre) + its voxel row / half row
+    int toff[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+        const int tap = 16 * t2 + c < 27 ? 16 * t2 + c : 13;
+        toff[t2] = ((tap / 9) * HY + (tap % 9) / 3) * HX + tap % 3 + (g >> 1) * HX + 8 * (g & 1);
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acc3 = {0.f, 0.f, 0.f, 0.f};
+    const long item = (long)D * H * W;
+    float nxt[NPT];
+    u32x4 ybuf[2], y3buf[2];
+    auto tload = [&](int b_, int z_, int y_, int x_) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int hz = id / (HY * HX), rem = id - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z_ - 1 + hz, gy = y_ - 1 + hy, gx = x_ - 1 + hx;
+            const bool ok = id < NHALO && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            float t = 0.f;
+            if (ok) t = x[b_ * item + ((long)gz * H + gy) * W + gx];
+            nxt[j] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int id = threadIdx.x + j * 256, v = id >> 1, ch = id & 1;
+            const int gz = z_ + (v >> 6), gy = y_ + ((v >> 4) & 3), gx = x_ + (v & 15);
+            const bool ok = gz < D && gy < H && gx < W;
+            const long vox = ok ? ((((long)b_ * D + gz) * H + gy) * W + gx) : 0;
+            ybuf[j] = act_chunk<PrecBF16>(dy + vox * lddy + ch * 8, ok);
+            if (has3) y3buf[j] = act_chunk<PrecBF16>(dy3 + vox * lddy3 + ch * 8, ok);
+        }
+    };
+    TileTable tt;
+    int kt = 0, tx = 0, ty = 0, tz = 0, b = 0;
+    if ((int)blockIdx.x < ntiles) {
+        tt.get(0, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        tload(b, tz * TZ, ty * TY, tx * TX);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++kt) {
+        int ax = tx, ay = ty, az = tz, ab = b;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            if (id < NHALO) win[id] = f2bf(nxt[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int id = threadIdx.x + j * 256, v = id >> 1, ch = id & 1;
+            *(u32x4*)(yimg + lay_flip(v) * PY + ch * 16) = ybuf[j];
+            if (has3) *(u32x4*)(y3img + lay_flip(v) * PY + ch * 16) = y3buf[j];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) {
+            tt.get(kt + 1, ntiles, ntx, nty, ntz, ax, ay, az, ab);
+            tload(ab, az * TZ, ay * TY, ax * TX);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kb = wv + 4 * h;                            // this wave's k-block: voxels 32 kb .. 32 kb + 31
+            const int ykb = kb * 32 * PY;
+            s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(yimg + ykb + ylane0));
+            s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(yimg + ykb + ylane1));
+            const s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            u32x4 af3 = {0u, 0u, 0u, 0u};
+            if (has3) {
+                s16x4 clo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + ykb + ylane0));
+                s16x4 chi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(y3img + ykb + ylane1));
+                const s16x8 c8 = {clo[0], clo[1], clo[2], clo[3], chi[0], chi[1], chi[2], chi[3]};
+                af3 = __builtin_bit_cast(u32x4, c8);
+            }
+            const uint16_t* wb = win + ((kb >> 1) * HY + (kb & 1) * 2) * HX;      // window row of the k-block's first voxel row
+            u32x4 bf[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                uint16_t b8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = wb[toff[t2] + j];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bf[t2][d] = (uint32_t)b8[2 * d] | ((uint32_t)b8[2 * d + 1] << 16);
+            }
+            PrecBF16::mma(acc[0], __builtin_bit_cast(u32x4, a8), bf[0]);
+            PrecBF16::mma(acc[1], __builtin_bit_cast(u32x4, a8), bf[1]);
+            if (has3) PrecBF16::mma(acc3, af3, bf[1]);
+        }
+        tx = ax; ty = ay; tz = az; b = ab;
+    }
+    // accumulator: lane (column c = tap within its tile, g) holds rows co = 4g .. 4g+3
+    const long row = (long)blockIdx.x * 4 + wv;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int co = 4 * g + rr;
+        part[(row * 16 + co) * 27 + c] = acc[0][rr];
+        if (16 + c < 27) part[(row * 16 + co) * 27 + 16 + c] = acc[1][rr];
+        if (has3 && c == 11) part3[row * 16 + co] = acc3[rr];
+    }
+}
+
 // dw[i] = sum_g part[g][i]: 32 outputs x 8 g-phases per workgroup, fixed summation order (reproducible); eight loads of
 // a phase are in flight together (the slabs sit in L2: the pass is latency-, not bandwidth-bound)
 __global__ void __launch_bounds__(256)
@@ -1487,6 +1740,21 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
     }
     if (B16 && fz && fz->k3 > 0 && ((fz->ldy3 & 7) || ((uintptr_t)fz->y3 & 15) || (fz->k3 & 7))) return UNETR_ERR_UNSUPPORTED;
     if ((long)D * H * W * ldx >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;      // 32-bit in-item offsets (halo_load)
+    if constexpr (B16) {
+        // the single-channel image -> 16 channels with fused statistics (and the 1x1x1 branch): the dedicated one-MFMA kernel
+        if (conv_pipe_enabled() && x_f32 && Cin == 1 && Cout == 16 && ldx == 1 && fz && fz->k3 == 0 && !accumulate && use_pair<P>(Cin) &&
+            ntx < 256 && nty < 256 && ntz < 256 && B < 256 && (ldy & 3) == 0 && ((uintptr_t)y & 7) == 0 && (long)D * H * W < (1L << 31) &&
+            (!fz->y3 || (((uintptr_t)fz->y3 & 7) == 0 && fz->ldy3 == ldy)) && !getenv("UNETR_CONV_C1_OFF")) {
+            long cap = 1024;
+            if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) cap = std::min<long>(cap, atoi(e)); }
+            if (cap < spatial) cap = std::max<long>(8, cap / 8 * 8);
+            const unsigned gx = (unsigned)std::min<long>(spatial, cap);
+            fz->rows = (int)gx * 4;
+            hipLaunchKernelGGL(conv3_c1_fwd_kernel, dim3(gx), dim3(256), 0, st, (const float*)x, (const uint16_t*)wp, (uint16_t*)y, ldy, D, H, W,
+                               ntx, nty, ntz, (int)spatial, fz->part, (const uint16_t*)fz->wp3, (uint16_t*)fz->y3, fz->part3);
+            return unetr_check_launch();
+        }
+    }
     if (conv_pipe_enabled() && ntb <= 4 && ntx < 256 && nty < 256 && ntz < 256 && B < 256) {      // (TileTable packs the coordinates in bytes)
         // persistent, software-pipelined kernel: a few resident workgroups per CU walk the tiles
         const bool pair = use_pair<P>(Cin);
@@ -1588,6 +1856,22 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     // 16-channel slabs everywhere (measured: 32->16 @ 96^3 200 -> 170 us, 64->32 @ 48^3 133 -> 88 us, step -0.16 ms): the dy tile is
     // re-staged once per slab, but three pipelined workgroups per CU beat two with the 32-channel window.  UNETR_WG_CIS1 = largest
     // Cin that still takes the 16-channel variant (tuning hook).
+    if constexpr (B16) {
+        // the single-channel image (encoder1's first conv + its 1x1x1 branch): the dedicated tap-column kernel
+        if (x_f32 && Cin == 1 && Cout == 16 && ldx == 1 && ((uintptr_t)dy & 15) == 0 && (lddy & 7) == 0 &&
+            (!dy3 || (((uintptr_t)dy3 & 15) == 0 && (lddy3 & 7) == 0)) && (long)D * H * W < (1L << 31) && !getenv("UNETR_CONV_C1_OFF")) {
+            long G = std::min<long>(1024, ntiles);
+            if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) G = std::min<long>(G, atoi(e)); }
+            const long n1 = 27L * 16, n31 = dy3 ? 16 : 0, rows = G * 4;
+            if (!ws || (size_t)rows * (n1 + n31) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+            float* wsb = ws + (size_t)rows * n1;
+            hipLaunchKernelGGL(conv3_c1_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, st, (const float*)x, (const uint16_t*)dy, lddy, (const uint16_t*)dy3, lddy3,
+                               ws, wsb, D, H, W, ntx, nty, ntz, (int)ntiles);
+            const int blocks = (int)cdiv(n1, 32), blocks3 = dy3 ? 1 : 0;
+            hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)rows, n1, dw, blocks, (const float*)wsb, n31, dw3);
+            return unetr_check_launch();
+        }
+    }
     const int cis = Cin <= (getenv("UNETR_WG_CIS1") ? atoi(getenv("UNETR_WG_CIS1")) : (1 << 30)) ? 1 : 2;
     const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
@@ -1671,7 +1955,7 @@ extern "C" int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack,
     if ((w3pack != nullptr) != (y3 != nullptr) || (w3pack != nullptr) != (stats3 != nullptr)) return UNETR_ERR_ARG;
     if (Cout % 16 || (w3pack && ldy3 != ldy)) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int max_rows = 512 * 4;                                            // (workgroup, wave) partial rows per batch item
+    const int max_rows = 1024 * 4;                                           // (workgroup, wave) partial rows per batch item
     const size_t per = (size_t)B * max_rows * 2 * Cout;
     if (!ws || per * (w3pack ? 2 : 1) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
     FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr, 0, 0};

@@ -269,7 +269,7 @@ def test_conv3(pkg, dev, prec, B, dims3, cin, cout):
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("B,dims3,cin,cout,with3", [(2, (8, 8, 16), 16, 16, True), (1, (9, 7, 19), 1, 16, True), (2, (6, 10, 20), 32, 16, True),
                                                      (1, (12, 12, 12), 64, 32, True), (1, (5, 6, 7), 16, 32, False), (2, (4, 4, 16), 256, 128, True),
-                                                     (1, (10, 9, 33), 4, 16, True)])
+                                                     (1, (10, 9, 33), 4, 16, True), (2, (20, 12, 40), 1, 16, True), (2, (8, 8, 32), 1, 16, False)])
 def test_conv3_fused_stats_and_1x1(pkg, dev, prec, B, dims3, cin, cout, with3):
     """Fused residual-block front: conv3x3x3 + InstanceNorm statistics (+ the 1x1x1 conv on the same input with its
     statistics) in one launch == torch conv3d / mean / rstd, over ragged volumes and all kernel modes (pair, slab, scalar)."""
@@ -356,6 +356,45 @@ def test_conv3_halo(pkg, dev, prec, B, dims3, cin, cout):
         assert relerr(ncdhw(buf[..., :cin].cpu()), xr.grad + 1) < TOL[prec]
         assert (buf[..., cin:] == 1).all()
     assert relerr(Fn.conv3_wgrad(xd, cin, dyd, cout, dims, cin, cout, prec), wr.grad) < TOL[prec]
+
+
+@pytest.mark.parametrize("B,dims3,max_wg", [(2, (9, 7, 19), 0), (2, (20, 12, 40), 0), (3, (16, 16, 32), 8)])
+def test_conv3_single_channel_image(pkg, dev, monkeypatch, B, dims3, max_wg):
+    """The dedicated kernels for the 1-channel image in front of encoder1 (UnetrBasicBlock(in_channels=1, feature_size=16),
+    unetr.py:90-98) in bf16 mode -- forward: 27 taps as the K dimension of ONE MFMA per 16 voxels (+ the 1x1x1 branch on the VALU,
+    + both InstanceNorm statistics); weight gradient: taps as the output column -- against torch, over ragged volumes, several
+    batch items, and (max_wg) workgroups that walk many tiles across batch items.  The generic pair-mode kernels
+    (UNETR_CONV_C1_OFF=1) must give the same results up to accumulation order."""
+    Fn = pkg.functional
+    if max_wg:
+        monkeypatch.setenv("UNETR_TEST_MAX_WG", str(max_wg))
+    D, H, W = dims3
+    x = g(B, 1, D, H, W, seed=1)
+    w, w3 = g(16, 1, 3, 3, 3, seed=2, scale=0.2), g(16, 1, 1, 1, 1, seed=3, scale=0.5)
+    dy, dy3 = rq(g(B, 16, D, H, W, seed=4), 1), rq(g(B, 16, D, H, W, seed=5), 1)
+    xb = x.bfloat16().float()                       # what the kernels contract: bf16-rounded image and weights
+    wr, w3r = w.bfloat16().float().requires_grad_(True), w3.bfloat16().float().requires_grad_(True)
+    yr, y3r = F.conv3d(xb, wr, padding=1), F.conv3d(xb, w3r)
+    (yr * dy).sum().backward()
+    (y3r * dy3).sum().backward()
+    xd, dims = cl(x).to(dev), (B, D, H, W)
+    res = {}
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("UNETR_CONV_C1_OFF", "1")
+        c, st, c3, st3 = Fn.conv3_fused(xd, 1, w.to(dev), w3.to(dev), dims, 1)
+        assert relerr(ncdhw(c.float().cpu()), yr) < 5e-3 and relerr(ncdhw(c3.float().cpu()), y3r) < 5e-3
+        for out, stats in ((c, st), (c3, st3)):
+            o = out.float().cpu().double().reshape(B, -1, 16)
+            assert relerr(stats[..., 0], o.mean(1).float()) < 4e-3
+            assert relerr(stats[..., 1], (1.0 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)).float()) < 4e-3
+        dw3 = torch.empty(16, 1, 1, 1, 1, device=dev)
+        dw = Fn.conv3_wgrad(xd, 1, act(cl(dy), 1, dev), 16, dims, 1, 16, 1, dy3=act(cl(dy3), 1, dev), out3=dw3)
+        assert relerr(dw, wr.grad) < 2e-3 and relerr(dw3, w3r.grad) < 2e-3
+        res[off] = (c.float(), c3.float(), st, st3, dw.clone(), dw3.clone())
+    for a, b in zip(res[""], res["1"]):
+        assert relerr(a, b) < 2e-3
+    assert torch.equal(res[""][1], res["1"][1])      # the 1x1x1 branch is the exact product of two bf16 numbers on both paths
 
 
 @pytest.mark.parametrize("prec", [0, 1])

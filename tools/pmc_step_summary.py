@@ -1,4 +1,4 @@
-"""summarise the two rocprofv3 --pmc passes of tools/pmc_step.sh into profiles/r02_pmc_step_kernels.json"""
+"""summarise the two rocprofv3 --pmc passes of tools/pmc_step.sh into gpurun_out/<PMC_STEP_NAME> (copied to profiles/ by hand)"""
 import collections
 import csv
 import glob
@@ -38,7 +38,7 @@ for k in sorted(set(fetch) | set(write)):
 res = {"command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- {cmd} (tools/pmc_step.sh; separate passes)",
        "steps_in_process": steps, "correction": "read = FETCH_SIZE x 1024 x 2 (gfx950 half-count of 16 B/lane streams), write = WRITE_SIZE x 1024",
        "kernels": kernels}
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r02_pmc_step_kernels.json")
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", os.environ.get("PMC_STEP_NAME", "r03_pmc_step_kernels.json"))
 json.dump(res, open(dst, "w"), indent=1)
 tot = sum(v["hbm_bytes_per_step"] for v in kernels.values())
 print(f"{len(kernels)} kernels, {tot / 1e9:.2f} GB of HBM traffic per step -> {dst}")

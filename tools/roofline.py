@@ -26,13 +26,13 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 # (family, regex on the demangled kernel name)
 FAMILIES = [
     ("AdamW (fp32 master + moments, bf16 shadow)", r"adamw_kernel"),
-    ("ViT Linear GEMMs fwd + data-grad (bf16 operands)", r"gemm_bf16_kernel|splitk_reduce_kernel<.*EpBf"),
+    ("ViT Linear GEMMs fwd + data-grad (bf16 operands)", r"gemm_bf16_kernel|gemm_bf16_big_kernel|splitk_reduce_kernel<.*EpBf"),
     ("ViT Linear weight-grad (grouped)", r"gemm_bf16_grouped_wgrad|gemm_grouped_wgrad"),
     ("attention fwd + bwd", r"attn16_|attn_fwd|attn_bwd"),
     ("LayerNorm fwd + bwd", r"layernorm_"),
     ("InstanceNorm passes", r"in_apply|in_bwd_|in_stats"),
-    ("3x3x3 conv fwd + data-grad", r"conv3_fwd"),
-    ("3x3x3 conv weight-grad", r"conv3_wgrad"),
+    ("3x3x3 conv fwd + data-grad", r"conv3_fwd|conv3_c1_fwd"),
+    ("3x3x3 conv weight-grad", r"conv3_wgrad|conv3_c1_wgrad"),
     ("2x2x2 transposed conv (voxel-tile kernels, shuffles)", r"tconv2_|pixel_"),
     ("out conv + DiceCE", r"outconv|dicece"),
 ]
@@ -123,10 +123,14 @@ def _short(name):
 
 def _pmc_traffic(kernel_rx):
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    path = os.path.join(root, "r02_pmc_step_kernels.json")
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
+    d, rel = None, None
+    for cand in ("r03_pmc_step_kernels.json", "r02_pmc_step_kernels.json"):      # newest committed summary first
+        try:
+            d, rel = json.load(open(os.path.join(root, cand))), "profiles/" + cand
+            break
+        except (OSError, ValueError):
+            continue
+    if d is None:
         return None, None
     tot, n = 0.0, 0
     for k, v in d.get("kernels", {}).items():
@@ -135,7 +139,7 @@ def _pmc_traffic(kernel_rx):
             n += v["launches_per_step"]
     if n == 0:
         return None, None
-    return tot / n, "profiles/r02_pmc_step_kernels.json (" + d.get("command", "rocprofv3 --pmc") + ")"
+    return tot / n, rel + " (" + d.get("command", "rocprofv3 --pmc") + ")"
 
 
 def step_report(pkg, step, batch, precision, ms_per_step):
