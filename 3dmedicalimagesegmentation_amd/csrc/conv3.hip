@@ -1493,7 +1493,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
 // [32 voxels x 16 taps] (taps 0-15 and 16-31; column 27 = the centre voxel again, which the dy3 product reads its result from).
 // dy / dy3 tiles (256 voxels x 16 channels, bf16) are staged in the conflict-free transposing-read layout of conv3_wgrad_kernel
 // (lay_flip), the image window as bf16 scalars; each wave owns two of the eight k-blocks of a tile and keeps its sums in
-// registers across its workgroup's tile walk: partial rows part[workgroup * 4 + wave][16][27], part3[...][16].
+// registers across its workgroup's tile walk; one partial row per workgroup: part[workgroup][16][27], part3[workgroup][16].
 __global__ void __launch_bounds__(256, 4)
 conv3_c1_wgrad_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy, long lddy, const uint16_t* __restrict__ dy3, long lddy3,
                       float* __restrict__ part, float* __restrict__ part3, int D, int H, int W, int ntx, int nty, int ntz, int ntiles) {
@@ -1594,14 +1594,29 @@ conv3_c1_wgrad_kernel(const float* __restrict__ x, const uint16_t* __restrict__ 
         }
         tx = ax; ty = ay; tz = az; b = ab;
     }
-    // accumulator: lane (column c = tap within its tile, g) holds rows co = 4g .. 4g+3
-    const long row = (long)blockIdx.x * 4 + wv;
+    // the four waves' sums are added through LDS (fixed order: wave 0 + 1 + 2 + 3): ONE partial row per workgroup
+    __syncthreads();
+    f32x4* red = (f32x4*)lds;                                // [3 accumulators][4 waves][64 lanes]
+    red[(0 * 4 + wv) * 64 + lane] = acc[0];
+    red[(1 * 4 + wv) * 64 + lane] = acc[1];
+    red[(2 * 4 + wv) * 64 + lane] = acc3;
+    __syncthreads();
+    if (wv == 0) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int co = 4 * g + rr;
-        part[(row * 16 + co) * 27 + c] = acc[0][rr];
-        if (16 + c < 27) part[(row * 16 + co) * 27 + 16 + c] = acc[1][rr];
-        if (has3 && c == 11) part3[row * 16 + co] = acc3[rr];
+        for (int a = 0; a < 3; ++a) {
+            f32x4 t = red[(a * 4 + 0) * 64 + lane];
+            t += red[(a * 4 + 1) * 64 + lane]; t += red[(a * 4 + 2) * 64 + lane]; t += red[(a * 4 + 3) * 64 + lane];
+            if (a == 0) acc[0] = t; else if (a == 1) acc[1] = t; else acc3 = t;
+        }
+        // accumulator: lane (column c = tap within its tile, g) holds rows co = 4g .. 4g+3
+        const long row = blockIdx.x;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int co = 4 * g + rr;
+            part[(row * 16 + co) * 27 + c] = acc[0][rr];
+            if (16 + c < 27) part[(row * 16 + co) * 27 + 16 + c] = acc[1][rr];
+            if (has3 && c == 11) part3[row * 16 + co] = acc3[rr];
+        }
     }
 }
 
@@ -1862,7 +1877,7 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
             (!dy3 || (((uintptr_t)dy3 & 15) == 0 && (lddy3 & 7) == 0)) && (long)D * H * W < (1L << 31) && !getenv("UNETR_CONV_C1_OFF")) {
             long G = std::min<long>(1024, ntiles);
             if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) G = std::min<long>(G, atoi(e)); }
-            const long n1 = 27L * 16, n31 = dy3 ? 16 : 0, rows = G * 4;
+            const long n1 = 27L * 16, n31 = dy3 ? 16 : 0, rows = G;
             if (!ws || (size_t)rows * (n1 + n31) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
             float* wsb = ws + (size_t)rows * n1;
             hipLaunchKernelGGL(conv3_c1_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, st, (const float*)x, (const uint16_t*)dy, lddy, (const uint16_t*)dy3, lddy3,

@@ -110,10 +110,12 @@ def main():
 
 
 # The two feature sizes of BASELINE config[4] at 96^3 -- enc4 [4,128,12,12,12] ('feat' stage) and the logits-like [4,2,24,24,24]
-# -- through the reference's ContrastiveLoss / BTLoss (minutes of Python loops, once, here).  The inputs are NOT stored: they
-# are features(C, S, seed, float32) of this file, which the test regenerates (torch's CPU generator is deterministic); stored
-# are the loss and every 97th element of the input gradient.
-LARGE = ((128, 12, 2, "contrastive", 41), (2, 24, 4, "ranking", 42), (2, 24, 3, "contrastive", 43))
+# -- through the reference's BTLoss / ContrastiveLoss.  The inputs are NOT stored: they are features(C, S, seed, float32) of this
+# file, which the test regenerates (torch's CPU generator is deterministic).  BTLoss (576 terms): loss and every 97th element of
+# the input gradient.  ContrastiveLoss (576 x 577 cosine terms): its autograd graph at these sizes takes > 40 GB (the run was
+# killed at 37 GB), so it is executed WITHOUT a graph -- torch.no_grad() and Tensor.backward patched to a no-op around the
+# reference's unmodified function -- and only the loss value is stored.
+LARGE = ((128, 12, 2, "ranking", 41), (128, 12, 3, "contrastive", 44), (2, 24, 4, "ranking", 42), (2, 24, 3, "contrastive", 43))
 OUT_LARGE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ranking_ref_large.npz")
 GRAD_STRIDE = 97
 
@@ -122,20 +124,28 @@ def large(ns):
     out = {"temperature": np.float64(TEMPERATURE), "grad_stride": np.int64(GRAD_STRIDE),
            "cases": np.array([(C, S, ax, int(k == "contrastive"), seed) for C, S, ax, k, seed in LARGE], dtype=np.int64)}
     for i, (C, S, axis, kind, seed) in enumerate(LARGE):
-        feat = features(C, S, seed, torch.float32).to(torch.float64).requires_grad_(True)
+        with_grad = kind == "ranking"
+        feat = features(C, S, seed, torch.float32).to(torch.float64).requires_grad_(with_grad)
         f1, f2 = torch.split(feat, [2, 2], dim=0)
         part = int(S / 4)
         np.random.seed(seed)
         init_idx = int(np.random.choice(np.arange(0, part)))
         np.random.seed(seed)
-        with contextlib.redirect_stdout(io.StringIO()):
-            ref, sim, dis = ns["extract_triplets_more_partitions"](f1, f2, axis)
-            loss = ns["ContrastiveLoss" if kind == "contrastive" else "BTLoss"](ref, sim, dis, _NoOpOptimizer())
-        g = feat.grad.flatten()
+        saved_backward = torch.Tensor.backward
+        try:
+            if not with_grad:
+                torch.Tensor.backward = lambda self, *a, **k: None
+            with contextlib.redirect_stdout(io.StringIO()), torch.set_grad_enabled(with_grad):
+                ref, sim, dis = ns["extract_triplets_more_partitions"](f1, f2, axis)
+                loss = ns["ContrastiveLoss" if kind == "contrastive" else "BTLoss"](ref, sim, dis, _NoOpOptimizer())
+        finally:
+            torch.Tensor.backward = saved_backward
         out[f"c{i}_loss"] = np.float64(loss)
         out[f"c{i}_init_idx"] = np.int64(init_idx)
-        out[f"c{i}_grad_sub"] = g[::GRAD_STRIDE].numpy().astype(np.float32)
-        out[f"c{i}_grad_absmax"] = np.float64(g.abs().max())
+        if with_grad:
+            g = feat.grad.flatten()
+            out[f"c{i}_grad_sub"] = g[::GRAD_STRIDE].numpy().astype(np.float32)
+            out[f"c{i}_grad_absmax"] = np.float64(g.abs().max())
         print(f"large case {i}: C={C} S={S} axis={axis} {kind}: loss {float(loss):.6f}", flush=True)
     np.savez_compressed(OUT_LARGE, **out)
     print(f"-> {OUT_LARGE} ({os.path.getsize(OUT_LARGE) / 1024:.0f} KiB)")

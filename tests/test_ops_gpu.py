@@ -542,7 +542,8 @@ def test_ranking_losses(pkg, dev, kind, shape, slice_dim, init_idx):
     (this part of the reference is in-repo code, so its parity is pinned by the reference itself)."""
     from oracle.unetr_oracle import oracle_bt_loss, oracle_contrastive_loss, oracle_extract_triplets
     if kind == "contrastive" and shape[1] * shape[2] * shape[3] * shape[4] > 8 * 12 ** 3:
-        pytest.skip("the CPU oracle's 576 x 577-term Python loop takes minutes at this size; covered by the BT case")
+        pytest.skip("the CPU oracle's 576 x 577-term Python loop takes minutes at this size: these two sizes are held to outputs of "
+                    "the REFERENCE's own functions instead (test_ranking_losses_large_vs_reference_fixture)")
     T = 0.1 if kind == "ranking" else 0.5
     feat = g(*shape, seed=3) + 0.3
     fr = feat.clone().double().requires_grad_(True)
@@ -573,6 +574,34 @@ def test_ranking_losses_vs_reference_fixture(pkg, dev):
         assert relerr(fd.grad, grad) < 2e-4, key
         n += 1
     assert n == 12
+
+
+@pytest.mark.gpu
+def test_ranking_losses_large_vs_reference_fixture(pkg, dev):
+    """BASELINE config[4]'s two feature sizes at 96^3 -- enc4 [4,128,12,12,12] and the logits-like [4,2,24,24,24] -- against
+    tests/golden/ranking_ref_large.npz: outputs of the reference's own BTLoss / ContrastiveLoss
+    (unetr_ranking_pretraining_3d.py:202-236) executed by tests/golden/make_ranking_golden.py.  BT: loss and every 97th
+    element of the input gradient; contrastive: the loss (its autograd graph does not fit the build host at these sizes)."""
+    import os
+    import numpy as np
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(here, "ranking_ref_large.npz"))
+    spec = importlib.util.spec_from_file_location("make_ranking_golden", os.path.join(here, "make_ranking_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                     # (only its deterministic input generator `features` is used)
+    T, stride = float(z["temperature"]), int(z["grad_stride"])
+    for i, (C, S, axis, contrastive, seed) in enumerate(z["cases"].tolist()):
+        feat = gen.features(C, S, seed, torch.float32)
+        fd = feat.to(dev).requires_grad_(True)
+        loss = pkg.ranking_loss(fd, axis, int(z[f"c{i}_init_idx"]), T, kind="contrastive" if contrastive else "ranking")
+        ref = float(z[f"c{i}_loss"])
+        assert abs(loss.item() - ref) <= 5e-5 * abs(ref), (i, loss.item(), ref)
+        loss.backward()
+        assert torch.isfinite(fd.grad).all()
+        if f"c{i}_grad_sub" in z.files:
+            got = fd.grad.flatten()[::stride].cpu().numpy()
+            assert np.abs(got - z[f"c{i}_grad_sub"]).max() <= 3e-4 * float(z[f"c{i}_grad_absmax"]), i
 
 
 @pytest.mark.gpu

@@ -147,6 +147,33 @@ def test_ranking_oracle_pinned_by_reference_outputs():
     assert n == 12
 
 
+def test_ranking_oracle_pinned_at_config4_sizes():
+    """The Bradley-Terry cases of tests/golden/ranking_ref_large.npz (the reference's own BTLoss at BASELINE config[4]'s feature
+    sizes [4,128,12,12,12] and [4,2,24,24,24]): the oracle reproduces loss (1e-10, fp64) and the stored gradient samples.  (The
+    contrastive cases of that file are loss-only and cost the oracle's Python loop minutes: the HIP kernels are held to them in
+    tests/test_ops_gpu.py::test_ranking_losses_large_vs_reference_fixture.)"""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(here, "ranking_ref_large.npz"))
+    spec = importlib.util.spec_from_file_location("make_ranking_golden", os.path.join(here, "make_ranking_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    T, stride, n = float(z["temperature"]), int(z["grad_stride"]), 0
+    for i, (C, S, axis, contrastive, seed) in enumerate(z["cases"].tolist()):
+        if contrastive:
+            continue
+        f = gen.features(C, S, seed, torch.float32).double().requires_grad_(True)
+        f1, f2 = torch.split(f, [2, 2], dim=0)
+        r, s_, d = oracle_extract_triplets(f1, f2, axis, int(z[f"c{i}_init_idx"]))
+        loss = oracle_bt_loss(r, s_, d, T)
+        assert abs(loss.item() - float(z[f"c{i}_loss"])) <= 1e-10 * abs(float(z[f"c{i}_loss"])), i
+        loss.backward()
+        got = f.grad.flatten()[::stride].numpy()
+        assert np.abs(got - z[f"c{i}_grad_sub"]).max() <= 2e-7 * float(z[f"c{i}_grad_absmax"]), i
+        n += 1
+    assert n == 2
+
+
 def test_ranking_losses_triplet_structure():
     # unetr_ranking_pretraining_3d.py:59-133: 4 partitions x 12 ordered in-partition pairs x 12 other slices = 576;
     # the reference-pinned value checks are in test_ranking_oracle_pinned_by_reference_outputs above
