@@ -2,6 +2,7 @@
 // layout moves, patch gather, the 1x1x1 output conv (NCDHW logits) and fused AdamW.
 // All reductions are wave64 shuffle reductions + fixed-order partial buffers (bitwise reproducible).
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/unetr_hip.h"
 
@@ -1233,7 +1234,12 @@ static int adamw_launch(float* p, const void* g, int g_bf16, float gscale, float
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) return UNETR_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(g) & (g_bf16 ? 7 : 15)) return UNETR_ERR_ARG;
     long n4 = n >> 2;
-    dim3 grid(grid_for(std::max<long>(n4, 1), 256, 4096));
+    // grid cap: 4096 grid-stride workgroups fill every CU to its thread limit -- the right shape when AdamW runs alone, the wrong
+    // one when it runs on a side stream underneath a chain of short latency-bound kernels (they then wait for CU slots until the
+    // optimizer kernel has drained): UNETR_ADAMW_GRID limits the resident workgroups in that launch form
+    int cap = 4096;
+    if (const char* e = getenv("UNETR_ADAMW_GRID")) { const int v = atoi(e); if (v >= 64) cap = v; }
+    dim3 grid(grid_for(std::max<long>(n4, 1), 256, cap));
     if (g_bf16)
         hipLaunchKernelGGL(adamw_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g, gscale, m, v, n4, n, lr, beta1, beta2, eps,
                            weight_decay, step_dev, (uint16_t*)shadow_bf16);

@@ -52,7 +52,9 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (staged backward + per-pass all-reduce slots) on one rank")
     ap.add_argument("--overlap-update", type=int, default=0, help="N=1: AdamW per backward pass on a side-stream branch of the ONE captured graph "
                     "(measured SLOWER on MI355X / ROCm 7.2: 5.46 vs 5.00 ms per step -- a branch in a hipGraph costs more than the optimizer kernels it hides)")
-    ap.add_argument("--bf16-comm", action="store_true", help="all-reduce gradients in bf16 (default: fp32, the single-GPU arithmetic)")
+    ap.add_argument("--bf16-comm", action="store_true", help="all-reduce gradients in bf16 (the default when more than one rank runs in bf16 mode)")
+    ap.add_argument("--fp32-comm", action="store_true", help="all-reduce gradients in fp32 (the single-GPU arithmetic; twice the xGMI bytes: "
+                    "370 MB per step, more than the backward passes it has to hide under -- DESIGN.md section 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-oracle steps (after 3 warm-up steps; SURVEY 8d)")
@@ -166,7 +168,7 @@ def main():
 
     ddp_on = dist_on or args.force_dist
     if args.config == "c5":
-        out = run_c5(args, pkg, dev, rank, world)
+        out = run_c5(args, pkg, dev, rank, world, dist if dist_on else None)
     else:
         out = run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume)
     out["rccl_world"] = dist.get_world_size() if dist_on else 1
@@ -211,7 +213,10 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
         if flat is not None:
             flat["shadow"].copy_(flat["param"])         # (and the arena's bf16 shadow follows)
 
-    comm_dtype = torch.bfloat16 if (args.bf16_comm and args.precision == "bf16") else torch.float32
+    # gradient communication type: bf16 by default for real multi-rank runs in bf16 mode (185 MB per step instead of 370 MB: the
+    # fp32 form cannot hide under backward); fp32 on request and for the 1-rank --force-dist form
+    bf16_comm = args.precision == "bf16" and not args.fp32_comm and (args.bf16_comm or world > 1)
+    comm_dtype = torch.bfloat16 if bf16_comm else torch.float32
     graph_err = None
     try:
         step = pkg.TrainStep(model, crit, opt, x, y, use_graph=not args.no_graph, data_parallel=ddp_on, comm_dtype=comm_dtype,
@@ -285,7 +290,7 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
     return out
 
 
-def run_c5(args, pkg, dev, rank, world):
+def run_c5(args, pkg, dev, rank, world, dist=None):
     """BASELINE config[4]: one pre-training step of unetr_ranking_pretraining_3d.py:238-296 at 96^3 = for each of the
     three slice axes (:241) a 'feat' update (loss on enc4, :259-260) and a 'recon' update (loss on the logits with the
     encoder frozen, :261-262) on a [4, 1, 96^3] batch (2 volumes x 2 transforms) -- six forward/backward/AdamW passes."""
@@ -299,6 +304,21 @@ def run_c5(args, pkg, dev, rank, world):
     opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
     x, _ = synthetic_volume(4, 1, 96, 2, seed=1234 + rank)
     x = x.to(dev)
+    if dist is not None:
+        if flat is None:
+            raise SystemExit("the data-parallel pre-training step needs the flat arenas (drop --no-flat)")
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+        pkg.functional.invalidate_weight_shadows()
+        flat["shadow"].copy_(flat["param"])
+
+    def reduce_grads():
+        """data parallel (volumes are independent, the loss of a rank was divided by the world size): sum-all-reduce, in place,
+        of every contiguous arena run that received a gradient in this pass (the frozen-encoder passes touch the decoder only)"""
+        params = opt.param_groups[0]["params"]
+        pattern = tuple(p.grad is not None for p in params)
+        for _, _, lo, hi in opt._flat_runs(params, pattern):
+            dist.all_reduce(flat["grad"][lo:hi], op=dist.ReduceOp.SUM)
 
     def step():
         last = None
@@ -311,7 +331,11 @@ def run_c5(args, pkg, dev, rank, world):
                     _, inp = model(x, freeze_encoder=True)
                     init_idx = 7                           # logits are 96^3: partition size 24
                 loss = pkg.ranking_loss(inp, axis, init_idx, 0.1, kind="ranking")
-                loss.backward()
+                if dist is not None:
+                    (loss / world).backward()
+                    reduce_grads()
+                else:
+                    loss.backward()
                 opt.step()
                 opt.zero_grad(set_to_none=True)
                 last = loss
@@ -322,7 +346,7 @@ def run_c5(args, pkg, dev, rank, world):
     torch.cuda.synchronize()
     launch, graph_err = "eager launches", None
     run = step
-    if not args.no_graph and flat is not None:
+    if not args.no_graph and flat is not None and dist is None:      # (collectives are eager calls: N > 1 runs eagerly)
         # the six passes (each forward + loss + backward + AdamW, with its own gradient pattern) as ONE hipGraph
         try:
             side = pkg.train_step.side_stream(dev)
@@ -354,7 +378,9 @@ def run_c5(args, pkg, dev, rank, world):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "configs[4]: ranking pre-training, [4,1,96^3] batch, 3 slice axes x (feat + recon) = 6 "
-                                   f"fwd/BT-loss/bwd/AdamW passes per step, {launch}", "final_loss": float(loss.item()),
+                                   f"fwd/BT-loss/bwd/AdamW passes per step, {launch}"
+                                   + ("" if dist is None else ", gradients summed over ranks after every backward pass (fp32, in place)"),
+                       "final_loss": float(loss.item()),
                        "graph_capture_error": graph_err}}
 
 
