@@ -1692,7 +1692,12 @@ __global__ void __launch_bounds__(256) conv3_pack_grouped_kernel(PkArgs a, int S
         const long i = base + threadIdx.x + u * 256;
         if (i >= pr.total) break;
         float v = 0.f;
-        if (pr.kind <= 1) {
+        if (pr.kind == 4) {
+            // 2x2x2 transposed conv, tap-major GEMM operand: out[ci][tap][co] = w[ci][co][tap] (torch ConvTranspose3d layout
+            // [in, out, 2, 2, 2]); the problem's Cout field carries the layer's INPUT channels (dim 0 of w), Cin its output channels
+            const int tco = Cin, co = (int)(i % tco); const long t = i / tco; const int tap = (int)(t & 7); const long ci = t >> 3;
+            v = w[(ci * tco + co) * 8 + tap];
+        } else if (pr.kind <= 1) {
             const int mode = pr.kind, K = mode ? Cout : Cin, N = mode ? Cin : Cout;
             if (pr.pair) {
                 const int kk = (int)(i & 31); const long t = i >> 5; const int n = (int)(t % N), tp = (int)(t / N);
@@ -2000,7 +2005,14 @@ extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, 
         int blocks = 0;
         for (int i = 0; i < a.n; ++i) {
             const unetr_pack_problem& q = probs[base + i];
-            if (!q.w || !q.out || q.Cin <= 0 || q.Cout <= 0 || q.kind < 0 || q.kind > 3) return UNETR_ERR_ARG;
+            if (!q.w || !q.out || q.Cin <= 0 || q.Cout <= 0 || q.kind < 0 || q.kind > 4) return UNETR_ERR_ARG;
+            if (q.kind == 4) {       // transposed-conv tap-major pack: always bf16 (the operand of unetr_gemm_bf16)
+                if (prec != UNETR_PREC_BF16) return UNETR_ERR_UNSUPPORTED;
+                const long total4 = 8L * q.Cin * q.Cout;
+                a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, 4, 0, blocks, total4};
+                blocks += cdiv(total4, 2048);
+                continue;
+            }
             const int K = (q.kind == 0 || q.kind == 2) ? q.Cin : q.Cout, N = (q.kind == 0 || q.kind == 2) ? q.Cout : q.Cin;
             const int pair = (prec == UNETR_PREC_BF16 && q.kind != 3 && K <= 16 && conv_pipe_enabled()) ? 1 : 0;
             long total;

@@ -39,6 +39,14 @@ struct EpBf {
     float* pre;
     const float* aux; long ldaux;
     int act, accumulate; float alpha;
+    int tc_d, tc_h, tc_w, tc_cout;      // > 0: transposed-conv scatter of the bf16 output (see unetr_gemm_bf16_desc)
+    // element offset in Cb of (input voxel m, column n = tap * tc_cout + co)
+    __device__ __forceinline__ long tc_off(int m, int n) const {
+        const int tap = n / tc_cout, co = n - tap * tc_cout;
+        const int x = m % tc_w; int t = m / tc_w; const int y = t % tc_h; t /= tc_h; const int z = t % tc_d; const int b = t / tc_d;
+        const long ov = (((long)b * 2 * tc_d + 2 * z + (tap >> 2)) * 2 * tc_h + 2 * y + ((tap >> 1) & 1)) * 2 * tc_w + 2 * x + (tap & 1);
+        return ov * ldcb + co;
+    }
     __device__ __forceinline__ void store(int, int m, int n, float v) const {
         v *= alpha;
         if (bias) v += bias[n];
@@ -52,7 +60,7 @@ struct EpBf {
         }
         if (Cb) {
             __bf16 h = (__bf16)v;
-            Cb[(long)m * ldcb + n] = __builtin_bit_cast(uint16_t, h);
+            Cb[tc_cout ? tc_off(m, n) : (long)m * ldcb + n] = __builtin_bit_cast(uint16_t, h);
         }
     }
     // four consecutive columns n..n+3 of row m (n % 4 == 0, all pitches multiples of 4 checked by the host)
@@ -73,7 +81,7 @@ struct EpBf {
             if (accumulate) v += *(const f32x4*)(C + (long)m * ldc + n);
             *(f32x4*)(C + (long)m * ldc + n) = v;
         }
-        if (Cb) *(bf16x4*)(Cb + (long)m * ldcb + n) = __builtin_convertvector(v, bf16x4);
+        if (Cb) *(bf16x4*)(Cb + (tc_cout ? tc_off(m, n) : (long)m * ldcb + n)) = __builtin_convertvector(v, bf16x4);
     }
 };
 
@@ -640,8 +648,11 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
     const int vec_ok = (N % 4 == 0) && (!C || (d->ldc % 4 == 0 && al16(C))) && (!Cb || (d->ldcb % 4 == 0 && ((uintptr_t)Cb & 7) == 0)) &&
                        (!d->bias || al16(d->bias)) && (!d->res || (d->ldr % 4 == 0 && al16(d->res))) && (!d->pre || al16(d->pre)) &&
                        (!d->aux || (d->ldaux % 4 == 0 && al16(d->aux))) && al16(ws);
+    // transposed-conv scatter: bf16 output only, whole 4-column groups inside one tap, rows = voxels of the input grid
+    if (d->tc_cout > 0 && (C || !Cb || d->pre || d->accumulate || d->tc_cout % 4 || N != 8 * d->tc_cout || d->tc_d <= 0 || d->tc_h <= 0 ||
+                           d->tc_w <= 0 || M % (d->tc_d * d->tc_h * d->tc_w))) return UNETR_ERR_UNSUPPORTED;
     EpBf ep{vec_ok, C, d->ldc, (uint16_t*)Cb, d->ldcb, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : M,
-            d->pre, d->aux, d->ldaux, d->act, d->accumulate, d->alpha};
+            d->pre, d->aux, d->ldaux, d->act, d->accumulate, d->alpha, d->tc_d, d->tc_h, d->tc_w, d->tc_cout > 0 ? d->tc_cout : 0};
     const uint16_t* a = (const uint16_t*)A;
     const uint16_t* b = (const uint16_t*)B;
     const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hooks
@@ -649,7 +660,7 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
     const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
     // the 256 x 256 ping-pong kernel: many rows, weights as stored ([N, K]); K tiles of 64 (checked above).  Narrow outputs
     // (N = 768 at 6912 rows: 81 tiles for 256 CUs) keep the 128 x 128 tile, which fills the chip
-    if (!d->b_kn && (env_cfg == 256 || (env_cfg == 0 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 256) >= 160)))
+    if (!d->b_kn && d->tc_cout <= 0 && (env_cfg == 256 || (env_cfg == 0 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 256) >= 160)))
         return launch_bf16_big(M, N, K, a, d->lda, b, d->ldb, ep, st);
 #define BF16_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st, psp)
     // Small token counts (batch 2: M = 432).  Measured per launch on MI355X (tools/probe_encoder.py, us incl. launch boundary):

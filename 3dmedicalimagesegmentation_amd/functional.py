@@ -282,7 +282,7 @@ def cast_bf16(src, out=None):
 
 
 def gemm_bf16(A, B, M, N, K, *, b_kn=False, C=None, Cb=None, lda=None, ldb=None, bias=None, res=None, ldr=0, res_mod=0,
-              pre=None, aux=None, ldaux=0, act=0, accumulate=False, alpha=1.0):
+              pre=None, aux=None, ldaux=0, act=0, accumulate=False, alpha=1.0, ldcb=None, tc=None):
     """C / Cb [M,N] = epilogue(A[M,K] @ (B[N,K]^T | B[K,N])) with bf16-stored operands (csrc/gemm_bf16.hip)"""
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     d = GemmBf16Desc()
@@ -290,6 +290,10 @@ def gemm_bf16(A, B, M, N, K, *, b_kn=False, C=None, Cb=None, lda=None, ldb=None,
     d.lda = lda if lda is not None else K
     d.ldb = ldb if ldb is not None else (N if b_kn else K)
     d.ldc = d.ldcb = N
+    if ldcb is not None:
+        d.ldcb = ldcb
+    if tc is not None:              # (D, H, W, Cout): scatter the bf16 output as a 2x2x2 transposed conv (tap-major columns)
+        d.tc_d, d.tc_h, d.tc_w, d.tc_cout = tc
     d.bias = bias.data_ptr() if bias is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.ldr, d.res_mod = ldr, res_mod
@@ -422,8 +426,11 @@ def conv_pack_get(w, kind, prec):
     cout, cin = w.shape[0], w.shape[1]
     if ent is None or ent[4]() is not w or ent[0].device != w.device:
         lib = _capi.load()
-        nbytes = lib.unetr_conv3_packed_bytes(cin, cout, kind, prec) if kind <= 1 else (
-            lib.unetr_conv3_packed_1x1_bytes(cin, cout, prec) if kind == 2 else lib.unetr_conv3_packed_1x1_bytes(cout, cin, prec))
+        if kind == 4:          # transposed conv [in, out, 2, 2, 2] -> bf16 [in][tap][out]
+            nbytes = w.numel() * 2
+        else:
+            nbytes = lib.unetr_conv3_packed_bytes(cin, cout, kind, prec) if kind <= 1 else (
+                lib.unetr_conv3_packed_1x1_bytes(cin, cout, prec) if kind == 2 else lib.unetr_conv3_packed_1x1_bytes(cout, cin, prec))
         ent = [torch.empty(nbytes, dtype=torch.uint8, device=w.device), -1, -1, False, weakref.ref(w), 0]
         _PACKS[key] = ent
     fresh = ent[1] == w._version and ent[5] == w.data_ptr() and (
@@ -894,6 +901,13 @@ def tconv_fwd(x, ldx, w, dims, cin, cout, prec, out=None, ldo=None):
     M = B * D * H * W
     if _tconv_as_gemm(prec, M, cin, cout, ldx):
         xb = _twin(x).view(M, cin)             # (a bf16 feature map is its own operand; tokens bring their bf16 twin)
+        if out.dtype == torch.bfloat16 and cout % 4 == 0 and ldo % 4 == 0 and os.environ.get("UNETR_AMD_TCONV_SCATTER", "1") != "0":
+            # tap-major weight pack [Cin][tap][Cout] (re-packed with the conv weights after every update): the GEMM's epilogue
+            # writes each (voxel, tap) row of Cout channels straight to its output voxel -- no fp32 [M, 8 Cout] intermediate, no
+            # pixel-shuffle launch
+            wp = conv_pack_get(w, 4, prec).view(torch.bfloat16)
+            gemm_bf16(xb, wp, M, 8 * cout, cin, b_kn=True, Cb=out, ldcb=ldo, tc=(D, H, W, cout))
+            return out, xb
         tmp = torch.empty(M, 8 * cout, dtype=torch.float32, device=x.device)
         gemm_bf16(xb, weight_bf16(w).view(cin, 8 * cout), M, 8 * cout, cin, b_kn=True, C=tmp)
         call("unetr_pixel_shuffle2", tmp.data_ptr(), out.data_ptr(), ldo, B, D, H, W, cout, _a16(out), _stream())

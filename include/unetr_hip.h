@@ -33,7 +33,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 4
+#define UNETR_ABI_VERSION 5
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -81,6 +81,11 @@ typedef struct {
     int act;
     int accumulate;
     float alpha;
+    /* tc_cout > 0: the output is a 2x2x2 stride-2 ConvTranspose3d result scattered in place (UnetrPrUpBlock / UnetrUpBlock,
+     * unetr.py:99-174): row m is voxel (b, z, y, x) of the INPUT grid [*, tc_d, tc_h, tc_w], column n = tap * tc_cout + co (the
+     * tap-major weight pack, kind 4 of unetr_conv3_pack_grouped), and the value goes to Cb[outvox(m, tap) * ldcb + co] with
+     * outvox = (b, 2z + tap/4, 2y + (tap/2)%2, 2x + tap%2) of the output grid.  bf16 output only (C and pre NULL). */
+    int tc_d, tc_h, tc_w, tc_cout;
 } unetr_gemm_bf16_desc;
 int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
                     float* ws, size_t ws_bytes, void* stream);
