@@ -86,6 +86,30 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
+// The same two functions for the bf16-storage epilogues (EpBf: GELU output rounded to bf16, relative spacing 4e-3): libm's erff
+// is ~45 instructions with a branch -- 96-128 calls per thread in a 256-wide GEMM tile cost 6-12 us of a 30 us launch -- so erf
+// comes from Abramowitz & Stegun 7.1.26 (one v_rcp, one v_exp, five fmas): |error| <= 5.3e-7 on erf in fp32 arithmetic (checked
+// over [-8, 8]), i.e. <= 2e-7 absolute on GELU and GELU' -- four orders of magnitude below the bf16 rounding of what is stored.
+// exp(-x^2 / 2) is shared between the erf tail and the Gaussian density of GELU'.  The fp32 precision mode keeps erff (EpStd).
+__device__ __forceinline__ float erf_poly_tail(float t /* |x| / sqrt(2) */, float e /* exp(-t^2) */) {
+    const float k = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * t);
+    float p = 1.061405429f;
+    p = fmaf(p, k, -1.453152027f); p = fmaf(p, k, 1.421413741f); p = fmaf(p, k, -0.284496736f); p = fmaf(p, k, 0.254829592f);
+    return 1.0f - p * k * e;                      // erf(t), t >= 0
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float t = fabsf(x) * 0.70710678118654752440f;
+    const float e = __expf(-t * t);
+    const float er = copysignf(erf_poly_tail(t, e), x);
+    return 0.5f * x * (1.0f + er);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float t = fabsf(x) * 0.70710678118654752440f;
+    const float e = __expf(-t * t);               // = exp(-x^2 / 2)
+    const float er = copysignf(erf_poly_tail(t, e), x);
+    return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- activation storage type of the conv side: fp32 (fp32 precision mode) or bf16 (bf16 precision mode: every feature map

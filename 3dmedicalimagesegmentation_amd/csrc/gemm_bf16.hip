@@ -51,8 +51,8 @@ struct EpBf {
         v *= alpha;
         if (bias) v += bias[n];
         if (pre) pre[(long)m * ldc + n] = v;
-        if (act == 1) v = gelu_exact(v);
-        else if (act == 2) v *= gelu_grad(aux[(long)m * ldaux + n]);
+        if (act == 1) v = gelu_fast(v);
+        else if (act == 2) v *= gelu_grad_fast(aux[(long)m * ldaux + n]);
         if (res) v += res[(long)(m % res_mod) * ldr + n];
         if (C) {
             if (accumulate) v += C[(long)m * ldc + n];
@@ -70,11 +70,11 @@ struct EpBf {
         if (pre) *(f32x4*)(pre + (long)m * ldc + n) = v;
         if (act == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
         } else if (act == 2) {
             const f32x4 a = *(const f32x4*)(aux + (long)m * ldaux + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(a[e]);
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(a[e]);
         }
         if (res) v += *(const f32x4*)(res + (long)(m % res_mod) * ldr + n);
         if (C) {
@@ -295,11 +295,16 @@ int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t
 template <int BUF>
 struct BufC { static constexpr int value = BUF; };
 
+// WN = 16-column MFMA tiles per wave: the tile is 256 rows x 64 WN columns (256 / 192 / 128).  Narrower tiles exist for the
+// tile COUNT: [6912 x 3072] is 324 tiles of 256 x 256 (two rounds of 256 CUs, the second 27 % full) but 432 of 256 x 192, and
+// N = 768 is 81 / 162 tiles at WN 4 / 2.  The B region of a K tile is 64 WN rows = WN DMA pieces per thread.
+template <int WN>
 __global__ void __launch_bounds__(512, 2)
 gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
                      const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep) {
-    constexpr int NT = 512, HALF = 128 * 128, BUFB = 4 * HALF;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * BUFB];
+    constexpr int NT = 512, HALF = 128 * 128, BN = 64 * WN, BUFB = 2 * HALF + BN * 128;
+    constexpr int LDSB = 2 * BUFB > 8 * 16384 ? 2 * BUFB : 8 * 16384;      // (the epilogue stages 16 KB per wave)
+    __shared__ __attribute__((aligned(1024))) char lds[LDSB];
 
     // tile order: workgroup L runs on XCD L % 8; an XCD gets a contiguous run of tiles, fastest along the operand whose re-use
     // saves more traffic (n_fast: the run shares A rows and walks the weight columns; else the other way round)
@@ -310,26 +315,36 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
         if ((L >> 3) >= per || t >= T) return;
         if (n_fast) { tn = t % nt; tm = t / nt; } else { tm = t % mt; tn = t / mt; }
     }
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * 256, n0 = tn * BN;
     const int nk = K / 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
 
-    // DMA sources: piece i (0, 1) of half-tile h covers rows (tid + i * 512) >> 3 of the half, chunk (id & 7) ^ ((r >> 1) & 7)
+    // DMA sources: piece i of a region covers row (tid + i * 512) >> 3 of the region, chunk (id & 7) ^ ((r >> 1) & 7).  A: two
+    // half-tiles of 128 rows (2 pieces each); B: one region of BN rows (WN pieces)
     const uint16_t* asrc[2][2];
-    const uint16_t* bsrc[2][2];
+    const uint16_t* bsrc[WN];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * NT, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
             asrc[h][i] = A + (long)min(m0 + h * 128 + r, M - 1) * lda + c * 8;
-            bsrc[h][i] = B + (long)min(n0 + h * 128 + r, N - 1) * ldb + c * 8;
         }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+        const int id = tid + i * NT, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
+        bsrc[i] = B + (long)min(n0 + r, N - 1) * ldb + c * 8;
+    }
     auto dma = [&](const uint16_t* const (&src)[2], int T, char* dst) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + (long)T * 64), (lds_void_t*)(dst + (wave * 64 + i * NT) * 16), 16, 0, 0);
+    };
+    auto dmab = [&](int T, char* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WN; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[i] + (long)T * 64), (lds_void_t*)(dst + (wave * 64 + i * NT) * 16), 16, 0, 0);
     };
     // fragment read offsets inside a half-tile: row (tile * 16 + lane & 15), 16-byte chunk kh * 4 + (lane >> 4), swizzled; the
     // swizzle term does not depend on the tile index, so a tile is a constant 2048-byte step
@@ -337,21 +352,19 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) off[kh] = lds_tile_off(lane & 15, kh * 4 + (lane >> 4));
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][WN];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4 af[4][2], bf[4][2];
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 af[4][2], bf[WN][2];
     // prologue: tile 0 whole, B of tile 1; tile 0 must have landed (and be published by the barrier) before the first read
     dma(asrc[0], 0, lds);
     dma(asrc[1], 0, lds + HALF);
-    dma(bsrc[0], 0, lds + 2 * HALF);
-    dma(bsrc[1], 0, lds + 3 * HALF);
+    dmab(0, lds + 2 * HALF);
     if (nk > 1) {
-        dma(bsrc[0], 1, lds + BUFB + 2 * HALF);
-        dma(bsrc[1], 1, lds + BUFB + 3 * HALF);
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        dmab(1, lds + BUFB + 2 * HALF);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WN) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -360,12 +373,12 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
 
 #define BIG_MEM_END() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define BIG_CMP_END(last_) do { __builtin_amdgcn_sched_barrier(0); if (!(last_)) asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define BIG_QUAD(qa_, qb_) do {                                                                      \
+#define BIG_HALF(qa_) do {                                                                           \
         __builtin_amdgcn_s_setprio(1);                                                               \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
-                    PrecBF16::mma(acc[(qa_) * 4 + i][(qb_) * 2 + j], bf[(qb_) * 2 + j][kh], af[i][kh]); \
+                _Pragma("unroll") for (int j = 0; j < WN; ++j)                                       \
+                    PrecBF16::mma(acc[(qa_) * 4 + i][j], bf[j][kh], af[i][kh]);                      \
         __builtin_amdgcn_s_setprio(0);                                                               \
     } while (0)
 
@@ -374,7 +387,7 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
         char* const cur = lds + b * BUFB;
         char* const oth = lds + (b ^ 1) * BUFB;
         const char* la = cur + wr * HALF;                                    // this wave's 128 A rows
-        const char* lb = cur + (2 + (wc >> 1)) * HALF + (wc & 1) * 64 * 128;   // this wave's 64 B rows
+        const char* lb = cur + 2 * HALF + wc * (16 * WN) * 128;              // this wave's 16 WN B rows
         const bool n1 = T + 1 < nk, n2 = T + 2 < nk;
         {
             // two phases of 32 MFMAs (half the barriers): P0 reads all of B and A rows 0-63 and issues both A halves of tile T+1,
@@ -382,7 +395,7 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j][kh] = *(const u32x4*)(lb + off[kh] + j * 2048);
+                for (int j = 0; j < WN; ++j) bf[j][kh] = *(const u32x4*)(lb + off[kh] + j * 2048);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -392,8 +405,7 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
             }
             if (n1) { dma(asrc[0], T + 1, oth); dma(asrc[1], T + 1, oth + HALF); }
             BIG_MEM_END();
-            BIG_QUAD(0, 0);
-            BIG_QUAD(0, 1);
+            BIG_HALF(0);
             BIG_CMP_END(false);
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
@@ -401,15 +413,13 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
                 for (int i = 0; i < 4; ++i) af[i][kh] = *(const u32x4*)(la + off[kh] + (4 + i) * 2048);
             }
             if (n2) {
-                dma(bsrc[0], T + 2, cur + 2 * HALF);
-                dma(bsrc[1], T + 2, cur + 3 * HALF);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                dmab(T + 2, cur + 2 * HALF);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN) : "memory");
             } else if (n1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             BIG_MEM_END();
-            BIG_QUAD(1, 0);
-            BIG_QUAD(1, 1);
+            BIG_HALF(1);
             BIG_CMP_END(!n1 && wr == 1);        // group 1 skips its very last barrier: both groups execute the same number
         }
     };
@@ -419,19 +429,19 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
     }
 #undef BIG_MEM_END
 #undef BIG_CMP_END
-#undef BIG_QUAD
+#undef BIG_HALF
 
     // accumulator tile = C^T (swapped MFMA operands): lane (c, g) holds C[m = tile row c][n = 4g .. 4g+3].  The epilogue kind is
     // chosen ONCE (a 32-tile loop over the general store4 is too large to unroll: the accumulators would go through scratch)
-    const int mb = m0 + wr * 128 + (lane & 15), nb = n0 + wc * 64 + 4 * (lane >> 4);
+    const int mb = m0 + wr * 128 + (lane & 15), nb = n0 + wc * (16 * WN) + 4 * (lane >> 4);
     if (!ep.vec_ok) {
-        for (int t = 0; t < 32; ++t) {
-            const int i = t >> 2, j = t & 3, m = mb + i * 16, n = nb + j * 16;
+        for (int t = 0; t < 8 * WN; ++t) {
+            const int i = t / WN, j = t - i * WN, m = mb + i * 16, n = nb + j * 16;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma clang loop unroll(full)
             for (int ii = 0; ii < 8; ++ii)
 #pragma clang loop unroll(full)
-                for (int jj = 0; jj < 4; ++jj) v = (ii == i && jj == j) ? acc[ii][jj] : v;
+                for (int jj = 0; jj < WN; ++jj) v = (ii == i && jj == j) ? acc[ii][jj] : v;
             if (m < M)
                 for (int r = 0; r < 4; ++r)
                     if (n + r < N) ep.store(0, m, n + r, v[r]);
@@ -448,15 +458,16 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
     const int kind = (ep.act == 1 ? 1 : ep.act == 2 ? 2 : 0);
     char* const stg = lds + wave * 16384;
     const int rr = lane >> 4, rc = lane & 15;                 // read-back: row within a group of 4, 16-byte chunk
-    const int ncol = n0 + wc * 64 + rc * 4;
+    const int ncol = n0 + wc * (16 * WN) + rc * 4;
+    const bool cok = rc < 4 * WN && ncol < N;                 // this lane's 16-byte chunk exists (WN < 4: chunks 4 WN .. 15 are unused)
     f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ep.bias && ncol < N) bias4 = *(const f32x4*)(ep.bias + ncol);
+    if (ep.bias && cok) bias4 = *(const f32x4*)(ep.bias + ncol);
     auto half = [&](auto kc, auto hc) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kc)::value, h = decltype(hc)::value;
 #pragma clang loop unroll(full)
         for (int i = 0; i < 4; ++i)
 #pragma clang loop unroll(full)
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < WN; ++j) {
                 const int r = i * 16 + (lane & 15), ch = j * 4 + (lane >> 4);
                 *(f32x4*)(stg + r * 256 + ((ch ^ (r & 7)) << 4)) = acc[h * 4 + i][j] * ep.alpha;
             }
@@ -465,15 +476,15 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
         for (int it = 0; it < 16; ++it) {
             const int r = it * 4 + rr, m = m0 + wr * 128 + h * 64 + r;
             f32x4 v = *(const f32x4*)(stg + r * 256 + ((rc ^ (r & 7)) << 4)) + bias4;
-            if (m < M && ncol < N) {
+            if (m < M && cok) {
                 if (ep.pre) *(f32x4*)(ep.pre + (long)m * ep.ldc + ncol) = v;
                 if constexpr (KIND == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                 } else if constexpr (KIND == 2) {
                     const f32x4 a = *(const f32x4*)(ep.aux + (long)m * ep.ldaux + ncol);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad(a[e]);
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(a[e]);
                 }
                 if (ep.res) v += *(const f32x4*)(ep.res + (long)(m % ep.res_mod) * ep.ldr + ncol);
                 if (ep.C) {
@@ -490,16 +501,37 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
     else { half(BufC<0>{}, BufC<0>{}); half(BufC<0>{}, BufC<1>{}); }
 }
 
-static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep, hipStream_t st) {
-    const int mt = cdiv(M, 256), nt = cdiv(N, 256);
+static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep, hipStream_t st, int wn) {
+    const int BN = 64 * wn;
+    const int mt = cdiv(M, 256), nt = cdiv(N, BN);
     const long tiles = (long)mt * nt;
     // traffic of the two tile orders, in rows of K elements fetched per XCD pass: m fastest re-reads A for every weight column
     // tile an XCD touches (up to 8 XCDs share the grid), n fastest re-reads the weights
     const long cost_m = (long)M * std::min(8, nt) + N, cost_n = M + (long)N * std::min(8, mt);
     const int n_fast = cost_n < cost_m;
     const int per = cdiv(tiles, 8);
-    hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3(per * 8), dim3(512), 0, st, M, N, K, mt, nt, n_fast, A, lda, B, ldb, ep);
+#define BIG_GO(W_) hipLaunchKernelGGL(gemm_bf16_big_kernel<W_>, dim3(per * 8), dim3(512), 0, st, M, N, K, mt, nt, n_fast, A, lda, B, ldb, ep)
+    if (wn == 2) BIG_GO(2); else if (wn == 3) BIG_GO(3); else BIG_GO(4);
+#undef BIG_GO
     return unetr_check_launch();
+}
+
+// which large-tile width (columns = 64 wn) serves [M, N]: the one with the least estimated time = rounds of 256 CUs x time of one
+// tile (K-loop share ~ wn + 1: MFMAs scale with wn, the A half of the DMA and the fragment reads do not; + a fixed prologue /
+// epilogue share).  0 = the 128 x 128 family (too few large tiles to fill the chip).
+static int big_tile_width(int M, int N, int K) {
+    if (const char* e = getenv("UNETR_GEMM_BIG_WN")) { const int v = atoi(e); if (v >= 2 && v <= 4) return v; }
+    int best = 0; double best_t = 1e30;
+    for (int wn = 4; wn >= 2; --wn) {
+        const long tiles = (long)cdiv(M, 256) * cdiv(N, 64 * wn);
+        if (tiles < 128) continue;
+        // (measured at 6912 rows: the 128-wide tile beats the 128 x 128 family only on long reductions -- N = 768: K = 4096
+        // 60 vs 68 us, K = 3072 62 vs 62, K = 768 34 vs 30)
+        if (wn == 2 && K < 2048) continue;
+        const double t = (double)cdiv(tiles, 256) * (wn + 1.5);
+        if (t < best_t - 1e-9) { best_t = t; best = wn; }
+    }
+    return best;
 }
 
 // ---- grouped weight-gradient GEMM on bf16-stored operands: dW_i[N_i, K_i] = dY_i[M, N_i]^T * X_i[M, K_i] ------------------
@@ -660,8 +692,10 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
     const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
     // the 256 x 256 ping-pong kernel: many rows, weights as stored ([N, K]); K tiles of 64 (checked above).  Narrow outputs
     // (N = 768 at 6912 rows: 81 tiles for 256 CUs) keep the 128 x 128 tile, which fills the chip
-    if (!d->b_kn && d->tc_cout <= 0 && (env_cfg == 256 || (env_cfg == 0 && M >= 1024 && (long)cdiv(M, 256) * cdiv(N, 256) >= 160)))
-        return launch_bf16_big(M, N, K, a, d->lda, b, d->ldb, ep, st);
+    if (!d->b_kn && d->tc_cout <= 0 && (env_cfg == 256 || (env_cfg == 0 && M >= 1024))) {
+        const int wn = env_cfg == 256 ? (getenv("UNETR_GEMM_BIG_WN") ? big_tile_width(M, N, K) : 4) : big_tile_width(M, N, K);
+        if (wn) return launch_bf16_big(M, N, K, a, d->lda, b, d->ldb, ep, st, wn);
+    }
 #define BF16_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_>(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, st, psp)
     // Small token counts (batch 2: M = 432).  Measured per launch on MI355X (tools/probe_encoder.py, us incl. launch boundary):
     //   forward, K = 768:   N = 768: 64x32 5.6 < 32x64 5.7 < 64x64 7.1;  N = 2304: 64x64 6.6 < 64x96 7.5 < 64x128 9.1;

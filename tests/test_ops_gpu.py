@@ -60,16 +60,19 @@ def test_gemm_bf16_storage(pkg, dev, M, N, K):
         assert relerr(dx, (dy.double() @ w.double()).float()) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K,force", [(6912, 2304, 768, False), (6912, 3072, 768, False), (1030, 520, 192, True), (1024, 512, 64, True),
-                                         (2100, 772, 128, True), (1500, 1026, 320, True), (300, 256, 3072, True)])
+@pytest.mark.parametrize("M,N,K,force", [(6912, 2304, 768, 0), (6912, 3072, 768, 0), (6912, 768, 3072, 0), (1030, 520, 192, 4), (1024, 512, 64, 4),
+                                         (2100, 772, 128, 4), (1500, 1026, 320, 4), (300, 256, 3072, 4), (1030, 520, 192, 3), (2100, 772, 128, 3),
+                                         (1500, 1026, 320, 2), (1024, 384, 64, 3), (1300, 130, 256, 2)])
 def test_gemm_bf16_big_tile(pkg, dev, monkeypatch, M, N, K, force):
-    """The 256 x 256 ping-pong kernel (8 waves, two groups one barrier interval apart, LDS-DMA into half-tile regions): picked by
-    itself at encoder shapes of batch 32 (243 / 324 tiles), forced (UNETR_GEMM_CFG=256) on ragged shapes -- M / N tails, 1 / 2 / 3 /
+    """The 256 x {256, 192, 128} ping-pong kernel (8 waves, two groups one barrier interval apart, LDS-DMA into half-tile regions):
+    picked by itself at encoder shapes of batch 32 (N = 2304 / 3072 / 768 -> tile widths 256 / 192 / 128), forced (UNETR_GEMM_CFG=256,
+    UNETR_GEMM_BIG_WN) on ragged shapes -- M / N tails, 1 / 2 / 3 /
     5 / 48 K tiles (odd and even counts walk both LDS buffers), N % 4 != 0 (scalar epilogue) -- with every epilogue kind,
     against fp64 products of the same bf16 inputs."""
     Fn = pkg.functional
-    if force:
+    if force:                       # force = columns / 64 of the tile (256 x 256 / 192 / 128); 0 = the dispatcher's own choice
         monkeypatch.setenv("UNETR_GEMM_CFG", "256")
+        monkeypatch.setenv("UNETR_GEMM_BIG_WN", str(force))
     L = 206 if M == 1030 else M
     x, w = g(M, K, seed=1).bfloat16(), g(N, K, seed=2, scale=0.1).bfloat16()
     b, res, aux = g(N, seed=3), g(L, N, seed=4), g(M, N, seed=6)

@@ -50,13 +50,16 @@ def main():
         ("mlp2  N=768  K=3072 (+bias, res, fp32 out)", 2 * M * H * MLP, lambda: Fn.gemm_bf16(hb, w["w2"], M, H, MLP, C=x1, bias=bias1, res=x, ldr=H)),
         ("patch N=768  K=4096 (+bias, fp32 out)", 2 * M * H * 4096, lambda: Fn.gemm_bf16(pb, w["pe"], M, H, 4096, C=x1, bias=bias1)),
     ]
-    for cfg in os.environ.get("PROBE_CFGS", "0,128,256").split(","):
+    for cfg in os.environ.get("PROBE_CFGS", "0,128,256:4,256:3,256:2").split(","):
         os.environ.pop("UNETR_GEMM_CFG", None)
+        os.environ.pop("UNETR_GEMM_BIG_WN", None)
         if cfg != "0":
-            os.environ["UNETR_GEMM_CFG"] = cfg
+            os.environ["UNETR_GEMM_CFG"] = cfg.split(":")[0]
+            if ":" in cfg:
+                os.environ["UNETR_GEMM_BIG_WN"] = cfg.split(":")[1]
         for name, flops, fn in cases:
             us = timeit(fn)
-            print(f"cfg {cfg:>4}  {us:8.2f} us  {flops / us / 1e6:8.1f} TFLOP/s  {name}", flush=True)
+            print(f"cfg {cfg:>5}  {us:8.2f} us  {flops / us / 1e6:8.1f} TFLOP/s  {name}", flush=True)
 
 
 if __name__ == "__main__":
