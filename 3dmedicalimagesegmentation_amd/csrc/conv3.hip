@@ -1155,7 +1155,13 @@ template <class P, bool HAS3 = false, int CIS = 2> struct WgCfg {
 #ifndef WG_LB
 #define WG_LB 2
 #endif
-template <class P, int XMX, bool VECY, bool HAS3, int CIS, bool PIPE_OK>
+template <int V> struct IntC { static constexpr int value = V; };
+// NSL = 16-channel input slabs per workgroup (1 or 2; 2 only on the bf16 / conflict-free-layout / planned-staging path): the dy
+// (and dy3) tile is staged ONCE per voxel tile and serves both slabs -- with one slab per workgroup the 32-channel layers staged it
+// twice, the 64-channel ones four times (PMC: 1.73x the algorithmic bytes for the family).  Per tile: window of slab 0 + dy ->
+// MFMAs of slab 0 (the window of slab 1 in flight) -> window of slab 1 over the same image -> MFMAs of slab 1 (the next tile's
+// slab-0 window + dy in flight); two accumulator sets.
+template <class P, int XMX, bool VECY, bool HAS3, int CIS, bool PIPE_OK, int NSL = 1>
 __global__ void __launch_bounds__(256, CIS == 1 ? ((HAS3 && !WgCfg<P, HAS3, CIS>::FLIP) ? 2 : WG_LB) : 1)   // CIS = 1: WG_LB workgroups per CU
 conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>::type* __restrict__ dy, long lddy, float* __restrict__ part,
                    const typename ActOf<P>::type* __restrict__ dy3, long lddy3, float* __restrict__ part3,
@@ -1172,7 +1178,8 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     char* y3img = yimg + NVOX * C::PY;
     constexpr int nunits = C::NUX;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, g = lane >> 4;
-    const int ci0 = blockIdx.y * 16 * CIS, co0 = blockIdx.z * 16;
+    static_assert(NSL == 1 || (CIS == 1 && PIPE_OK && XMX == 2 && sizeof(typename ElemOf<P>::type) == 2), "two slabs: fast path only");
+    const int ci0 = blockIdx.y * 16 * CIS * NSL, co0 = blockIdx.z * 16;
     // per-unit LDS byte offsets of the shifted window (wave-uniform)
     // FLIP layout: the column part of the address is per lane AND per tap column dx (the LAY 2 permutation is not a shift):
     // the three candidates of this lane's two voxel rows are formed once (they do not depend on the k-block: v & 15 is
@@ -1207,9 +1214,11 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
         ylane0 = lay_flip(8 * g + q) * C::PY + 8 * p;
         ylane1 = lay_flip(8 * g + q + 4) * C::PY + 8 * p;
     }
-    f32x4 acc[WG_UPW];
+    f32x4 acc[NSL][WG_UPW];
 #pragma unroll
-    for (int ui = 0; ui < WG_UPW; ++ui) acc[ui] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int ui = 0; ui < WG_UPW; ++ui) acc[sl][ui] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // dy tile(s): 256 voxels x 16 channels
     constexpr int YCH = 16 / CH, YIT = NVOX * YCH / 256, NQ = CH / 4;
@@ -1285,9 +1294,11 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     }
     const long xitem = (long)D * H * W * ldx;
     // window + dy tile(s) of tile (b_, z_, y_, x_) into the prefetch registers
-    auto tile_load = [&](int b_, int z_, int y_, int x_) {
+    auto tile_load = [&](int b_, int z_, int y_, int x_, int c0_ = -1, bool with_dy = true) {
+        if (c0_ < 0) c0_ = ci0;
         if constexpr (PLAN) {
-            halo_load_planned<P, 16 / CH>(R, xplan, (const uint16_t*)x + b_ * xitem, (int)ldx, z_, y_, x_, D, H, W, ci0, Cin);
+            halo_load_planned<P, 16 / CH>(R, xplan, (const uint16_t*)x + b_ * xitem, (int)ldx, z_, y_, x_, D, H, W, c0_, Cin);
+            if (!with_dy) return;
             const bool interior = z_ + TZ <= D && y_ + TY <= H && x_ + TX <= W && co0 + 16 <= Cout;      // wave-uniform
             const long vb = (((long)b_ * D + z_) * H + y_) * W + x_;
             const GT* __restrict__ pdy = dy + vb * lddy;
@@ -1333,7 +1344,8 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
             }
             __syncthreads();
             const int nt = tile + gridDim.x;
-            if (nt < ntiles) tile_load(ab, az * TZ, ay * TY, ax * TX);
+            if constexpr (NSL == 2) tile_load(b, z0, y0, x0, ci0 + 16, false);      // this tile's second slab: window only
+            else if (nt < ntiles) tile_load(ab, az * TZ, ay * TY, ax * TX);
         } else {
             stage_halo<P, 16 * CIS / CH, XMX, C::LAY>(x, ldx, b, z0, y0, x0, D, H, W, ci0, Cin, C::PX, ximg);
             load_dy(dy, lddy, b, z0, y0, x0, ybuf);
@@ -1342,7 +1354,8 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
             __syncthreads();
         }
 
-        if constexpr (CH == 8 && C::FLIP && XMX == 2) {
+        auto fast_compute = [&](auto slc) __attribute__((always_inline)) {
+            constexpr int SLAB = decltype(slc)::value;
             // bf16, 16-channel slab, conflict-free layout: every per-lane address part is k-block independent (formed once before
             // the loop: ylane0/1, xs0/1[3]); per read one add of a wave-uniform (k-block, unit) offset.  The NKB x UPW (k-block,
             // unit) steps run as ONE straight line, software-pipelined: the x fragments of the next DPT steps and the dy fragment
@@ -1379,9 +1392,21 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
                 const s16x4 blo = rlo[st % DPT], bhi = rhi[st % DPT];
                 s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
                 const bool ext1 = HAS3 && ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS;
-                P::mma(acc[ui], ext1 ? af3 : af[kb & 1], __builtin_bit_cast(u32x4, b8));
+                P::mma(acc[SLAB][ui], ext1 ? af3 : af[kb & 1], __builtin_bit_cast(u32x4, b8));
                 if (st + DPT < NST) bread(st + DPT, rlo[st % DPT], rhi[st % DPT]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (CH == 8 && C::FLIP && XMX == 2) {
+            fast_compute(IntC<0>{});
+            if constexpr (NSL == 2) {
+                // second slab of the same voxel tile: its window replaces the first one's (the dy images stay), and the next tile's
+                // first-slab window + dy tiles go in flight under its MFMAs
+                __syncthreads();
+                halo_store_planned<P, 16 / CH>(R, xplan, ximg);
+                __syncthreads();
+                if (tile + (int)gridDim.x < ntiles) tile_load(ab, az * TZ, ay * TY, ax * TX);
+                fast_compute(IntC<NSL - 1>{});
             }
         } else
         for (int kb = 0; kb < C::NKB; ++kb) {
@@ -1410,7 +1435,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
                         s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + uo + (ext1 ? xc0 : xs0[ui % 3])));
                         s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + uo + (ext1 ? xc1 : xs1[ui % 3])));
                         s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-                        P::mma(acc[ui], ext1 ? afrag3 : afrag, __builtin_bit_cast(u32x4, b8));
+                        P::mma(acc[0][ui], ext1 ? afrag3 : afrag, __builtin_bit_cast(u32x4, b8));
                     }
                 }
             } else if constexpr (CH == 8) {
@@ -1439,7 +1464,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
                         s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + h0 + uoff[ui]));
                         s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ximg + h1 + uoff[ui]));
                         s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-                        P::mma(acc[ui], (ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS) ? afrag3 : afrag, __builtin_bit_cast(u32x4, b8));
+                        P::mma(acc[0][ui], (ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS) ? afrag3 : afrag, __builtin_bit_cast(u32x4, b8));
                     }
                 }
             } else {
@@ -1460,7 +1485,7 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
 #pragma unroll
                         for (int tt = 0; tt < 4; ++tt) {
                             float bv = *(const float*)(ximg + hb[tt] + uoff[ui]);
-                            acc[ui] = __builtin_amdgcn_mfma_f32_16x16x4f32(ext ? av3[tt] : av[tt], bv, acc[ui], 0, 0, 0);
+                            acc[0][ui] = __builtin_amdgcn_mfma_f32_16x16x4f32(ext ? av3[tt] : av[tt], bv, acc[0][ui], 0, 0, 0);
                         }
                     }
                 }
@@ -1470,17 +1495,19 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     }
     // partial sums: part[blockIdx.x][co][ci][tap]
 #pragma unroll
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
     for (int ui = 0; ui < WG_UPW; ++ui) {
         int u = wv + 4 * ui;
         if (u < nunits) {
             int tap = u / CIS, cit = u >= WG_UNITS ? u - WG_UNITS : u % CIS;
-            int ci = ci0 + cit * 16 + c;
+            int ci = ci0 + sl * 16 + cit * 16 + c;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 int co = co0 + 4 * g + rr;
                 if (ci < Cin && co < Cout) {
-                    if (u < WG_UNITS) part[(((long)blockIdx.x * Cout + co) * Cin + ci) * 27 + tap] = acc[ui][rr];
-                    else part3[((long)blockIdx.x * Cout + co) * Cin + ci] = acc[ui][rr];
+                    if (u < WG_UNITS) part[(((long)blockIdx.x * Cout + co) * Cin + ci) * 27 + tap] = acc[sl][ui][rr];
+                    else part3[((long)blockIdx.x * Cout + co) * Cin + ci] = acc[sl][ui][rr];
                 }
             }
         }
@@ -1893,7 +1920,12 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
         }
     }
     const int cis = Cin <= (getenv("UNETR_WG_CIS1") ? atoi(getenv("UNETR_WG_CIS1")) : (1 << 30)) ? 1 : 2;
-    const int nci = cdiv(Cin, 16 * cis), nco = cdiv(Cout, 16);
+    // UNETR_WG_NSL=2: two 16-channel slabs per workgroup (the dy / dy3 tile staged once for both) where the fast path applies and the
+    // slabs pair up.  OFF by default: measured SLOWER on MI355X (same box, three interleaved rounds: 5.03 / 5.12 / 5.03 ms per step
+    // against 4.93 / 4.92 / 4.91) -- the kernel is bound by latency and instruction issue, not by the 22 % of bytes this saves, and
+    // half as many workgroups share a tile's work.  (The same verdict as the 32-channel window of round 2.)
+    const int nsl = (B16 && cis == 1 && !x_f32 && Cin % 32 == 0 && getenv("UNETR_WG_NSL") && atoi(getenv("UNETR_WG_NSL")) == 2) ? 2 : 1;
+    const int nci = cdiv(Cin, 16 * cis * nsl), nco = cdiv(Cout, 16);
     const long n = 27L * Cin * Cout;
     // persistent workgroups: all of them resident at once (3 per CU with the 16-channel slab, else 2 rounds of 2 per CU)
     long G = std::max<long>(1, (cis == 1 ? ((dy3 && !B16) ? 512 : 256 * WG_LB) : 1024) / ((long)nci * nco));
@@ -1919,13 +1951,17 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
 #define LAUNCH_WG_C(VX_, VY_, H3_, CIS_)                                                                                          \
     hipLaunchKernelGGL((conv3_wgrad_kernel<P, VX_, VY_, H3_, CIS_, (CIS_ == 1)>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, \
                        ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles)
+#define LAUNCH_WG_2(H3_)                                                                                                          \
+    hipLaunchKernelGGL((conv3_wgrad_kernel<P, 2, true, H3_, 1, true, 2>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, x, ldx, dy, lddy, \
+                       ws, dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles)
 #define LAUNCH_WG(VX_, VY_)                                                                                                        \
     do {                                                                                                                           \
         if (dy3) { if (cis == 1) LAUNCH_WG_C(VX_, VY_, true, 1); else LAUNCH_WG_C(VX_, VY_, true, 2); }                            \
         else { if (cis == 1) LAUNCH_WG_C(VX_, VY_, false, 1); else LAUNCH_WG_C(VX_, VY_, false, 2); }                              \
     } while (0)
     if constexpr (B16) {
-        if (vecx == 2) LAUNCH_WG(2, true);
+        if (vecx == 2 && nsl == 2) { if (dy3) LAUNCH_WG_2(true); else LAUNCH_WG_2(false); }
+        else if (vecx == 2) LAUNCH_WG(2, true);
         else if (vecx == 1) LAUNCH_WG(1, true);
         else LAUNCH_WG(0, true);
     } else {
