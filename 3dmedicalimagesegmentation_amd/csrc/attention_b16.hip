@@ -239,14 +239,14 @@ attn16_fwd_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ out, uin
 }
 
 // ------------------------------------------------------------------------------- backward: dQ pass
-// query on the lane; writes delta[b,h,q] = sum_d dO[q,d] O[q,d] for the dK/dV pass that follows on the same stream
+// query on the lane; also writes delta[b,h,q] = sum_d dO[q,d] O[q,d] (kept as an output of the entry point; the dK/dV role below
+// recomputes the values it needs, so the two roles have no dependence and share one launch)
 template <int NW>
-__global__ void __launch_bounds__(64 * NW)
-attn16_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ outb, const uint16_t* __restrict__ doutb,
-                     const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb,
-                     int L, int heads, float scale) {
+__device__ __forceinline__ void
+attn16_bwd_dq_body(char* lds, int xblk, const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ outb, const uint16_t* __restrict__ doutb,
+                   const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb,
+                   int L, int heads, float scale) {
     constexpr int NT = 64 * NW;
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
     char* kimg = lds;
     char* vimg = lds + IMG;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, g = lane >> 4;
@@ -255,7 +255,7 @@ attn16_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restric
     const uint16_t* qb = qkv + (long)b * L * rs + head * DH;
     const uint16_t* kb_ = qb + Hd;
     const uint16_t* vb = qb + 2 * Hd;
-    const int q = blockIdx.x * (16 * NW) + wave * 16 + c, qc = min(q, L - 1);
+    const int q = xblk * (16 * NW) + wave * 16 + c, qc = min(q, L - 1);
     u32x4 qf[2], dof[2], of[2];
     load_vec(qb + (long)qc * rs, qf);
     load_vec(doutb + ((long)b * L + qc) * Hd + head * DH, dof);
@@ -328,13 +328,13 @@ attn16_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restric
 }
 
 // ---------------------------------------------------------------------------- backward: dK/dV pass
-// key on the lane: no atomics; loops over chunks of queries (Q and dO images resident, lse / delta of the chunk in LDS)
+// key on the lane: no atomics; loops over chunks of queries (Q and dO images resident, lse / delta of the chunk in LDS; delta is
+// computed here from the O and dO rows -- 2 x 128 B per query -- with the same summation order as the dQ role uses)
 template <int NW>
-__global__ void __launch_bounds__(64 * NW)
-attn16_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ doutb, const float* __restrict__ lse,
-                      const float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb, int L, int heads, float scale) {
+__device__ __forceinline__ void
+attn16_bwd_dkv_body(char* lds, int xblk, const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ outb, const uint16_t* __restrict__ doutb,
+                    const float* __restrict__ lse, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb, int L, int heads, float scale) {
     constexpr int NT = 64 * NW;
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
     char* qimg = lds;
     char* doimg = lds + IMG;
     float* lse_t = (float*)(lds + 2 * IMG);
@@ -346,7 +346,8 @@ attn16_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
     const uint16_t* kb_ = qb + Hd;
     const uint16_t* vb = qb + 2 * Hd;
     const uint16_t* dob = doutb + (long)b * L * Hd + head * DH;
-    const int key = blockIdx.x * (16 * NW) + wave * 16 + c, kc = min(key, L - 1);
+    const uint16_t* ob_ = outb + (long)b * L * Hd + head * DH;
+    const int key = xblk * (16 * NW) + wave * 16 + c, kc = min(key, L - 1);
     u32x4 kf[2], vf[2];
     load_vec(kb_ + (long)kc * rs, kf);
     load_vec(vb + (long)kc * rs, vf);
@@ -361,7 +362,24 @@ attn16_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
         for (int i = threadIdx.x; i < rows; i += NT) {
             const int qq = q0 + i;
             lse_t[i] = qq < L ? lse[((long)b * heads + head) * L + qq] : 1.0e30f;     // p = exp(s - 1e30) = 0 for padding
-            del_t[i] = qq < L ? delta[((long)b * heads + head) * L + qq] : 0.f;
+        }
+        // delta of the chunk's queries, one query row per thread (2 x 128 B of O and dO).  The dQ role sums pieces g and 4+g in
+        // one chain and then adds the four chains as (0+1)+(2+3); the same order is kept here
+        for (int i = threadIdx.x; i < rows; i += NT) {
+            const int qq = min(q0 + i, L - 1);
+            float part[4];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                part[gg] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *(const u32x4*)(ob_ + (long)qq * Hd + (kb * 4 + gg) * 8));
+                    const bf16x8 d = __builtin_bit_cast(bf16x8, *(const u32x4*)(dob + (long)qq * Hd + (kb * 4 + gg) * 8));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) part[gg] += (float)a[e] * (float)d[e];
+                }
+            }
+            del_t[i] = q0 + i < L ? (part[0] + part[1]) + (part[2] + part[3]) : 0.f;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -420,6 +438,19 @@ attn16_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restri
     }
 }
 
+// one launch, two roles: workgroups [0, nqb) of x are dQ blocks, [nqb, 2 nqb) are dK/dV blocks.  Neither role fills the chip at
+// batch 2 (168 workgroups of 128 threads each), so back to back they cost two launch boundaries and two half-empty rounds
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+attn16_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ outb, const uint16_t* __restrict__ doutb,
+                  const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, uint16_t* __restrict__ dqkvb,
+                  int L, int heads, float scale, int nqb) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int xb = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    if (xb < nqb) attn16_bwd_dq_body<NW>(lds, xb, qkv, outb, doutb, lse, delta, dqkv, dqkvb, L, heads, scale);
+    else attn16_bwd_dkv_body<NW>(lds, xb - nqb, qkv, outb, doutb, lse, dqkv, dqkvb, L, heads, scale);
+}
+
 template <class K, class... A>
 void launch_dyn(K kern, dim3 grid, int nt, size_t lds, hipStream_t st, A... args) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -456,15 +487,13 @@ extern "C" int unetr_attention_bf16_bwd(const void* qkv, const void* out_bf16, c
     const uint16_t* o = (const uint16_t*)out_bf16;
     const uint16_t* d = (const uint16_t*)dout_bf16;
     uint16_t* gq = (uint16_t*)dqkv_bf16;
-    const size_t lq = 2 * IMG, lk = 2 * IMG + 2 * CKEYS * sizeof(float);
+    const size_t lk = 2 * IMG + 2 * CKEYS * sizeof(float);
     if (pick_nw(B, L, heads) == 2) {
-        dim3 grid(cdiv(L, 32), heads, B);
-        launch_dyn(attn16_bwd_dq_kernel<2>, grid, 128, lq, st, q, o, d, lse, delta, dqkv, gq, L, heads, scale);
-        launch_dyn(attn16_bwd_dkv_kernel<2>, grid, 128, lk, st, q, d, lse, (const float*)delta, dqkv, gq, L, heads, scale);
+        const int nqb = cdiv(L, 32);
+        launch_dyn(attn16_bwd_kernel<2>, dim3(2 * nqb, heads, B), 128, lk, st, q, o, d, lse, delta, dqkv, gq, L, heads, scale, nqb);
     } else {
-        dim3 grid(cdiv(L, 64), heads, B);
-        launch_dyn(attn16_bwd_dq_kernel<4>, grid, 256, lq, st, q, o, d, lse, delta, dqkv, gq, L, heads, scale);
-        launch_dyn(attn16_bwd_dkv_kernel<4>, grid, 256, lk, st, q, d, lse, (const float*)delta, dqkv, gq, L, heads, scale);
+        const int nqb = cdiv(L, 64);
+        launch_dyn(attn16_bwd_kernel<4>, dim3(2 * nqb, heads, B), 256, lk, st, q, o, d, lse, delta, dqkv, gq, L, heads, scale, nqb);
     }
     return unetr_check_launch();
 }

@@ -224,16 +224,27 @@ class TrainStep:
             self.graphs = [g]
             self.one_graph = True
             return
-        graphs = [torch.cuda.CUDAGraph()]
-        with torch.cuda.graph(graphs[0], stream=self.side, capture_error_mode=mode):
-            self._pass0()
-        pool = graphs[0].pool()
-        for k in range(1, self.npass):
+        # one graph per hand-over to the communication stream: passes that hand nothing over (pass 0: the conv side's range
+        # travels with pass 1) are captured together with the pass that follows them -- every extra graph in the chain costs
+        # the main stream ~25 us, every hand-over ~55 us (tools/probe_dp_split.py)
+        groups, cur = [], []
+        for k in range(self.npass):
+            cur.append(k)
+            if self.pieces[k] or k == self.npass - 1:
+                groups.append(cur)
+                cur = []
+        graphs, pool = [], None
+        for ks in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, stream=self.side, capture_error_mode=mode):
-                self._pass(k)
+                for k in ks:
+                    if k == 0:
+                        self._pass0()
+                    else:
+                        self._pass(k)
+            pool = g.pool()
             graphs.append(g)
-        self.graphs = graphs
+        self.graphs, self.graph_passes = graphs, groups
 
     def run(self):
         """one training step; returns nothing (self.loss is the device scalar of this step)"""
@@ -242,9 +253,9 @@ class TrainStep:
         elif not self.dp or self.one_graph:
             self.graphs[0].replay()
         else:
-            for k, g in enumerate(self.graphs):
+            for g, ks in zip(self.graphs, self.graph_passes):
                 g.replay()
-                self._reduce_and_update(k)
+                self._reduce_and_update(ks[-1])
 
     @property
     def launch(self):
@@ -254,5 +265,5 @@ class TrainStep:
             return "hipGraph(fwd+loss+bwd+AdamW)"
         if self.one_graph:
             return (f"hipGraph(fwd+loss+bwd in {self.npass} passes; AdamW per pass on a side-stream branch underneath the passes that follow)")
-        return (f"{self.npass} hipGraphs (fwd+loss+bwd pass 0 | ViT passes 1-{self.npass - 1}), per-pass all-reduce on a side stream, "
-                "AdamW per reduced piece")
+        return (f"{len(self.graphs)} hipGraphs ({self.npass} backward passes: fwd+loss+conv side | ViT passes 1-{self.npass - 1}), "
+                "per-pass all-reduce on a side stream, AdamW per reduced piece")

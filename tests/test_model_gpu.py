@@ -607,8 +607,8 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
             if size == "c2":        # the tail that cannot overlap with backward: block 0 + patch embedding, 41 MB of 370 MB
                 tail = sum(hi - lo for lo, hi in step.pieces[4]) * 4
                 assert tail < 45e6 and sum(hi - lo for st in step.pieces for lo, hi in st) * 4 > 365e6
-            if mode != "staged_eager":
-                assert len(step.graphs) == 5
+            if mode != "staged_eager":      # pass 0 hands nothing over: it shares a graph with pass 1
+                assert len(step.graphs) == 4 and step.graph_passes == [[0, 1], [2], [3], [4]]
         for _ in range(3):
             step.run()
         torch.cuda.synchronize()
