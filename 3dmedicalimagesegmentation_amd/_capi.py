@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
-ABI_VERSION = 5        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 6        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -55,6 +55,11 @@ class GroupedProblem(ctypes.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int)]
 
 
+class AdamWArena(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("m", c_void_p), ("v", c_void_p), ("shadow_bf16", c_void_p), ("steps", c_void_p),
+                ("total", c_long), ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float)]
+
+
 class PackProblem(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("Cin", c_int), ("Cout", c_int), ("kind", c_int)]
 
@@ -76,6 +81,8 @@ _SIGNATURES = {
     "unetr_attention_bf16_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "unetr_gemm_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, c_int, P],
     "unetr_gemm_bf16_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, P],
+    "unetr_gemm_bf16_grouped_wgrad_adamw": [ctypes.POINTER(GroupedProblem), c_int, ctypes.POINTER(AdamWArena), ctypes.POINTER(c_int), P],
+    "unetr_adamw_ranges": [ctypes.POINTER(AdamWArena), P, c_int, c_long, P],
     "unetr_colsum_grouped": [ctypes.POINTER(ColsumProblem), c_int, P],
     "unetr_tconv_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],

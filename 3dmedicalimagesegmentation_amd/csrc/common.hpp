@@ -81,6 +81,27 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// ---- AdamW element update (torch.optim.AdamW: decoupled weight decay, bias-corrected moments), shared by the streaming optimizer
+// kernel (norm_misc.hip) and the fused epilogue of the grouped ViT weight gradient (gemm_bf16.hip) so that both give the same bits
+struct AdamWCoef { float decay, b1, b2, eps, step_size, inv_sqrt_bc2; };
+__device__ __forceinline__ AdamWCoef adamw_coef(float lr, float b1, float b2, float eps, float wd, float step) {
+#pragma clang fp contract(off)
+    const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+    return AdamWCoef{1.f - lr * wd, b1, b2, eps, lr / bc1, rsqrtf(bc2)};
+}
+__device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g, const AdamWCoef& c) {
+    // every multiply-add is spelled out (contraction off, explicit fmaf): left to the compiler, the same expression was fused
+    // differently in the streaming kernel and in the GEMM epilogue and ~0.6 % of the elements differed in the last bit
+#pragma clang fp contract(off)
+    const float pe = p * c.decay;
+    const float me = fmaf(c.b1, m, (1.f - c.b1) * g);
+    const float ve = fmaf(c.b2, v, ((1.f - c.b2) * g) * g);
+    const float denom = fmaf(sqrtf(ve), c.inv_sqrt_bc2, c.eps);
+    p = fmaf(-c.step_size, me / denom, pe);
+    m = me;
+    v = ve;
+}
+
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);

@@ -539,12 +539,17 @@ static int big_tile_width(int M, int N, int K) {
 // features of dY and of X, staged by LDS-DMA into two swizzled images (bkn_x<16>), and all MFMA fragments (k = token) come
 // out through ds_read_b64_tr_b16.  One launch covers up to 48 problems (descriptors in the kernel arguments); tokens beyond
 // M in the last stage read a clamped row and are zeroed in the A fragments (M is a multiple of 8: whole lane groups).
+#ifndef GW_WAVES
+#define GW_WAVES 4
+#endif
 constexpr int GW_MAX = 64;     // 12 blocks x 4 Linear layers + patch embedding in ONE launch
-struct GwProblem { const uint16_t* dy; const uint16_t* x; float* dw; int M, N, K, tile0, ntn; };
-struct GwArgs { int n; GwProblem p[GW_MAX]; };
+struct GwProblem { const uint16_t* dy; const uint16_t* x; float* dw; int M, N, K, tile0, ntn, step_idx; };
+// FUSE: the arenas of the fused optimizer epilogue (dw then only NAMES the arena slice: element offset = dw - gb)
+struct GwFuse { float* pb; const float* gb; float* mb; float* vb; uint16_t* sb; const float* steps; float lr, b1, b2, eps, wd; };
+struct GwArgs { int n; GwFuse f; GwProblem p[GW_MAX]; };
 
-template <int NS, int BKT>                                  // BKT = tokens per stage (64 or 32)
-__global__ void __launch_bounds__(256)
+template <int NS, int BKT, bool FUSE>                       // BKT = tokens per stage (64 or 32)
+__global__ void __launch_bounds__(256, GW_WAVES)
 gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
     constexpr int BT = 128;                                // output tile 128 x 128
     constexpr int IMG = BKT * BT * 2, STAGE = 2 * IMG, PCS = IMG / 16 / 256, G = 2 * PCS, CPR = 16;
@@ -629,13 +634,73 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
     }
     // lane (cc, g) holds dW[n = tile row cc][k = 4g .. 4g+3]: ONE 16-byte store per tile (was four 4-byte stores whose 16 lanes
     // covered 64 bytes each); dW is written once and next read by AdamW after 350 MB of other gradients: non-temporal
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + (wm * 4 + i) * 16 + cc, k = k0 + (wn * 4 + j) * 16 + 4 * g;
-            if (n < pr.N && k < pr.K) __builtin_nontemporal_store(acc[i][j], (f32x4*)(pr.dw + (long)n * pr.K + k));
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + (wm * 4 + i) * 16 + cc, k = k0 + (wn * 4 + j) * 16 + 4 * g;
+                if (n < pr.N && k < pr.K) __builtin_nontemporal_store(acc[i][j], (f32x4*)(pr.dw + (long)n * pr.K + k));
+            }
+    } else {
+        // AdamW on the tile instead of the gradient store: the weight's master / moment / shadow slices sit at the same arena
+        // offset as dw.  The accumulator layout (lane = one row, 16 bytes) would touch 64-byte pieces of 16 rows per instruction:
+        // each wave turns its 64 x 64 sub-tile through its own 8 KB of the (now free) stage buffers, half at a time, so that 16
+        // lanes cover 256 contiguous bytes of a row -- p / m / v are streamed once (non-temporal), the bf16 shadow is what the
+        // next forward reads.  chunk c of staged row r sits at slot c ^ (r & 15): conflict-free for the row-per-lane writes.
+        static_assert(NS * STAGE >= 4 * 8192, "8 KB of staging per wave");
+        const GwFuse& f = ga.f;
+        const AdamWCoef c = adamw_coef(f.lr, f.b1, f.b2, f.eps, f.wd, f.steps[pr.step_idx]);
+        const long off0 = pr.dw - f.gb;
+        __syncthreads();                                   // every wave has read its last fragments out of the stage buffers
+        char* stg = lds + wave * 8192;
+        const int rr = lane >> 4, rc = lane & 15;          // reader: row within a group of 4, 16-byte chunk of the 256-byte row
+        const int kcol = k0 + wn * 64 + rc * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = ii * 16 + cc;
+                    *(f32x4*)(stg + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4)) = acc[2 * h + ii][j];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (wave-private region: no barrier)
+#pragma unroll 2
+            for (int it = 0; it < 8; it += 2) {
+                f32x4 gv[2], pv[2], mv[2], vv[2];
+                long idx[2];
+                bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int r = (it + u) * 4 + rr, n = n0 + wm * 64 + h * 32 + r;
+                    ok[u] = n < pr.N && kcol < pr.K;
+                    idx[u] = off0 + (long)n * pr.K + kcol;
+                    gv[u] = *(const f32x4*)(stg + r * 256 + ((rc ^ (r & 15)) << 4));
+                    if (ok[u]) {
+                        pv[u] = __builtin_nontemporal_load((const f32x4*)(f.pb + idx[u]));
+                        mv[u] = __builtin_nontemporal_load((const f32x4*)(f.mb + idx[u]));
+                        vv[u] = __builtin_nontemporal_load((const f32x4*)(f.vb + idx[u]));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!ok[u]) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pe = pv[u][e], me = mv[u][e], ve = vv[u][e];
+                        adamw_elem(pe, me, ve, gv[u][e], c);
+                        pv[u][e] = pe; mv[u][e] = me; vv[u][e] = ve;
+                    }
+                    __builtin_nontemporal_store(pv[u], (f32x4*)(f.pb + idx[u]));
+                    __builtin_nontemporal_store(mv[u], (f32x4*)(f.mb + idx[u]));
+                    __builtin_nontemporal_store(vv[u], (f32x4*)(f.vb + idx[u]));
+                    if (f.sb) *(bf16x4*)(f.sb + idx[u]) = __builtin_convertvector(pv[u], bf16x4);
+                }
+            }
+            if (h == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this half are done before it is overwritten
         }
+    }
 }
 
 __global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n8) {
@@ -789,27 +854,48 @@ extern "C" int unetr_add_cast_bf16(const float* a, const float* b, float* out, v
     return unetr_check_launch();
 }
 
-// dw_i[N_i, K_i] = dy_i[M_i, N_i]^T * x_i[M_i, K_i] on bf16-stored dy / x (dense row-major), one launch per <= 48 problems
-extern "C" int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs, int n, void* stream) {
+// dw_i[N_i, K_i] = dy_i[M_i, N_i]^T * x_i[M_i, K_i] on bf16-stored dy / x (dense row-major), one launch per <= 64 problems;
+// a: optimizer arenas -> the epilogue applies AdamW (step count a->steps[step_index[i]]) instead of storing dw
+static int grouped_wgrad_bf16(const unetr_grouped_problem* probs, int n, const unetr_adamw_arena* a, const int* step_index, void* stream) {
     if (!probs || n <= 0) return UNETR_ERR_ARG;
+    if (a && (!a->param || !a->grad || !a->m || !a->v || !a->steps || !step_index || a->total <= 0)) return UNETR_ERR_ARG;
+    if (a && ((((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->m | (uintptr_t)a->v) & 15) || ((uintptr_t)a->shadow_bf16 & 7))) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += GW_MAX) {
         GwArgs ga;
         ga.n = std::min(GW_MAX, n - base);
+        ga.f = GwFuse{};
+        if (a) ga.f = GwFuse{a->param, a->grad, a->m, a->v, (uint16_t*)a->shadow_bf16, a->steps, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay};
         int tiles = 0;
         for (int i = 0; i < ga.n; ++i) {
             const unetr_grouped_problem& q = probs[base + i];
             if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.N < 8 || q.K < 8) return UNETR_ERR_ARG;
             if (q.M % 8 || q.N % 8 || q.K % 8 || ((uintptr_t)q.dy & 15) || ((uintptr_t)q.x & 15) || ((uintptr_t)q.dw & 15)) return UNETR_ERR_UNSUPPORTED;
+            if (a) {       // dw names a slice of the gradient arena
+                const long off = q.dw - a->grad;
+                if (q.dw < a->grad || off + (long)q.N * q.K > a->total || step_index[base + i] < 0) return UNETR_ERR_ARG;
+            }
             GwProblem& g = ga.p[i];
             g.dy = (const uint16_t*)q.dy; g.x = (const uint16_t*)q.x; g.dw = q.dw; g.M = q.M; g.N = q.N; g.K = q.K;
             g.tile0 = tiles; g.ntn = cdiv(q.N, 128);
+            g.step_idx = a ? step_index[base + i] : 0;
             tiles += g.ntn * cdiv(q.K, 128);
         }
         // 32 tokens per stage, two stages: 32 KB of LDS per workgroup -> four workgroups per CU.  The launch is latency-bound per
         // K step (7-14 short steps per tile, operands out of HBM / MALL); measured at 432 rows (tools/probe_gw.py, us):
         // 64 tokens x 2 stages (two workgroups per CU) 201, 32 x 2 178, 32 x 3 190, 32 x 4 203, 64 x 3 268, 64 x 4 245
-        hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32>), dim3(tiles), dim3(256), 0, st, ga);
+        if (a) hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32, true>), dim3(tiles), dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32, false>), dim3(tiles), dim3(256), 0, st, ga);
     }
     return unetr_check_launch();
+}
+
+extern "C" int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs, int n, void* stream) {
+    return grouped_wgrad_bf16(probs, n, nullptr, nullptr, stream);
+}
+
+extern "C" int unetr_gemm_bf16_grouped_wgrad_adamw(const unetr_grouped_problem* probs, int n, const unetr_adamw_arena* a,
+                                                   const int* step_index, void* stream) {
+    if (!a) return UNETR_ERR_ARG;
+    return grouped_wgrad_bf16(probs, n, a, step_index, stream);
 }

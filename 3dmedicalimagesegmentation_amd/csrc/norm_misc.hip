@@ -878,9 +878,7 @@ __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale, float* __restrict__ m, float* __restrict__ v,
              long n4, long n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ step_dev,
              uint16_t* __restrict__ shadow) {
-    const float step = *step_dev;
-    const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
-    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    const AdamWCoef c = adamw_coef(lr, b1, b2, eps, wd, *step_dev);
     auto grad1 = [&](long i) -> float {
         if (GB16) { uint32_t u = (uint32_t)((const uint16_t*)gsrc)[i] << 16; return __builtin_bit_cast(float, u) * gscale; }
         return ((const float*)gsrc)[i] * gscale;
@@ -892,12 +890,9 @@ adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale,
         else gv = __builtin_nontemporal_load((const f32x4*)gsrc + i) * gscale;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float pe = pv[e] * (1.f - lr * wd);
-            float me = b1 * mv[e] + (1.f - b1) * gv[e];
-            float ve = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
-            float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
-            pv[e] = pe - step_size * (me / denom);
-            mv[e] = me; vv[e] = ve;
+            float pe = pv[e], me = mv[e], ve = vv[e];
+            adamw_elem(pe, me, ve, gv[e], c);
+            pv[e] = pe; mv[e] = me; vv[e] = ve;
         }
         __builtin_nontemporal_store(pv, (f32x4*)p + i); __builtin_nontemporal_store(mv, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i);
         if (shadow) ((bf16x4*)shadow)[i] = __builtin_convertvector(pv, bf16x4);
@@ -905,13 +900,39 @@ adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale,
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
         long i = n4 * 4 + threadIdx.x;
-        const float g = grad1(i);
-        float pe = p[i] * (1.f - lr * wd);
-        float me = b1 * m[i] + (1.f - b1) * g;
-        float ve = b2 * v[i] + (1.f - b2) * g * g;
-        p[i] = pe - step_size * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
-        m[i] = me; v[i] = ve;
+        float pe = p[i], me = m[i], ve = v[i];
+        adamw_elem(pe, me, ve, grad1(i), c);
+        p[i] = pe; m[i] = me; v[i] = ve;
         if (shadow) { __bf16 h = (__bf16)p[i]; shadow[i] = __builtin_bit_cast(uint16_t, h); }
+    }
+}
+
+// AdamW over a table of arena ranges: block -> range by binary search over the running block counts; 4096 elements per block
+constexpr int AR_BLOCK = 4096;
+__global__ void __launch_bounds__(256)
+adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                    uint16_t* __restrict__ shadow, const float* __restrict__ steps, const long* __restrict__ table, int nr,
+                    float lr, float b1, float b2, float eps, float wd) {
+    int lo_r = 0, hi_r = nr - 1;
+    const long blk = blockIdx.x;
+    while (lo_r < hi_r) {                                  // last range whose first block <= blk (uniform: scalar loads)
+        const int mid = (lo_r + hi_r + 1) >> 1;
+        if (table[4 * mid + 3] <= blk) lo_r = mid; else hi_r = mid - 1;
+    }
+    const long lo = table[4 * lo_r], hi = table[4 * lo_r + 1];
+    const AdamWCoef c = adamw_coef(lr, b1, b2, eps, wd, steps[table[4 * lo_r + 2]]);
+    const long beg = lo + (blk - table[4 * lo_r + 3]) * AR_BLOCK, end = min(hi, beg + AR_BLOCK);
+    for (long i = beg / 4 + threadIdx.x; i < end / 4; i += 256) {
+        f32x4 pv = __builtin_nontemporal_load((f32x4*)p + i), mv = __builtin_nontemporal_load((f32x4*)m + i), vv = __builtin_nontemporal_load((f32x4*)v + i);
+        const f32x4 gv = __builtin_nontemporal_load((const f32x4*)g + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pv[e], me = mv[e], ve = vv[e];
+            adamw_elem(pe, me, ve, gv[e], c);
+            pv[e] = pe; mv[e] = me; vv[e] = ve;
+        }
+        __builtin_nontemporal_store(pv, (f32x4*)p + i); __builtin_nontemporal_store(mv, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i);
+        if (shadow) ((bf16x4*)shadow)[i] = __builtin_convertvector(pv, bf16x4);
     }
 }
 
@@ -1252,6 +1273,15 @@ static int adamw_launch(float* p, const void* g, int g_bf16, float gscale, float
 extern "C" int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, const float* step_dev, void* shadow_bf16, void* stream) {
     return adamw_launch(p, g, 0, 1.0f, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_bf16, stream);
+}
+
+extern "C" int unetr_adamw_ranges(const unetr_adamw_arena* a, const long* table_dev, int n_ranges, long n_blocks, void* stream) {
+    if (!a || !a->param || !a->grad || !a->m || !a->v || !a->steps || !table_dev || n_ranges <= 0 || n_blocks <= 0) return UNETR_ERR_ARG;
+    if (((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->m | (uintptr_t)a->v) & 15 || ((uintptr_t)a->shadow_bf16 & 7)) return UNETR_ERR_ARG;
+    if (n_blocks > 0x7fffffffL) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, a->param, a->grad, a->m, a->v,
+                       (uint16_t*)a->shadow_bf16, a->steps, table_dev, n_ranges, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay);
+    return unetr_check_launch();
 }
 
 // the data-parallel form: gradients are read from the all-reduced communication buffer (fp32 or bf16) and averaged

@@ -49,6 +49,7 @@ class ArenaState:
         self.ready_cb = []         # data-parallel reducers: called with a parameter once its arena gradient is final
         self.defer = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0}
         self.unmaintained = 0      # arena shadows of THIS model re-derived since its flat optimizer last vouched for them
+        self.fuse = None           # optim.AdamW.begin_fused_step: the deferred weight-gradient launch applies AdamW itself
 
     def reset_deferred(self):
         """Drop whatever a backward pass that raised left queued (its end-of-pass callback never ran): without this the
@@ -57,6 +58,7 @@ class ArenaState:
         d["wgrad"], d["wgrad_b"], d["colsum"], d["params"], d["armed"] = [], [], [], [], False
 
     def clear(self):
+        self.fuse = None
         for k in list(self.sinks):
             _GRAD_SINK.pop(k, None)
         self.sinks.clear()
@@ -169,7 +171,22 @@ def colsum_or_defer(x, M, N, ld, b, view_shape=None):
     return _ret(b, out, deferred=True)
 
 
-def _launch_deferred(wq, cq, wbq=(), prec=0):
+def _launch_deferred(wq, cq, wbq=(), prec=0, fuse=None):
+    if wbq and fuse is not None:
+        # the optimizer rides on the launch: problems whose destination is a registered arena slice get AdamW in the epilogue
+        # (their gradient is never stored); anything else keeps the plain launch below
+        index = fuse["index"]
+        fused = [(q, index[q[2].data_ptr()]) for q in wbq if q[2].data_ptr() in index]
+        wbq = [q for q in wbq if q[2].data_ptr() not in index]
+        if fused:
+            arr = (_capi.GroupedProblem * len(fused))()
+            idx = (ctypes.c_int * len(fused))()
+            for i, ((dyb, xb, out), pi) in enumerate(fused):
+                arr[i].dy, arr[i].x, arr[i].dw = dyb.data_ptr(), xb.data_ptr(), out.data_ptr()
+                arr[i].M, arr[i].N, arr[i].K = dyb.shape[0], dyb.shape[1], xb.shape[1]
+                idx[i] = pi
+            call("unetr_gemm_bf16_grouped_wgrad_adamw", arr, len(fused), ctypes.byref(fuse["arena"]), idx, _stream())
+            fuse["done"].extend(pi for _, pi in fused)
     if wbq:
         arr = (_capi.GroupedProblem * len(wbq))()
         for i, (dyb, xb, out) in enumerate(wbq):
@@ -195,7 +212,7 @@ def flush_deferred(st=None):
     d = st.defer
     wq, cq, wbq, params, prec = d["wgrad"], d["colsum"], d["wgrad_b"], d["params"], d["prec"]
     st.reset_deferred()
-    _launch_deferred(wq, cq, wbq, prec)
+    _launch_deferred(wq, cq, wbq, prec, st.fuse)
     for p in params:
         for cb in st.ready_cb:
             cb(p)

@@ -125,6 +125,73 @@ class AdamW(torch.optim.Optimizer):
             Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has], flat.get("state"))
         return True
 
+    # ---- single-GPU fused step: AdamW of the ViT Linear weights rides on the grouped weight-gradient launch ----------------
+    # begin_fused_step(pattern) BEFORE backward (step counters advance, the arena state is handed to functional.flush_deferred),
+    # finish_fused_step() AFTER backward: one table-driven launch updates every parameter the fused launch did not cover.
+    # The gradients of the fused weights are never written: p.grad of those parameters names a stale arena slice.
+    @torch.no_grad()
+    def begin_fused_step(self, pattern):
+        import ctypes
+        from . import _capi
+        flat = self._flat
+        if flat is None or len(self.param_groups) != 1 or flat.get("state") is None:
+            raise RuntimeError("begin_fused_step needs AdamW(..., flat=model.use_flat_buffers())")
+        group = self.param_groups[0]
+        params = group["params"]
+        pattern = tuple(bool(f) for f in pattern)
+        if self._flat_state is None:
+            self._flat_state = (torch.zeros_like(flat["param"]), torch.zeros_like(flat["param"]))
+        steps = self._advance_steps(0, params, pattern, flat["param"].device)
+        m, v = self._flat_state
+        shadow = flat.get("shadow")
+        b1, b2 = group["betas"]
+        arena = _capi.AdamWArena(flat["param"].data_ptr(), flat["grad"].data_ptr(), m.data_ptr(), v.data_ptr(),
+                                 shadow.data_ptr() if shadow is not None else None, steps.data_ptr(), flat["param"].numel(),
+                                 group["lr"], b1, b2, group["eps"], group["weight_decay"])
+        gbase = flat["grad"].data_ptr()
+        index = {gbase + o * 4: i for i, (o, has) in enumerate(zip(flat["offsets"], pattern)) if has}
+        self._fused = dict(pattern=pattern, arena=arena, index=index, done=[], keep=(m, v, steps))
+        flat["state"].fuse = self._fused
+
+    @torch.no_grad()
+    def finish_fused_step(self):
+        import ctypes
+        flat, fz = self._flat, self._fused
+        flat["state"].fuse = None
+        self._fused = None
+        group = self.param_groups[0]
+        params = group["params"]
+        pattern = fz["pattern"]
+        if tuple(p.grad is not None for p in params) != pattern:
+            raise RuntimeError("fused step: the set of parameters that received gradients differs from the planned pattern")
+        gbase = flat["grad"].data_ptr()
+        done = set(fz["done"])
+        for i, (p, o, has) in enumerate(zip(params, flat["offsets"], pattern)):
+            if has and i not in done and p.grad.data_ptr() != gbase + o * 4:
+                raise RuntimeError("fused step: a gradient was produced outside the arena")
+        rest = tuple(has and i not in done for i, has in enumerate(pattern))
+        key = (pattern, tuple(sorted(done)))
+        cache = getattr(self, "_range_tables", None)
+        if cache is None:
+            cache = self._range_tables = {}
+        ent = cache.get(key)
+        if ent is None:
+            rows, blocks = [], 0
+            for i, j, lo, hi in self._flat_runs(params, rest):
+                rows.append((lo, hi, i, blocks))
+                blocks += (hi - lo + 4095) // 4096
+            table = torch.tensor(rows, dtype=torch.int64, device=flat["param"].device) if rows else None
+            ent = cache[key] = (table, len(rows), blocks)
+        table, nr, blocks = ent
+        if nr:
+            call("unetr_adamw_ranges", ctypes.byref(fz["arena"]), table.data_ptr(), nr, blocks, torch.cuda.current_stream().cuda_stream)
+        for k, has in enumerate(pattern):
+            if has:
+                self._host_steps[k] += 1
+        if flat.get("shadow") is not None:
+            Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has], flat.get("state"))
+        Fn.refresh_conv_packs()
+
     # ---- data-parallel arena update: all-reduce pieces overlap the optimizer kernels of the pieces before them ----
     def plan_reduced(self, max_elems=None, cuts=(), pattern=None):
         """Freeze a gradient pattern (default: which parameters have .grad now) into arena ranges of <= max_elems that never

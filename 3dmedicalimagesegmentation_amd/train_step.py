@@ -47,13 +47,21 @@ def split_range(flat, lo, hi, pieces):
 
 class TrainStep:
     def __init__(self, model, criterion, optimizer, x, y, *, use_graph=True, data_parallel=False, process_group=None,
-                 comm_dtype=torch.float32, tail_pieces=2, warmup=2, overlap_update=False):
-        """overlap_update (single GPU): the data-parallel launch form without a process group -- backward in passes, AdamW on
+                 comm_dtype=torch.float32, tail_pieces=2, warmup=2, overlap_update=False, fuse_update=False):
+        """fuse_update (single GPU, flat arenas): AdamW of the ViT Linear weights (92 % of the parameters) is applied in the
+        epilogue of the grouped weight-gradient launch that ends backward -- their gradients are never stored or re-read (8 of
+        34 bytes per weight) and the optimizer's streaming hides under that launch's MFMA work; one table-driven AdamW launch
+        covers the rest.  Same bits as the unfused step.  ``p.grad`` of the fused weights is NOT valid afterwards.
+        overlap_update (single GPU): the data-parallel launch form without a process group -- backward in passes, AdamW on
         each pass's arena range on the side stream underneath the passes that follow -- captured as ONE hipGraph in which the
         side stream is a branch: the bandwidth-bound optimizer kernels hide under the latency-bound ViT backward chain."""
         flat = getattr(model, "_flat", None)
         self.model, self.crit, self.opt, self.x, self.y = model, criterion, optimizer, x, y
         self.flat = flat
+        self.fuse = bool(fuse_update) and not data_parallel and not overlap_update
+        if self.fuse and flat is None:
+            raise RuntimeError("fuse_update needs model.use_flat_buffers() and AdamW(flat=...)")
+        self._fuse_pattern = None      # which parameters receive gradients: known after the first (unfused) eager step
         self.dp = bool(data_parallel) or bool(overlap_update)
         self.overlap = bool(overlap_update) and not data_parallel
         self.group = process_group
@@ -92,7 +100,9 @@ class TrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             Fn.workspace(x.device)                      # exists before any capture on this stream
-            for _ in range(max(1, warmup)):
+            # (fused update: the first eager step runs unfused and records the gradient pattern, the second builds the range
+            # table of the fused form -- both must exist before capture)
+            for _ in range(max(2 if self.fuse else 1, warmup)):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -112,9 +122,17 @@ class TrainStep:
         self.loss.backward(self._one)
 
     def _single_step(self):
-        self.loss = self._fwd_loss()
-        self._backward()
-        self.opt.step()
+        if self.fuse and self._fuse_pattern is not None:
+            self.opt.begin_fused_step(self._fuse_pattern)
+            self.loss = self._fwd_loss()
+            self._backward()
+            self.opt.finish_fused_step()
+        else:
+            self.loss = self._fwd_loss()
+            self._backward()
+            if self.fuse:
+                self._fuse_pattern = tuple(p.grad is not None for p in self.opt.param_groups[0]["params"])
+            self.opt.step()
         self.opt.zero_grad(set_to_none=True)
 
     # ---------------------------------------------------------------------------------------- data parallel
@@ -262,7 +280,7 @@ class TrainStep:
         if self.graphs is None:
             return "eager"
         if not self.dp:
-            return "hipGraph(fwd+loss+bwd+AdamW)"
+            return "hipGraph(fwd+loss+bwd+AdamW" + (", AdamW of the ViT weights in the weight-gradient epilogue)" if self.fuse else ")")
         if self.one_graph:
             return (f"hipGraph(fwd+loss+bwd in {self.npass} passes; AdamW per pass on a side-stream branch underneath the passes that follow)")
         return (f"{len(self.graphs)} hipGraphs ({self.npass} backward passes: fwd+loss+conv side | ViT passes 1-{self.npass - 1}), "

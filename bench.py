@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (staged backward + per-pass all-reduce slots) on one rank")
     ap.add_argument("--overlap-update", type=int, default=0, help="N=1: AdamW per backward pass on a side-stream branch of the ONE captured graph "
                     "(measured SLOWER on MI355X / ROCm 7.2: 5.46 vs 5.00 ms per step -- a branch in a hipGraph costs more than the optimizer kernels it hides)")
+    ap.add_argument("--fuse-update", type=int, default=1, help="N=1: AdamW of the ViT Linear weights in the epilogue of the grouped weight-gradient "
+                    "launch (same bits as the separate optimizer launch; 0 = separate)")
     ap.add_argument("--bf16-comm", action="store_true", help="all-reduce gradients in bf16 (the default when more than one rank runs in bf16 mode)")
     ap.add_argument("--fp32-comm", action="store_true", help="all-reduce gradients in fp32 (the single-GPU arithmetic; twice the xGMI bytes: "
                     "370 MB per step, more than the backward passes it has to hide under -- DESIGN.md section 7)")
@@ -220,7 +222,8 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
     graph_err = None
     try:
         step = pkg.TrainStep(model, crit, opt, x, y, use_graph=not args.no_graph, data_parallel=ddp_on, comm_dtype=comm_dtype,
-                             overlap_update=bool(args.overlap_update) and flat is not None and not ddp_on)
+                             overlap_update=bool(args.overlap_update) and flat is not None and not ddp_on,
+                             fuse_update=bool(args.fuse_update) and flat is not None and not ddp_on and not args.overlap_update)
     except Exception as e:  # noqa: BLE001
         if args.no_graph:
             raise

@@ -33,7 +33,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 5
+#define UNETR_ABI_VERSION 6
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -343,6 +343,24 @@ int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, 
 int unetr_adamw_reduced(float* p, const void* g, int g_is_bf16, float gscale, float* m, float* v, long n, float lr,
                         float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
                         void* shadow_bf16, void* stream);
+
+/* ---- the single-GPU step's optimizer fused into the producer of the gradients (train_step.TrainStep(fuse_update=True)) ------
+ * The four arenas (parameters, gradients, both moments; fp32, `total` elements, identical layout) and the optional bf16 shadow
+ * arena of the parameters; steps = per-parameter step counts (float, already advanced for this step). */
+typedef struct {
+    float* param; const float* grad; float* m; float* v; void* shadow_bf16; const float* steps; long total;
+    float lr, beta1, beta2, eps, weight_decay;
+} unetr_adamw_arena;
+/* grouped ViT weight gradients (unetr_gemm_bf16_grouped_wgrad) whose epilogue APPLIES AdamW instead of storing dW: every
+ * probs[i].dw must address a slice of a->grad (it is not written); the parameter / moment / shadow slices at the same arena
+ * offset are updated with g = dW, step count a->steps[step_index[i]].  Same bits as the gradient store followed by unetr_adamw
+ * (torch.nn.Linear backward + torch.optim.AdamW.step, unetr_segmentation_3d.py:224-225), 8 bytes per weight less HBM traffic. */
+int unetr_gemm_bf16_grouped_wgrad_adamw(const unetr_grouped_problem* probs, int n, const unetr_adamw_arena* a,
+                                        const int* step_index, void* stream);
+/* AdamW over n_ranges arena ranges in ONE launch (the parameters the fused launch above did not cover: biases, LayerNorm,
+ * conv weights ...).  table (DEVICE memory, 4 longs per range): element offset lo, element offset hi (multiples of 4 as the
+ * arena packs them), index into a->steps, first block of the range (blocks of 4096 elements, running sum); n_blocks = total. */
+int unetr_adamw_ranges(const unetr_adamw_arena* a, const long* table_dev, int n_ranges, long n_blocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -589,7 +589,8 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
     x, y = synthetic_volume(2, 1, S, ncls, seed=41)
     xd, yd = x.to(dev), y.to(dev)
     res = {}
-    modes = ("single", "staged_eager", "staged_graph", "staged_bf16comm", "overlap_one_graph") if size == "c1" else ("single", "staged_graph")
+    modes = (("single", "staged_eager", "staged_graph", "staged_bf16comm", "overlap_one_graph", "fused_eager", "fused_graph") if size == "c1"
+             else ("single", "staged_graph", "fused_graph"))
     for mode in modes:
         torch.manual_seed(11)
         m = pkg.UNETRLogits(**cfg).to(dev)
@@ -597,9 +598,11 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         flat = m.use_flat_buffers()
         opt = pkg.AdamW(m.parameters(), lr=lr, weight_decay=1e-5, flat=flat)
         crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
-        step = pkg.TrainStep(m, crit, opt, xd, yd, use_graph=mode != "staged_eager", data_parallel=mode.startswith("staged"),
-                             comm_dtype=torch.bfloat16 if mode == "staged_bf16comm" else torch.float32, warmup=1,
-                             overlap_update=mode == "overlap_one_graph")
+        step = pkg.TrainStep(m, crit, opt, xd, yd, use_graph=not mode.endswith("_eager"), data_parallel=mode.startswith("staged"),
+                             comm_dtype=torch.bfloat16 if mode == "staged_bf16comm" else torch.float32, warmup=2,
+                             overlap_update=mode == "overlap_one_graph", fuse_update=mode.startswith("fused"))
+        if mode.startswith("fused"):         # AdamW of the 48 Linear weights + patch embedding rides on the weight-gradient launch
+            assert step.fuse and step._fuse_pattern is not None and "epilogue" in step.launch or mode == "fused_eager"
         if mode == "overlap_one_graph":      # the same passes + side-stream AdamW as ONE graph (the side stream is a branch of it)
             assert step.one_graph and len(step.graphs) == 1
         if mode.startswith("staged"):
@@ -612,7 +615,7 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         for _ in range(3):
             step.run()
         torch.cuda.synchronize()
-        res[mode] = (flat["param"].clone(), float(step.loss))
+        res[mode] = (flat["param"].clone(), float(step.loss), opt._flat_state[0].clone(), opt._flat_state[1].clone(), flat["shadow"].clone())
         flat["state"].clear()
         del step, opt, m, flat
     if "staged_eager" in res:
@@ -620,6 +623,10 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         assert torch.equal(res["single"][0], res["overlap_one_graph"][0])
     assert torch.equal(res["single"][0], res["staged_graph"][0])
     assert res["single"][1] == res["staged_graph"][1]
+    for mode in (k for k in res if k.startswith("fused")):      # the fused optimizer epilogue: masters, both moments, bf16 shadows, loss
+        for k in (0, 2, 3, 4):
+            assert torch.equal(res["single"][k], res[mode][k]), (mode, k)
+        assert res["single"][1] == res[mode][1]
     if "staged_bf16comm" in res:
         assert relerr(res["staged_bf16comm"][0], res["single"][0]) < 1e-2       # bf16-rounded gradients: close, not equal
 
