@@ -632,40 +632,44 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
                 for (int j = 0; j < 4; ++j) PrecBF16::mma(acc[i][j], b[j], a[i]);    // swapped operands: the accumulator tile is dW^T
         }
     }
-    // lane (cc, g) holds dW[n = tile row cc][k = 4g .. 4g+3]: ONE 16-byte store per tile (was four 4-byte stores whose 16 lanes
-    // covered 64 bytes each); dW is written once and next read by AdamW after 350 MB of other gradients: non-temporal
-    if constexpr (!FUSE) {
+    // Epilogue.  In the accumulator layout lane (cc, g) holds dW[n = tile row cc][k = 4g .. 4g+3]: a store instruction would touch
+    // 64-byte pieces of 16 rows.  Each wave instead turns its 64 x 64 sub-tile through its own 8 KB of the (now free) stage
+    // buffers, half at a time, so that 16 lanes cover 256 contiguous bytes of a row (chunk c of staged row r at slot c ^ (r & 15):
+    // conflict-free for the row-per-lane writes): the plain gradient store went from 0.213 to 0.180 ms that way, and the fused
+    // optimizer epilogue from 0.76 to 0.44 ms.
+    static_assert(NS * STAGE >= 4 * 8192, "8 KB of staging per wave");
+    __syncthreads();                                       // every wave has read its last fragments out of the stage buffers
+    char* stg = lds + wave * 8192;
+    const int rr = lane >> 4, rc = lane & 15;              // reader: row within a group of 4, 16-byte chunk of the 256-byte row
+    const int kcol = k0 + wn * 64 + rc * 4;
+    [[maybe_unused]] AdamWCoef c{};
+    [[maybe_unused]] long off0 = 0;
+    if constexpr (FUSE) {
+        c = adamw_coef(ga.f.lr, ga.f.b1, ga.f.b2, ga.f.eps, ga.f.wd, ga.f.steps[pr.step_idx]);
+        off0 = pr.dw - ga.f.gb;
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + (wm * 4 + i) * 16 + cc, k = k0 + (wn * 4 + j) * 16 + 4 * g;
-                if (n < pr.N && k < pr.K) __builtin_nontemporal_store(acc[i][j], (f32x4*)(pr.dw + (long)n * pr.K + k));
+                const int r = ii * 16 + cc;
+                *(f32x4*)(stg + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4)) = acc[2 * h + ii][j];
             }
-    } else {
-        // AdamW on the tile instead of the gradient store: the weight's master / moment / shadow slices sit at the same arena
-        // offset as dw.  The accumulator layout (lane = one row, 16 bytes) would touch 64-byte pieces of 16 rows per instruction:
-        // each wave turns its 64 x 64 sub-tile through its own 8 KB of the (now free) stage buffers, half at a time, so that 16
-        // lanes cover 256 contiguous bytes of a row -- p / m / v are streamed once (non-temporal), the bf16 shadow is what the
-        // next forward reads.  chunk c of staged row r sits at slot c ^ (r & 15): conflict-free for the row-per-lane writes.
-        static_assert(NS * STAGE >= 4 * 8192, "8 KB of staging per wave");
-        const GwFuse& f = ga.f;
-        const AdamWCoef c = adamw_coef(f.lr, f.b1, f.b2, f.eps, f.wd, f.steps[pr.step_idx]);
-        const long off0 = pr.dw - f.gb;
-        __syncthreads();                                   // every wave has read its last fragments out of the stage buffers
-        char* stg = lds + wave * 8192;
-        const int rr = lane >> 4, rc = lane & 15;          // reader: row within a group of 4, 16-byte chunk of the 256-byte row
-        const int kcol = k0 + wn * 64 + rc * 4;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (wave-private region: no barrier)
+        if constexpr (!FUSE) {
+            // dW is written once and next read by AdamW after 350 MB of other gradients: non-temporal
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = ii * 16 + cc;
-                    *(f32x4*)(stg + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4)) = acc[2 * h + ii][j];
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (wave-private region: no barrier)
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 4 + rr, n = n0 + wm * 64 + h * 32 + r;
+                const f32x4 gv = *(const f32x4*)(stg + r * 256 + ((rc ^ (r & 15)) << 4));
+                if (n < pr.N && kcol < pr.K) __builtin_nontemporal_store(gv, (f32x4*)(pr.dw + (long)n * pr.K + kcol));
+            }
+        } else {
+            // AdamW on the tile instead of the gradient store: the weight's master / moment / shadow slices sit at the same arena
+            // offset as dw; p / m / v are streamed once (non-temporal), the bf16 shadow is what the next forward reads
+            const GwFuse& f = ga.f;
 #pragma unroll 2
             for (int it = 0; it < 8; it += 2) {
                 f32x4 gv[2], pv[2], mv[2], vv[2];
@@ -698,8 +702,8 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
                     if (f.sb) *(bf16x4*)(f.sb + idx[u]) = __builtin_convertvector(pv[u], bf16x4);
                 }
             }
-            if (h == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this half are done before it is overwritten
         }
+        if (h == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this half are done before it is overwritten
     }
 }
 

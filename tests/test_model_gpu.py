@@ -615,7 +615,7 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         for _ in range(3):
             step.run()
         torch.cuda.synchronize()
-        res[mode] = (flat["param"].clone(), float(step.loss), opt._flat_state[0].clone(), opt._flat_state[1].clone(), flat["shadow"].clone())
+        res[mode] = (flat["param"].clone(), float(step.loss.detach()), opt._flat_state[0].clone(), opt._flat_state[1].clone(), flat["shadow"].clone())
         flat["state"].clear()
         del step, opt, m, flat
     if "staged_eager" in res:

@@ -25,7 +25,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
 # (family, regex on the demangled kernel name)
 FAMILIES = [
-    ("AdamW (fp32 master + moments, bf16 shadow)", r"adamw_kernel"),
+    ("AdamW (fp32 master + moments, bf16 shadow)", r"adamw_kernel|adamw_ranges_kernel"),
     ("ViT Linear GEMMs fwd + data-grad (bf16 operands)", r"gemm_bf16_kernel|gemm_bf16_big_kernel|splitk_reduce_kernel<.*EpBf"),
     ("ViT Linear weight-grad (grouped)", r"gemm_bf16_grouped_wgrad|gemm_grouped_wgrad"),
     ("attention fwd + bwd", r"attn16_|attn_fwd|attn_bwd"),
@@ -38,17 +38,19 @@ FAMILIES = [
 ]
 
 
-def _arch(B):
-    """algorithmic work per step of config[1] at batch B (bytes with bf16 feature maps, flops = 2 MAC)"""
+def _arch(B, fused_update=False):
+    """algorithmic work per step of config[1] at batch B (bytes with bf16 feature maps, flops = 2 MAC).  fused_update: AdamW of the
+    88.3 M ViT Linear weights runs in the epilogue of the grouped weight-gradient launch (26 bytes per weight there -- masters and
+    moments read + written, bf16 shadow written -- instead of a 4-byte gradient store plus 30 bytes in the optimizer kernel)"""
     P = 92452868
     res = [(96 ** 3, 1, 16), (12 ** 3, 256, 128), (24 ** 3, 128, 64), (48 ** 3, 64, 32), (96 ** 3, 32, 16)]   # (V, Cin, Cout) of the 5 UnetResBlocks
     a = {}
-    a["AdamW (fp32 master + moments, bf16 shadow)"] = dict(bytes=30.0 * P, flops=0.0)
+    a["AdamW (fp32 master + moments, bf16 shadow)"] = dict(bytes=30.0 * (P - 88.3e6 if fused_update else P), flops=0.0)
     lin_fwd = B * 1e9 * (1.359 + 12 * (0.7644 + 0.2548 + 2.0384))
     lin_dg = B * 1e9 * 12 * (0.7644 + 0.2548 + 2.0384)
     # per GEMM: bf16 operands + fp32/bf16 outputs are a few MB; the weights dominate: 88.3 M params x 2 B, read fwd and dgrad
     a["ViT Linear GEMMs fwd + data-grad (bf16 operands)"] = dict(bytes=2 * 2.0 * 88.3e6, flops=lin_fwd + lin_dg)
-    a["ViT Linear weight-grad (grouped)"] = dict(bytes=4.0 * 88.3e6, flops=lin_fwd)
+    a["ViT Linear weight-grad (grouped)"] = dict(bytes=(26.0 if fused_update else 4.0) * 88.3e6, flops=lin_fwd)
     a["attention fwd + bwd"] = dict(bytes=B * 216 * 768 * 2.0 * 12 * (4 + 7), flops=B * 1e9 * 12 * 0.1434 * 3.5)
     a["LayerNorm fwd + bwd"] = dict(bytes=B * 216 * 768 * (25 * (4 + 2) + 25 * (4 * 3 + 4 + 2)), flops=0.0)
     inb = cvb = cwb = 0.0
@@ -144,7 +146,7 @@ def _pmc_traffic(kernel_rx):
 
 def step_report(pkg, step, batch, precision, ms_per_step):
     times = _kernel_times(step.run)
-    arch = _arch(batch)
+    arch = _arch(batch, fused_update=any(re.search(r"grouped_wgrad_kernel<.*true>", k) for k in times))
     fam = collections.OrderedDict()
     for name, (us, n) in times.items():
         f = _family_of(name)
