@@ -563,8 +563,10 @@ def test_c2_bench_path_bf16_parity(pkg, dev):
     # the benched step: AdamW on arenas, graph replay; losses of steps 1..4 against the oracle's
     o_ref = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=1e-5)
     opt = pkg.AdamW(hip.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
-    step = pkg.TrainStep(hip, crit, opt, xd, yd, use_graph=True, warmup=2)       # 2 eager steps, then capture (1 more: capture runs nothing)
-    assert step.graphs is not None and len(step.graphs) == 1
+    # (fuse_update as bench.py runs it at N=1: AdamW of the ViT Linear weights in the weight-gradient epilogue; held bit for bit to
+    # the separate optimizer launch by test_staged_backward_equals_single_pass)
+    step = pkg.TrainStep(hip, crit, opt, xd, yd, use_graph=True, warmup=2, fuse_update=True)     # 2 eager steps, then capture (1 more: capture runs nothing)
+    assert step.graphs is not None and len(step.graphs) == 1 and step.fuse
     l_ref = [float(oracle_train_step(ref, o_ref, x, y)) for _ in range(4)]
     traj = [abs(float(step.first_loss) - l_ref[0]) / l_ref[0]]
     step.run()                                                                     # optimizer step 3 (graph replay)
