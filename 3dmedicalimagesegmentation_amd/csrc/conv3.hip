@@ -785,39 +785,52 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 #pragma unroll
                     for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)slab * Cout + (nt0 + j) * 16 + r) * 64 + g * 16);
                 }
-                // 108 (tap, row) steps, software-pipelined like the pair loop above: window fragments DPT steps ahead, the weight
-                // fragments of the next tap one tap ahead
-                constexpr int NSTEP = 27 * 4, DPT = NTB == 1 ? 10 : 8;
+                // 108 (tap, row) MFMA steps walked as 9 (dz, dx) groups of 12 (dy, output row i) steps: the window fragment of input row
+                // dy + i is the same for every (dy, i) with that sum, so a group reads SIX row fragments for its twelve steps (54 window
+                // reads per tile instead of 108; with Cout = 16 every fragment feeds one MFMA and the 135 ds_read_b128 of a wave's tile
+                // kept the CU's LDS pipe busier than its matrix pipes).  Software-pipelined as before: the six fragments of the next
+                // group are requested behind the first six steps of this one, the weight fragments of the next tap one tap ahead.
                 const char* hw = halo + (wv * HY * HX) * PITCH;
-                auto afrag = [&](int s) {
-                    const int tap = s >> 2, i = s & 3;
-                    const int dz = tap / 9, dy = (tap % 9) / 3, dx = tap % 3;
-                    return *(const u32x4*)(hw + ((dz * HY + dy) * HX + i * HX) * PITCH + xo3[dx]);
+                auto rfrag = [&](int grp, int row) {
+                    const int dz = grp / 3, dx = grp % 3;
+                    return *(const u32x4*)(hw + ((dz * HY + row) * HX) * PITCH + xo3[dx]);
                 };
-                u32x4 ring[DPT], bw[2][NTB];
+                u32x4 fr[2][6], bw[2][NTB];
 #pragma unroll
                 for (int j = 0; j < NTB; ++j) bw[0][j] = *(const u32x4*)(wb + j * 1024);
 #pragma unroll
-                for (int s = 0; s < DPT; ++s) ring[s] = afrag(s);
+                for (int q = 0; q < 6; ++q) fr[0][q] = rfrag(0, q);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s) {
-                    const int tap = s >> 2, i = s & 3;
-                    if (i == 0 && tap + 1 < 27) {
+                for (int grp = 0; grp < 9; ++grp) {
+                    const int dz = grp / 3, dx = grp % 3;
 #pragma unroll
-                        for (int j = 0; j < NTB; ++j) bw[(tap + 1) & 1][j] = *(const u32x4*)(wb + ((tap + 1) * NTB + j) * 1024);
-                    }
-                    const u32x4 a = ring[s % DPT];
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int tap = dz * 9 + dy * 3 + dx;
+                        const int ord = grp * 3 + dy;                      // position of this tap in the walk (weights double-buffered along it)
+                        // the tap that follows in the walk
+                        const int ngrp = dy < 2 ? grp : grp + 1, ndy = dy < 2 ? dy + 1 : 0;
+                        const int ntap = (ngrp / 3) * 9 + ndy * 3 + ngrp % 3;
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], bw[tap & 1][j], a);
-                    if constexpr (has3) {
-                        if (tap == 13) {
+                        for (int i = 0; i < 4; ++i) {
+                            if (i == 0 && ord + 1 < 27) {
 #pragma unroll
-                            for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
+                                for (int j = 0; j < NTB; ++j) bw[(ord + 1) & 1][j] = *(const u32x4*)(wb + (ntap * NTB + j) * 1024);
+                            }
+                            const u32x4 a = fr[grp & 1][dy + i];
+#pragma unroll
+                            for (int j = 0; j < NTB; ++j) P::mma(acc[i][j], bw[ord & 1][j], a);
+                            if constexpr (has3) {
+                                if (tap == 13) {
+#pragma unroll
+                                    for (int j = 0; j < NTB; ++j) P::mma(acc3[i][j], w3res[j], a);
+                                }
+                            }
+                            const int k = dy * 4 + i;
+                            if (k < 6 && grp + 1 < 9) fr[(grp + 1) & 1][k] = rfrag(grp + 1, k);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (s + DPT < NSTEP) ring[s % DPT] = afrag(s + DPT);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 ++wit;
             } else {
