@@ -323,10 +323,15 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
         for _, _, lo, hi in opt._flat_runs(params, pattern):
             dist.all_reduce(flat["grad"][lo:hi], op=dist.ReduceOp.SUM)
 
+    patterns = {}          # stage -> which parameters receive gradients (recorded by the first, unfused, step)
+
     def step():
         last = None
         for axis in (2, 3, 4):
             for stage in ("feat", "recon"):
+                fused = dist is None and stage in patterns
+                if fused:
+                    opt.begin_fused_step(patterns[stage])
                 if stage == "feat":
                     inp, _ = model(x)
                     init_idx = 1                           # enc4 is 12^3: partition size 3
@@ -337,9 +342,17 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
                 if dist is not None:
                     (loss / world).backward()
                     reduce_grads()
+                    opt.step()
+                elif fused:
+                    # (the optimizer was armed before the forward: AdamW of the ViT weights rides on the weight-gradient launch that
+                    # ends this backward pass -- the three "feat" passes; the frozen-encoder passes update the conv side only)
+                    loss.backward()
+                    opt.finish_fused_step()
                 else:
                     loss.backward()
-                opt.step()
+                    if flat is not None and args.fuse_update:
+                        patterns[stage] = tuple(p.grad is not None for p in opt.param_groups[0]["params"])
+                    opt.step()
                 opt.zero_grad(set_to_none=True)
                 last = loss
         return last
