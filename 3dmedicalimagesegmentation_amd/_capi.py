@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
-ABI_VERSION = 6        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 7        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -83,6 +83,8 @@ _SIGNATURES = {
     "unetr_gemm_bf16_grouped_wgrad": [ctypes.POINTER(GroupedProblem), c_int, P],
     "unetr_gemm_bf16_grouped_wgrad_adamw": [ctypes.POINTER(GroupedProblem), c_int, ctypes.POINTER(AdamWArena), ctypes.POINTER(c_int), P],
     "unetr_adamw_ranges": [ctypes.POINTER(AdamWArena), P, c_int, c_long, P],
+    "unetr_gemm_bf16_grouped_wgrad_bf16out": [ctypes.POINTER(GroupedProblem), c_int, P, P, c_long, P],
+    "unetr_cast_bf16_ranges": [P, P, P, c_int, c_long, P],
     "unetr_colsum_grouped": [ctypes.POINTER(ColsumProblem), c_int, P],
     "unetr_tconv_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_tconv_dgrad": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],

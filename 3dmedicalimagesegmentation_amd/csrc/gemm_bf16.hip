@@ -548,7 +548,7 @@ struct GwProblem { const uint16_t* dy; const uint16_t* x; float* dw; int M, N, K
 struct GwFuse { float* pb; const float* gb; float* mb; float* vb; uint16_t* sb; const float* steps; float lr, b1, b2, eps, wd; };
 struct GwArgs { int n; GwFuse f; GwProblem p[GW_MAX]; };
 
-template <int NS, int BKT, bool FUSE>                       // BKT = tokens per stage (64 or 32)
+template <int NS, int BKT, int FUSE>                        // BKT = tokens per stage (64 or 32); FUSE: 0 store dW, 1 AdamW, 2 store bf16(dW)
 __global__ void __launch_bounds__(256, GW_WAVES)
 gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
     constexpr int BT = 128;                                // output tile 128 x 128
@@ -644,7 +644,7 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
     const int kcol = k0 + wn * 64 + rc * 4;
     [[maybe_unused]] AdamWCoef c{};
     [[maybe_unused]] long off0 = 0;
-    if constexpr (FUSE) {
+    if constexpr (FUSE == 1) {
         c = adamw_coef(ga.f.lr, ga.f.b1, ga.f.b2, ga.f.eps, ga.f.wd, ga.f.steps[pr.step_idx]);
         off0 = pr.dw - ga.f.gb;
     }
@@ -658,7 +658,17 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
                 *(f32x4*)(stg + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4)) = acc[2 * h + ii][j];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (wave-private region: no barrier)
-        if constexpr (!FUSE) {
+        if constexpr (FUSE == 2) {
+            // data-parallel step with bf16 gradient communication: the gradient goes straight into the communication buffer (laid
+            // out like the arena) as bf16 -- what the separate cast pass would have made of the fp32 store, which never happens
+            const long offg = pr.dw - ga.f.gb;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 4 + rr, n = n0 + wm * 64 + h * 32 + r;
+                const f32x4 gv = *(const f32x4*)(stg + r * 256 + ((rc ^ (r & 15)) << 4));
+                if (n < pr.N && kcol < pr.K) *(bf16x4*)(ga.f.sb + offg + (long)n * pr.K + kcol) = __builtin_convertvector(gv, bf16x4);
+            }
+        } else if constexpr (FUSE == 0) {
             // dW is written once and next read by AdamW after 350 MB of other gradients: non-temporal
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -850,6 +860,32 @@ extern "C" int unetr_cast_bf16(const float* src, void* dst, long n, void* stream
     return unetr_check_launch();
 }
 
+// fp32 -> bf16 over a table of arena ranges (DEVICE memory, 3 longs per range: element offsets lo, hi -- multiples of 8 -- and the
+// range's first block of 8192 elements): the gradient ranges the bf16-storing weight-gradient epilogue did not cover
+__global__ void __launch_bounds__(256) cast_bf16_ranges_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                               const long* __restrict__ table, int nr) {
+    int lo_r = 0, hi_r = nr - 1;
+    const long blk = blockIdx.x;
+    while (lo_r < hi_r) {
+        const int mid = (lo_r + hi_r + 1) >> 1;
+        if (table[3 * mid + 2] <= blk) lo_r = mid; else hi_r = mid - 1;
+    }
+    const long beg = table[3 * lo_r] + (blk - table[3 * lo_r + 2]) * 8192, end = min(table[3 * lo_r + 1], beg + 8192);
+    for (long i = beg / 8 + threadIdx.x; i < end / 8; i += 256) {
+        const f32x4 a = ((const f32x4*)src)[2 * i], b = ((const f32x4*)src)[2 * i + 1];
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        ((u32x4*)dst)[i] = PrecBF16::pack(v);
+    }
+}
+
+extern "C" int unetr_cast_bf16_ranges(const float* src_arena, void* dst_arena, const long* table_dev, int n_ranges, long n_blocks, void* stream) {
+    if (!src_arena || !dst_arena || !table_dev || n_ranges <= 0 || n_blocks <= 0 || n_blocks > 0x7fffffffL) return UNETR_ERR_ARG;
+    if (((uintptr_t)src_arena & 31) || ((uintptr_t)dst_arena & 15)) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cast_bf16_ranges_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, src_arena, (uint16_t*)dst_arena,
+                       table_dev, n_ranges);
+    return unetr_check_launch();
+}
+
 extern "C" int unetr_add_cast_bf16(const float* a, const float* b, float* out, void* out_bf16, long n, void* stream) {
     if (!a || !b || !out || n <= 0) return UNETR_ERR_ARG;
     if ((n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) || ((uintptr_t)out_bf16 & 7)) return UNETR_ERR_UNSUPPORTED;
@@ -859,11 +895,14 @@ extern "C" int unetr_add_cast_bf16(const float* a, const float* b, float* out, v
 }
 
 // dw_i[N_i, K_i] = dy_i[M_i, N_i]^T * x_i[M_i, K_i] on bf16-stored dy / x (dense row-major), one launch per <= 64 problems;
-// a: optimizer arenas -> the epilogue applies AdamW (step count a->steps[step_index[i]]) instead of storing dw
-static int grouped_wgrad_bf16(const unetr_grouped_problem* probs, int n, const unetr_adamw_arena* a, const int* step_index, void* stream) {
+// a: optimizer arenas -> the epilogue applies AdamW (step count a->steps[step_index[i]]) instead of storing dw;
+// b16: a with only grad / shadow_bf16 / total set -> the epilogue stores bf16(dw) at the arena offset of dw in shadow_bf16
+static int grouped_wgrad_bf16(const unetr_grouped_problem* probs, int n, const unetr_adamw_arena* a, const int* step_index, void* stream,
+                              bool b16 = false) {
     if (!probs || n <= 0) return UNETR_ERR_ARG;
-    if (a && (!a->param || !a->grad || !a->m || !a->v || !a->steps || !step_index || a->total <= 0)) return UNETR_ERR_ARG;
-    if (a && ((((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->m | (uintptr_t)a->v) & 15) || ((uintptr_t)a->shadow_bf16 & 7))) return UNETR_ERR_UNSUPPORTED;
+    if (b16 && (!a || !a->grad || !a->shadow_bf16 || a->total <= 0 || ((uintptr_t)a->grad & 15) || ((uintptr_t)a->shadow_bf16 & 7))) return UNETR_ERR_ARG;
+    if (a && !b16 && (!a->param || !a->grad || !a->m || !a->v || !a->steps || !step_index || a->total <= 0)) return UNETR_ERR_ARG;
+    if (a && !b16 && ((((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->m | (uintptr_t)a->v) & 15) || ((uintptr_t)a->shadow_bf16 & 7))) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += GW_MAX) {
         GwArgs ga;
@@ -877,25 +916,33 @@ static int grouped_wgrad_bf16(const unetr_grouped_problem* probs, int n, const u
             if (q.M % 8 || q.N % 8 || q.K % 8 || ((uintptr_t)q.dy & 15) || ((uintptr_t)q.x & 15) || ((uintptr_t)q.dw & 15)) return UNETR_ERR_UNSUPPORTED;
             if (a) {       // dw names a slice of the gradient arena
                 const long off = q.dw - a->grad;
-                if (q.dw < a->grad || off + (long)q.N * q.K > a->total || step_index[base + i] < 0) return UNETR_ERR_ARG;
+                if (q.dw < a->grad || off + (long)q.N * q.K > a->total || (!b16 && step_index[base + i] < 0)) return UNETR_ERR_ARG;
             }
             GwProblem& g = ga.p[i];
             g.dy = (const uint16_t*)q.dy; g.x = (const uint16_t*)q.x; g.dw = q.dw; g.M = q.M; g.N = q.N; g.K = q.K;
             g.tile0 = tiles; g.ntn = cdiv(q.N, 128);
-            g.step_idx = a ? step_index[base + i] : 0;
+            g.step_idx = a && !b16 ? step_index[base + i] : 0;
             tiles += g.ntn * cdiv(q.K, 128);
         }
         // 32 tokens per stage, two stages: 32 KB of LDS per workgroup -> four workgroups per CU.  The launch is latency-bound per
         // K step (7-14 short steps per tile, operands out of HBM / MALL); measured at 432 rows (tools/probe_gw.py, us):
         // 64 tokens x 2 stages (two workgroups per CU) 201, 32 x 2 178, 32 x 3 190, 32 x 4 203, 64 x 3 268, 64 x 4 245
-        if (a) hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32, true>), dim3(tiles), dim3(256), 0, st, ga);
-        else hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32, false>), dim3(tiles), dim3(256), 0, st, ga);
+        if (b16) hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32, 2>), dim3(tiles), dim3(256), 0, st, ga);
+        else if (a) hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32, 1>), dim3(tiles), dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_kernel<2, 32, 0>), dim3(tiles), dim3(256), 0, st, ga);
     }
     return unetr_check_launch();
 }
 
 extern "C" int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs, int n, void* stream) {
     return grouped_wgrad_bf16(probs, n, nullptr, nullptr, stream);
+}
+
+extern "C" int unetr_gemm_bf16_grouped_wgrad_bf16out(const unetr_grouped_problem* probs, int n, const float* grad_arena, void* out_bf16_arena,
+                                                     long total, void* stream) {
+    unetr_adamw_arena a{};
+    a.grad = grad_arena; a.shadow_bf16 = out_bf16_arena; a.total = total;
+    return grouped_wgrad_bf16(probs, n, &a, nullptr, stream, true);
 }
 
 extern "C" int unetr_gemm_bf16_grouped_wgrad_adamw(const unetr_grouped_problem* probs, int n, const unetr_adamw_arena* a,

@@ -185,7 +185,10 @@ def _launch_deferred(wq, cq, wbq=(), prec=0, fuse=None):
                 arr[i].dy, arr[i].x, arr[i].dw = dyb.data_ptr(), xb.data_ptr(), out.data_ptr()
                 arr[i].M, arr[i].N, arr[i].K = dyb.shape[0], dyb.shape[1], xb.shape[1]
                 idx[i] = pi
-            call("unetr_gemm_bf16_grouped_wgrad_adamw", arr, len(fused), ctypes.byref(fuse["arena"]), idx, _stream())
+            if fuse.get("kind") == "bf16out":      # data-parallel step, bf16 communication: bf16(dW) straight into the comm buffer
+                call("unetr_gemm_bf16_grouped_wgrad_bf16out", arr, len(fused), fuse["grad"], fuse["out"], fuse["total"], _stream())
+            else:
+                call("unetr_gemm_bf16_grouped_wgrad_adamw", arr, len(fused), ctypes.byref(fuse["arena"]), idx, _stream())
             fuse["done"].extend(pi for _, pi in fused)
     if wbq:
         arr = (_capi.GroupedProblem * len(wbq))()

@@ -47,11 +47,14 @@ def split_range(flat, lo, hi, pieces):
 
 class TrainStep:
     def __init__(self, model, criterion, optimizer, x, y, *, use_graph=True, data_parallel=False, process_group=None,
-                 comm_dtype=torch.float32, tail_pieces=2, warmup=2, overlap_update=False, fuse_update=False):
+                 comm_dtype=torch.float32, tail_pieces=2, warmup=2, overlap_update=False, fuse_update=False, fuse_comm=True):
         """fuse_update (single GPU, flat arenas): AdamW of the ViT Linear weights (92 % of the parameters) is applied in the
         epilogue of the grouped weight-gradient launch that ends backward -- their gradients are never stored or re-read (8 of
         34 bytes per weight) and the optimizer's streaming hides under that launch's MFMA work; one table-driven AdamW launch
         covers the rest.  Same bits as the unfused step.  ``p.grad`` of the fused weights is NOT valid afterwards.
+        fuse_comm (data parallel, bf16 gradient communication): the grouped weight-gradient launch of every backward pass writes
+        bf16 gradients straight into the communication buffer (no fp32 gradient store, no cast pass over them); one table-driven
+        cast per piece covers the other parameters.  Same bits in the communication buffer as the separate cast.
         overlap_update (single GPU): the data-parallel launch form without a process group -- backward in passes, AdamW on
         each pass's arena range on the side stream underneath the passes that follow -- captured as ONE hipGraph in which the
         side stream is a branch: the bandwidth-bound optimizer kernels hide under the latency-bound ViT backward chain."""
@@ -76,6 +79,9 @@ class TrainStep:
                 self.world = dist.get_world_size(process_group)
         self.comm_dtype = comm_dtype
         self.in_place = comm_dtype == torch.float32
+        self.fuse_comm = bool(fuse_comm) and self.dp and comm_dtype == torch.bfloat16 and not self.overlap
+        self._comm_fuse = None         # armed for the backward passes of a step once the gradient pattern is known
+        self._cast_tables = {}
         self.one_graph = False
         self.loss = None
         self._one = torch.ones((), dtype=torch.float32, device=x.device)
@@ -102,7 +108,7 @@ class TrainStep:
             Fn.workspace(x.device)                      # exists before any capture on this stream
             # (fused update: the first eager step runs unfused and records the gradient pattern, the second builds the range
             # table of the fused form -- both must exist before capture)
-            for _ in range(max(2 if self.fuse else 1, warmup)):
+            for _ in range(max(2 if (self.fuse or self.fuse_comm) else 1, warmup)):
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -137,6 +143,13 @@ class TrainStep:
 
     # ---------------------------------------------------------------------------------------- data parallel
     def _pass0(self):
+        if self.fuse_comm and self._plan is not None:
+            if self._comm_fuse is None:
+                flat = self.flat
+                gbase = flat["grad"].data_ptr()
+                index = {gbase + o * 4: i for i, (o, has) in enumerate(zip(flat["offsets"], self._plan["pattern"])) if has}
+                self._comm_fuse = dict(kind="bf16out", grad=gbase, out=self.comm_buf.data_ptr(), total=flat["param"].numel(), index=index, done=[])
+            self.flat["state"].fuse = self._comm_fuse
         _, logits, self.stages = self.model.forward_staged(self.x)
         self.loss = self.crit(logits, self.y)
         self._backward()
@@ -146,6 +159,8 @@ class TrainStep:
         roots = [r for r, leaf in st if leaf.grad is not None]
         if roots:
             torch.autograd.backward(roots, [leaf.grad for r, leaf in st if leaf.grad is not None])
+        if k == self.npass - 1 and self._comm_fuse is not None and self.flat["state"].fuse is self._comm_fuse:
+            self.flat["state"].fuse = None             # the last pass of the step has queued its weight-gradient launch
 
     def _reduce_and_update(self, k):
         """Pass k has been launched on the current stream.  On the communication stream, behind it: all-reduce each of its
@@ -170,7 +185,10 @@ class TrainStep:
             for lo, hi in self.pieces[k]:
                 buf = src[lo:hi]
                 if not self.in_place:
-                    Fn.cast_bf16(g[lo:hi], out=buf)
+                    if self._comm_fuse is not None:      # (armed in every step since the pattern is known: eager, captured, replayed)
+                        self._cast_rest(lo, hi)
+                    else:
+                        Fn.cast_bf16(g[lo:hi], out=buf)
                 works.append(self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
                              if self.dist is not None else None)
             for (lo, hi), work in zip(self.pieces[k], works):
@@ -181,6 +199,28 @@ class TrainStep:
                 self.opt.end_reduced_step(self._plan)
         if k == len(self.pieces) - 1:
             main.wait_stream(self.comm_stream)        # the next forward reads the updated parameters
+
+    def _cast_rest(self, lo, hi):
+        """fp32 -> bf16 of the gradient ranges of piece [lo, hi) that the weight-gradient epilogue did not already write into the
+        communication buffer (everything but the ViT weight matrices), as ONE table-driven launch"""
+        ent = self._cast_tables.get((lo, hi))
+        if ent is None:
+            flat = self.flat
+            params = flat["params"]
+            done = sorted(flat["offsets"][i] for i in set(self._comm_fuse["done"]) if lo <= flat["offsets"][i] < hi)
+            numel = {flat["offsets"][i]: (params[i].numel() + 7) // 8 * 8 for i in set(self._comm_fuse["done"])}
+            rows, blocks, cur = [], 0, lo
+            for o in done + [hi]:
+                if o > cur:
+                    rows.append((cur, o, blocks))
+                    blocks += (o - cur + 8191) // 8192
+                cur = max(cur, o + numel.get(o, 0))
+            table = torch.tensor(rows, dtype=torch.int64, device=flat["param"].device) if rows else None
+            ent = self._cast_tables[(lo, hi)] = (table, len(rows), blocks)
+        table, nr, blocks = ent
+        if nr:
+            Fn.call("unetr_cast_bf16_ranges", self.flat["grad"].data_ptr(), self.comm_buf.data_ptr(), table.data_ptr(), nr, blocks,
+                    torch.cuda.current_stream().cuda_stream)
 
     def _make_plan(self):
         """which parameters step (MONAI's ViT carries an unused cls_token: no gradient, skipped like torch.optim.AdamW does),

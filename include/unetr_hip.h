@@ -33,7 +33,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 6
+#define UNETR_ABI_VERSION 7
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -357,6 +357,14 @@ typedef struct {
  * (torch.nn.Linear backward + torch.optim.AdamW.step, unetr_segmentation_3d.py:224-225), 8 bytes per weight less HBM traffic. */
 int unetr_gemm_bf16_grouped_wgrad_adamw(const unetr_grouped_problem* probs, int n, const unetr_adamw_arena* a,
                                         const int* step_index, void* stream);
+/* the data-parallel counterpart (bf16 gradient communication, BASELINE.json configs[2]): the same grouped weight gradients stored
+ * as bf16 at the arena offset of probs[i].dw (a slice of grad_arena, NOT written) in out_bf16_arena -- the communication buffer --
+ * i.e. what unetr_cast_bf16 makes of the fp32 gradient, without the fp32 store, the cast pass and its re-read; and the cast of
+ * every other gradient range in one launch (table in DEVICE memory, 3 longs per range: element offsets lo, hi -- multiples of
+ * 8 --, first block of the range in blocks of 8192 elements, running sum; n_blocks = total). */
+int unetr_gemm_bf16_grouped_wgrad_bf16out(const unetr_grouped_problem* probs, int n, const float* grad_arena, void* out_bf16_arena,
+                                          long total, void* stream);
+int unetr_cast_bf16_ranges(const float* src_arena, void* dst_arena, const long* table_dev, int n_ranges, long n_blocks, void* stream);
 /* AdamW over n_ranges arena ranges in ONE launch (the parameters the fused launch above did not cover: biases, LayerNorm,
  * conv weights ...).  table (DEVICE memory, 4 longs per range): element offset lo, element offset hi (multiples of 4 as the
  * arena packs them), index into a->steps, first block of the range (blocks of 4096 elements, running sum); n_blocks = total. */

@@ -591,7 +591,8 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
     x, y = synthetic_volume(2, 1, S, ncls, seed=41)
     xd, yd = x.to(dev), y.to(dev)
     res = {}
-    modes = (("single", "staged_eager", "staged_graph", "staged_bf16comm", "overlap_one_graph", "fused_eager", "fused_graph") if size == "c1"
+    modes = (("single", "staged_eager", "staged_graph", "staged_bf16comm", "staged_bf16comm_nofuse", "staged_bf16comm_eager", "overlap_one_graph",
+              "fused_eager", "fused_graph") if size == "c1"
              else ("single", "staged_graph", "fused_graph"))
     for mode in modes:
         torch.manual_seed(11)
@@ -601,8 +602,10 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         opt = pkg.AdamW(m.parameters(), lr=lr, weight_decay=1e-5, flat=flat)
         crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
         step = pkg.TrainStep(m, crit, opt, xd, yd, use_graph=not mode.endswith("_eager"), data_parallel=mode.startswith("staged"),
-                             comm_dtype=torch.bfloat16 if mode == "staged_bf16comm" else torch.float32, warmup=2,
-                             overlap_update=mode == "overlap_one_graph", fuse_update=mode.startswith("fused"))
+                             comm_dtype=torch.bfloat16 if "bf16comm" in mode else torch.float32, warmup=2,
+                             overlap_update=mode == "overlap_one_graph", fuse_update=mode.startswith("fused"), fuse_comm="nofuse" not in mode)
+        if "bf16comm" in mode:               # bf16(dW) of the ViT weights straight from the weight-gradient epilogue into the comm buffer
+            assert step.fuse_comm == ("nofuse" not in mode) and (step._comm_fuse is not None) == step.fuse_comm
         if mode.startswith("fused"):         # AdamW of the 48 Linear weights + patch embedding rides on the weight-gradient launch
             assert step.fuse and step._fuse_pattern is not None and "epilogue" in step.launch or mode == "fused_eager"
         if mode == "overlap_one_graph":      # the same passes + side-stream AdamW as ONE graph (the side stream is a branch of it)
@@ -612,7 +615,7 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
             if size == "c2":        # the tail that cannot overlap with backward: block 0 + patch embedding, 41 MB of 370 MB
                 tail = sum(hi - lo for lo, hi in step.pieces[4]) * 4
                 assert tail < 45e6 and sum(hi - lo for st in step.pieces for lo, hi in st) * 4 > 365e6
-            if mode != "staged_eager":      # pass 0 hands nothing over: it shares a graph with pass 1
+            if not mode.endswith("_eager"):      # pass 0 hands nothing over: it shares a graph with pass 1
                 assert len(step.graphs) == 4 and step.graph_passes == [[0, 1], [2], [3], [4]]
         for _ in range(3):
             step.run()
@@ -631,6 +634,9 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         assert res["single"][1] == res[mode][1]
     if "staged_bf16comm" in res:
         assert relerr(res["staged_bf16comm"][0], res["single"][0]) < 1e-2       # bf16-rounded gradients: close, not equal
+        for other in ("staged_bf16comm_nofuse", "staged_bf16comm_eager"):        # the epilogue's bf16 gradients = the cast pass's
+            for k in (0, 2, 3, 4):
+                assert torch.equal(res["staged_bf16comm"][k], res[other][k]), (other, k)
 
 
 @pytest.mark.parametrize("mode,size", [("eager", "c1"), ("graph", "c1"), ("graph", "c2")])
