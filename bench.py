@@ -54,6 +54,8 @@ def parse(argv=None):
                     "(measured SLOWER on MI355X / ROCm 7.2: 5.46 vs 5.00 ms per step -- a branch in a hipGraph costs more than the optimizer kernels it hides)")
     ap.add_argument("--fuse-update", type=int, default=1, help="N=1: AdamW of the ViT Linear weights in the epilogue of the grouped weight-gradient "
                     "launch (same bits as the separate optimizer launch; 0 = separate)")
+    ap.add_argument("--handover", default="host", choices=["host", "stream"], help="N>1: how the communication stream learns that a backward pass "
+                    "has ended (host: the launching thread waits for the pass's event one graph behind; stream: cross-stream wait per pass)")
     ap.add_argument("--fuse-comm", type=int, default=1, help="N>1 with bf16 gradient communication: the weight-gradient epilogue writes bf16 gradients "
                     "straight into the communication buffer (same bits as the separate cast; 0 = fp32 store + cast pass)")
     ap.add_argument("--bf16-comm", action="store_true", help="all-reduce gradients in bf16 (the default when more than one rank runs in bf16 mode)")
@@ -226,7 +228,7 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
         step = pkg.TrainStep(model, crit, opt, x, y, use_graph=not args.no_graph, data_parallel=ddp_on, comm_dtype=comm_dtype,
                              overlap_update=bool(args.overlap_update) and flat is not None and not ddp_on,
                              fuse_update=bool(args.fuse_update) and flat is not None and not ddp_on and not args.overlap_update,
-                             fuse_comm=bool(args.fuse_comm))
+                             fuse_comm=bool(args.fuse_comm), handover=args.handover)
     except Exception as e:  # noqa: BLE001
         if args.no_graph:
             raise

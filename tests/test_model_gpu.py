@@ -591,7 +591,7 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
     x, y = synthetic_volume(2, 1, S, ncls, seed=41)
     xd, yd = x.to(dev), y.to(dev)
     res = {}
-    modes = (("single", "staged_eager", "staged_graph", "staged_bf16comm", "staged_bf16comm_nofuse", "staged_bf16comm_eager", "overlap_one_graph",
+    modes = (("single", "staged_eager", "staged_graph", "staged_graph_streamwait", "staged_bf16comm", "staged_bf16comm_nofuse", "staged_bf16comm_eager", "overlap_one_graph",
               "fused_eager", "fused_graph") if size == "c1"
              else ("single", "staged_graph", "fused_graph"))
     for mode in modes:
@@ -603,7 +603,8 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
         step = pkg.TrainStep(m, crit, opt, xd, yd, use_graph=not mode.endswith("_eager"), data_parallel=mode.startswith("staged"),
                              comm_dtype=torch.bfloat16 if "bf16comm" in mode else torch.float32, warmup=2,
-                             overlap_update=mode == "overlap_one_graph", fuse_update=mode.startswith("fused"), fuse_comm="nofuse" not in mode)
+                             overlap_update=mode == "overlap_one_graph", fuse_update=mode.startswith("fused"), fuse_comm="nofuse" not in mode,
+                             handover="stream" if mode.endswith("streamwait") else "host")
         if "bf16comm" in mode:               # bf16(dW) of the ViT weights straight from the weight-gradient epilogue into the comm buffer
             assert step.fuse_comm == ("nofuse" not in mode) and (step._comm_fuse is not None) == step.fuse_comm
         if mode.startswith("fused"):         # AdamW of the 48 Linear weights + patch embedding rides on the weight-gradient launch
@@ -628,6 +629,8 @@ def test_staged_backward_equals_single_pass(pkg, dev, size):
         assert torch.equal(res["single"][0], res["overlap_one_graph"][0])
     assert torch.equal(res["single"][0], res["staged_graph"][0])
     assert res["single"][1] == res["staged_graph"][1]
+    if "staged_graph_streamwait" in res:                        # hand-over by cross-stream wait instead of through the host
+        assert torch.equal(res["single"][0], res["staged_graph_streamwait"][0])
     for mode in (k for k in res if k.startswith("fused")):      # the fused optimizer epilogue: masters, both moments, bf16 shadows, loss
         for k in (0, 2, 3, 4):
             assert torch.equal(res["single"][k], res[mode][k]), (mode, k)

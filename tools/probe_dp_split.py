@@ -47,7 +47,7 @@ def timed(fn, steps=20, windows=3):
 def main():
     global st, all_pieces, hip, flag, one, count, Fn
     st = build(False)
-    only = os.environ.get("PROBE_ONLY", "single,V0,V1,V2,V3,V4,V5").split(",")
+    only = os.environ.get("PROBE_ONLY", "single,V0,V1,V2,V3,V4,V5,V6").split(",")
     if "single" in only:
         print(f"single : {timed(st.run):.3f} ms/step")
     del st
@@ -140,6 +140,35 @@ def main():
         main.wait_stream(st.comm_stream)
 
 
+    def v6():
+        # hand-over through the HOST: an event behind every graph; the launching thread runs one graph ahead, waits for the event
+        # of the pass before (the GPU is busy with the next graph meanwhile) and only then issues that pass's communication-stream
+        # work -- the communication stream never waits on an unfinished event of the main stream
+        main = torch.cuda.current_stream()
+        state = {"steps": None}
+
+        def comm_work(ev, k):
+            ev.synchronize()
+            with torch.cuda.stream(st.comm_stream):
+                if state["steps"] is None:
+                    state["steps"] = st.opt.begin_reduced_step(st._plan)
+                for lo, hi in st.pieces[k]:
+                    st.opt.step_runs(st._plan, st._runs_of[(lo, hi)], state["steps"], st.flat["grad"], 1.0)
+        pending = None
+        for g, ks in zip(st.graphs, st.graph_passes):
+            g.replay()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            if pending is not None:
+                comm_work(*pending)
+            pending = (ev, ks[-1])
+        comm_work(*pending)
+        with torch.cuda.stream(st.comm_stream):
+            st.opt.end_reduced_step(st._plan)
+        main.wait_stream(st.comm_stream)
+
+    if "V6" in only:
+        print(f"V6     : {timed(v6):.3f} ms/step   (graphs + event per graph, hand-over through the host, AdamW per piece on the communication stream)")
     if "V4" in only:
         print(f"V4     : {timed(v4):.3f} ms/step   (5 graphs, flag + wait-value per graph, AdamW afterwards on the main stream)")
     if "V5" in only:
