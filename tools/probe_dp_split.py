@@ -27,7 +27,7 @@ def build(dp):
     flat = model.use_flat_buffers()
     opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
     x, y = synthetic_volume(2, 1, 96, 4, seed=1234)
-    return pkg.TrainStep(model, crit, opt, x.to(dev), y.to(dev), data_parallel=dp)
+    return pkg.TrainStep(model, crit, opt, x.to(dev), y.to(dev), data_parallel=dp, handover=os.environ.get("PROBE_HANDOVER", "stream"))
 
 
 def timed(fn, steps=20, windows=3):

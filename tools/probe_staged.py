@@ -17,7 +17,7 @@ def build(dp):
     opt = pkg.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
     x, y = synthetic_volume(2, 1, 96, 4, seed=0)
     crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
-    return pkg.TrainStep(m, crit, opt, x.to(dev), y.to(dev), data_parallel=dp)
+    return pkg.TrainStep(m, crit, opt, x.to(dev), y.to(dev), data_parallel=dp, handover="stream")
 
 
 def timeit(fn, n=20):
