@@ -401,11 +401,14 @@ def begin_forward(state=None):
     """Called by UNETR.forward.  (1) A derived weight copy that no optimizer of this package keeps in step is trusted for
     ONE forward/backward pass only: a new pass starts a new weight epoch, so the first use re-derives it (a ``.data``
     write between two passes is then always seen; optimizer-maintained copies stay valid, see
-    invalidate_weight_shadows).  (2) Deferred weight-gradient work a failed backward left behind is dropped."""
+    invalidate_weight_shadows).  (2) Deferred weight-gradient work a failed backward left behind is dropped, and so is a fused
+    epilogue (AdamW.begin_fused_step / TrainStep's bf16 communication epilogue) that was armed for a step which never finished."""
     if not torch.cuda.is_current_stream_capturing():
         _WEIGHT_EPOCH[0] += 1
     if state is not None:
         state.reset_deferred()
+        state.fuse = None          # an optimizer / communication epilogue is armed AFTER the forward of the step it belongs to:
+                                   # whatever a failed step left armed must not ride on the next backward
 
 
 def register_weight_shadow(w, shadow):

@@ -126,7 +126,8 @@ class AdamW(torch.optim.Optimizer):
         return True
 
     # ---- single-GPU fused step: AdamW of the ViT Linear weights rides on the grouped weight-gradient launch ----------------
-    # begin_fused_step(pattern) BEFORE backward (step counters advance, the arena state is handed to functional.flush_deferred),
+    # begin_fused_step(pattern) AFTER the forward and BEFORE backward (step counters advance, the arena state is handed to
+    # functional.flush_deferred; the model's next forward drops an arming whose step never finished),
     # finish_fused_step() AFTER backward: one table-driven launch updates every parameter the fused launch did not cover.
     # The gradients of the fused weights are never written: p.grad of those parameters names a stale arena slice.
     @torch.no_grad()

@@ -138,8 +138,8 @@ class TrainStep:
 
     def _single_step(self):
         if self.fuse and self._fuse_pattern is not None:
-            self.opt.begin_fused_step(self._fuse_pattern)
             self.loss = self._fwd_loss()
+            self.opt.begin_fused_step(self._fuse_pattern)      # (armed after the forward: UNETR.forward drops a stale arming)
             self._backward()
             self.opt.finish_fused_step()
         else:
@@ -152,6 +152,7 @@ class TrainStep:
 
     # ---------------------------------------------------------------------------------------- data parallel
     def _pass0(self):
+        _, logits, self.stages = self.model.forward_staged(self.x)
         if self.fuse_comm and self._plan is not None:
             if self._comm_fuse is None:
                 flat = self.flat
@@ -159,7 +160,6 @@ class TrainStep:
                 index = {gbase + o * 4: i for i, (o, has) in enumerate(zip(flat["offsets"], self._plan["pattern"])) if has}
                 self._comm_fuse = dict(kind="bf16out", grad=gbase, out=self.comm_buf.data_ptr(), total=flat["param"].numel(), index=index, done=[])
             self.flat["state"].fuse = self._comm_fuse
-        _, logits, self.stages = self.model.forward_staged(self.x)
         self.loss = self.crit(logits, self.y)
         self._backward()
 

@@ -335,8 +335,6 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
         for axis in (2, 3, 4):
             for stage in ("feat", "recon"):
                 fused = dist is None and stage in patterns
-                if fused:
-                    opt.begin_fused_step(patterns[stage])
                 if stage == "feat":
                     inp, _ = model(x)
                     init_idx = 1                           # enc4 is 12^3: partition size 3
@@ -344,12 +342,14 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
                     _, inp = model(x, freeze_encoder=True)
                     init_idx = 7                           # logits are 96^3: partition size 24
                 loss = pkg.ranking_loss(inp, axis, init_idx, 0.1, kind="ranking")
+                if fused:
+                    opt.begin_fused_step(patterns[stage])      # (after the forward, which drops any stale arming)
                 if dist is not None:
                     (loss / world).backward()
                     reduce_grads()
                     opt.step()
                 elif fused:
-                    # (the optimizer was armed before the forward: AdamW of the ViT weights rides on the weight-gradient launch that
+                    # (the optimizer is armed: AdamW of the ViT weights rides on the weight-gradient launch that
                     # ends this backward pass -- the three "feat" passes; the frozen-encoder passes update the conv side only)
                     loss.backward()
                     opt.finish_fused_step()
