@@ -117,6 +117,95 @@ def test_gemm_bf16_grouped_wgrad(pkg, dev):
         assert relerr(out, ref) < 2e-5, shp
 
 
+def test_grouped_wgrad_fused_epilogues(pkg, dev):
+    """The grouped weight-gradient launch with (a) AdamW in its epilogue (unetr_gemm_bf16_grouped_wgrad_adamw) + the table-driven
+    AdamW over the other arena ranges (unetr_adamw_ranges), and (b) bf16 gradients written into a communication buffer
+    (unetr_gemm_bf16_grouped_wgrad_bf16out) + the table-driven cast (unetr_cast_bf16_ranges): bit for bit what the plain launch
+    followed by unetr_adamw / unetr_cast_bf16 produces (torch.nn.Linear backward + torch.optim.AdamW.step,
+    unetr_segmentation_3d.py:224-225).  Ragged tiles (N, K not multiples of 128), a ragged token count, parameters between the
+    weight matrices that only the range kernels touch, two optimizer steps with per-parameter step counts."""
+    import ctypes
+    capi = pkg._capi
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = [(432, 768, 256), (216, 200, 136), (64, 8, 8), (432, 128, 384)]
+    # arena: [bias-like 40][W0][48][W1][8][W2][W3][24]; every slice a multiple of 8 elements
+    sizes, is_w = [40], [False]
+    for k, (_, N, K) in enumerate(shapes):
+        sizes += [N * K, (48, 8, 0, 24)[k]]
+        is_w += [True, False]
+    sizes, is_w = zip(*[(n, w) for n, w in zip(sizes, is_w) if n])
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += n
+    nparam = len(sizes)
+    torch.manual_seed(5)
+    p0 = (torch.randn(total) * 0.05).to(dev)
+    grads_other = (torch.randn(total) * 0.01).to(dev)
+    ops = [(g(M, N, seed=30 + i).bfloat16().to(dev), g(M, K, seed=40 + i).bfloat16().to(dev)) for i, (M, N, K) in enumerate(shapes)]
+    widx = [i for i, w in enumerate(is_w) if w]
+    hyper = dict(lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2)
+
+    def problems(grad):
+        arr = (capi.GroupedProblem * len(shapes))()
+        for i, ((dy, x), (M, N, K)) in enumerate(zip(ops, shapes)):
+            arr[i].dy, arr[i].x, arr[i].dw = dy.data_ptr(), x.data_ptr(), grad.data_ptr() + 4 * offs[widx[i]]
+            arr[i].M, arr[i].N, arr[i].K = M, N, K
+        return arr
+
+    def run(fused):
+        p, m, v = p0.clone(), torch.zeros(total, device=dev), torch.zeros(total, device=dev)
+        shadow = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+        steps = torch.zeros(nparam, device=dev)
+        steps[1] = 3.0                                         # one weight matrix is further along (its own bias correction)
+        comm = None
+        for it in range(2):
+            grad = grads_other.clone() * (it + 1)
+            steps += 1.0
+            if fused:
+                arena = capi.AdamWArena(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), steps.data_ptr(), total,
+                                        hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"], hyper["wd"])
+                sidx = (ctypes.c_int * len(shapes))(*widx)
+                capi.call("unetr_gemm_bf16_grouped_wgrad_adamw", problems(grad), len(shapes), ctypes.byref(arena), sidx, st)
+                rows, blocks = [], 0
+                for i in range(nparam):
+                    if not is_w[i]:
+                        rows.append((offs[i], offs[i] + sizes[i], i, blocks))
+                        blocks += (sizes[i] + 4095) // 4096
+                table = torch.tensor(rows, dtype=torch.int64, device=dev)
+                capi.call("unetr_adamw_ranges", ctypes.byref(arena), table.data_ptr(), len(rows), blocks, st)
+            else:
+                capi.call("unetr_gemm_bf16_grouped_wgrad", problems(grad), len(shapes), st)
+                for i in range(nparam):
+                    o, n = offs[i], sizes[i]
+                    capi.call("unetr_adamw", p.data_ptr() + 4 * o, grad.data_ptr() + 4 * o, m.data_ptr() + 4 * o, v.data_ptr() + 4 * o, n,
+                              hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"], hyper["wd"], steps.data_ptr() + 4 * i,
+                              shadow.data_ptr() + 2 * o, st)
+            # (b) the communication-buffer form of the same gradients
+            comm = torch.full((total,), float("nan"), device=dev, dtype=torch.bfloat16)
+            grad2 = grads_other.clone() * (it + 1)
+            if fused:
+                capi.call("unetr_gemm_bf16_grouped_wgrad_bf16out", problems(grad2), len(shapes), grad2.data_ptr(), comm.data_ptr(), total, st)
+                rows, blocks = [], 0
+                for i in range(nparam):
+                    if not is_w[i]:
+                        rows.append((offs[i], offs[i] + sizes[i], blocks))
+                        blocks += (sizes[i] + 8191) // 8192
+                table = torch.tensor(rows, dtype=torch.int64, device=dev)
+                capi.call("unetr_cast_bf16_ranges", grad2.data_ptr(), comm.data_ptr(), table.data_ptr(), len(rows), blocks, st)
+            else:
+                capi.call("unetr_gemm_bf16_grouped_wgrad", problems(grad2), len(shapes), st)
+                capi.call("unetr_cast_bf16", grad2.data_ptr(), comm.data_ptr(), total, st)
+        torch.cuda.synchronize()
+        return p, m, v, shadow, comm
+
+    ref, fus = run(False), run(True)
+    for name, a, b in zip(("param", "exp_avg", "exp_avg_sq", "shadow", "comm buffer"), ref, fus):
+        assert not torch.isnan(a.float()).any(), name
+        assert torch.equal(a, b), name
+    assert (ref[0] != p0).float().mean() > 0.99               # every parameter moved
+
+
 def test_gemm_bf16_epilogues(pkg, dev):
     Fn = pkg.functional
     M, N, K, L = 432, 512, 256, 216

@@ -146,7 +146,7 @@ def _pmc_traffic(kernel_rx):
 
 def step_report(pkg, step, batch, precision, ms_per_step):
     times = _kernel_times(step.run)
-    arch = _arch(batch, fused_update=any(re.search(r"grouped_wgrad_kernel<.*true>", k) for k in times))
+    arch = _arch(batch, fused_update=any(re.search(r"grouped_wgrad_kernel<\d+, *\d+, *(1|true)>", k) for k in times))
     fam = collections.OrderedDict()
     for name, (us, n) in times.items():
         f = _family_of(name)
