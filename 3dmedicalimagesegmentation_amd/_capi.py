@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
-ABI_VERSION = 7        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 8        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -65,7 +65,7 @@ class PackProblem(ctypes.Structure):
 
 
 class ColsumProblem(ctypes.Structure):
-    _fields_ = [("x", c_void_p), ("out", c_void_p), ("ld", c_long), ("M", c_int), ("N", c_int)]
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("ld", c_long), ("M", c_int), ("N", c_int), ("x_bf16", c_int)]
 
 
 P = c_void_p

@@ -183,7 +183,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int RB, int 
 
 // grouped column sums: up to CS_MAX independent [M_i, N_i] -> [N_i] problems in one launch (descriptors in kernargs)
 constexpr int CS_MAX = 96;       // (x 40 bytes: the kernel-argument block holds 4 KB)
-struct ColsumProblem { const float* x; float* out; long ld; int M, N, blk0, vec; };
+struct ColsumProblem { const float* x; float* out; long ld; int M, N, blk0, vec; };   // vec 2: x is bf16, 16-byte loads of 8 columns
 struct ColsumArgs { int n; ColsumProblem p[CS_MAX]; };
 __global__ void __launch_bounds__(256)
 colsum_grouped_kernel(ColsumArgs a) {
@@ -192,6 +192,30 @@ colsum_grouped_kernel(ColsumArgs a) {
     for (int i = 1; i < a.n; ++i) pi = ((int)blockIdx.x >= a.p[i].blk0) ? i : pi;
     const ColsumProblem& pr = a.p[pi];
     const int n0 = ((int)blockIdx.x - pr.blk0) * 64;
+    if (pr.vec == 2) {
+        // bf16 rows: thread = (8 columns cg of the block's 64, row phase ph of 32); same fixed order as below
+        const int cg = threadIdx.x & 7, ph = threadIdx.x >> 3, n = n0 + 8 * cg;
+        const uint16_t* xb = (const uint16_t*)pr.x;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n < pr.N) {
+            for (int m = ph; m < pr.M; m += 32) {
+                const bf16x8 t = __builtin_bit_cast(bf16x8, *(const u32x4*)(xb + (long)m * pr.ld + n));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)t[e];
+            }
+        }
+        __shared__ float smb[32][64];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) smb[ph][8 * cg + e] = s[e];
+        __syncthreads();
+        if (threadIdx.x < 64 && n0 + (int)threadIdx.x < pr.N) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = (smb[4 * q][threadIdx.x] + smb[4 * q + 1][threadIdx.x]) + (smb[4 * q + 2][threadIdx.x] + smb[4 * q + 3][threadIdx.x]);
+            pr.out[n0 + threadIdx.x] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        return;
+    }
     if (pr.vec) {
         // 16-byte loads: thread = (4 columns cg, row phase ph of 16); a block still owns 64 columns.  (With one 4-byte load per
         // lane the launch was issue-bound: 95 MB of fp32 gradients at 2 TB/s.)  Fixed order: rows ph, ph+16, ... in groups of
@@ -1049,8 +1073,12 @@ extern "C" int unetr_colsum_grouped(const unetr_colsum_problem* probs, int n, vo
         for (int i = 0; i < a.n; ++i) {
             const unetr_colsum_problem& q = probs[base + i];
             if (!q.x || !q.out || q.M <= 0 || q.N <= 0) return UNETR_ERR_ARG;
-            const int vec = q.N % 4 == 0 && q.ld % 4 == 0 && (((uintptr_t)q.x | (uintptr_t)q.out) & 15) == 0;
-            a.p[i] = ColsumProblem{q.x, q.out, q.ld, q.M, q.N, blocks, vec};
+            int vec = q.N % 4 == 0 && q.ld % 4 == 0 && (((uintptr_t)q.x | (uintptr_t)q.out) & 15) == 0;
+            if (q.x_bf16) {
+                if (q.N % 8 || q.ld % 8 || ((uintptr_t)q.x & 15)) return UNETR_ERR_UNSUPPORTED;
+                vec = 2;
+            }
+            a.p[i] = ColsumProblem{(const float*)q.x, q.out, q.ld, q.M, q.N, blocks, vec};
             blocks += cdiv(q.N, 64);
         }
         hipLaunchKernelGGL(colsum_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -33,7 +33,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 7
+#define UNETR_ABI_VERSION 8
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -104,7 +104,9 @@ int unetr_gemm_grouped_wgrad(const unetr_grouped_problem* probs, int n, int prec
 /* the same grouped weight gradients on bf16-STORED dy / x (the pointers in unetr_grouped_problem then address bf16 data,
  * dense row-major [M,N] / [M,K]; M, N, K multiples of 8): LDS-DMA staging, transposing LDS reads for both operands */
 int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs, int n, void* stream);
-typedef struct { const float* x; float* out; long ld; int M, N; } unetr_colsum_problem;
+/* x_bf16 != 0: x addresses bf16 data (the bf16 twin of a data gradient: fc1's bias gradient is summed from the same bf16 values its
+ * weight gradient is formed from, and the fp32 copy of that gradient is never written) */
+typedef struct { const void* x; float* out; long ld; int M, N, x_bf16; } unetr_colsum_problem;
 int unetr_colsum_grouped(const unetr_colsum_problem* probs, int n, void* stream);
 
 /* ---- 2x2x2 stride-2 transposed conv (nn.ConvTranspose3d, bias=False; unetr.py:99-174) ---------------
