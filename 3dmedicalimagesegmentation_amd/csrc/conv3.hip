@@ -1716,7 +1716,7 @@ inline int conv_pipe_enabled() {   // tuning hook: UNETR_CONV_PIPE=0 selects the
 // kind 0 / 1: 3x3x3 forward / data-gradient layout (pair layout when the contraction has <= 16 channels in bf16),
 // kind 2: 1x1x1 forward (fused front), kind 3: 1x1x1 transposed (fused input gradient).
 constexpr int PK_MAX = 64;
-struct PkProblem { const float* w; void* out; int Cin, Cout, kind, pair, blk0; long total; };
+struct PkProblem { const float* w; void* out; int Cin, Cout, kind, pair, blk0; long total; int staged; };
 struct PkArgs { int n; PkProblem p[PK_MAX]; };
 
 template <class T>
@@ -1727,6 +1727,37 @@ __global__ void __launch_bounds__(256) conv3_pack_grouped_kernel(PkArgs a, int S
     const float* __restrict__ w = pr.w;
     T* __restrict__ wp = (T*)pr.out;
     const int Cin = pr.Cin, Cout = pr.Cout;
+    if (pr.staged) {
+        // slab-mode 3x3x3 packs (the many-channel layers: 16 MB of fp32 weights per step): element by element the gather reads w
+        // with a 108-byte stride (one useful value per cache line touched).  Here a block owns (slab of SL reduction channels,
+        // 8 output rows n): it reads its 8 x SL x 27 source values as contiguous runs into LDS and writes, per tap, the 8 x SL
+        // packed values as ONE contiguous run.
+        __shared__ float tile[32 * 217];
+        const int mode = pr.kind, K = mode ? Cout : Cin, N = mode ? Cin : Cout, nslab = (K + SL - 1) / SL;
+        const int lb = (int)blockIdx.x - pr.blk0, slab = lb % nslab, n0 = (lb / nslab) * 8, k0 = slab * SL;
+        const int kn = min(SL, K - k0), nn = min(8, N - n0);
+        if (mode == 0) {           // w[n][k][tap]: per n a run of kn * 27 values; tile[n_i * 868 + kk * 27 + tap]
+            for (int idx = threadIdx.x; idx < nn * kn * 27; idx += 256) {
+                const int ni = idx / (kn * 27), rem = idx - ni * (kn * 27);
+                tile[ni * 868 + rem] = w[((long)(n0 + ni) * Cin + k0) * 27 + rem];
+            }
+        } else {                   // w[k][n][tap]: per k a run of nn * 27 values; tile[kk * 217 + n_i * 27 + tap]
+            for (int idx = threadIdx.x; idx < kn * nn * 27; idx += 256) {
+                const int kk = idx / (nn * 27), rem = idx - kk * (nn * 27);
+                tile[kk * 217 + rem] = w[((long)(k0 + kk) * Cin + n0) * 27 + rem];
+            }
+        }
+        __syncthreads();
+        const int kk = threadIdx.x % SL, ni = threadIdx.x / SL;      // (SL 32: 8 rows per pass; SL 16: 16 threads per row, 8 rows of the 16)
+        if (ni < nn) {
+            for (int tap = 0; tap < 27; ++tap) {
+                float v = 0.f;
+                if (kk < kn) v = mode ? tile[kk * 217 + ni * 27 + (26 - tap)] : tile[ni * 868 + kk * 27 + tap];
+                wp[(((long)tap * nslab + slab) * N + n0 + ni) * SL + kk] = cvt_elem<T>(v);
+            }
+        }
+        return;
+    }
     const long base = ((long)blockIdx.x - pr.blk0) * 2048;
     for (int u = 0; u < 8; ++u) {
         const long i = base + threadIdx.x + u * 256;
@@ -2058,7 +2089,7 @@ extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, 
             if (q.kind == 4) {       // transposed-conv tap-major pack: always bf16 (the operand of unetr_gemm_bf16)
                 if (prec != UNETR_PREC_BF16) return UNETR_ERR_UNSUPPORTED;
                 const long total4 = 8L * q.Cin * q.Cout;
-                a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, 4, 0, blocks, total4};
+                a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, 4, 0, blocks, total4, 0};
                 blocks += cdiv(total4, 2048);
                 continue;
             }
@@ -2067,8 +2098,9 @@ extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, 
             long total;
             if (q.kind <= 1) total = pair ? 14L * N * 32 : 27L * ((K + SL - 1) / SL) * N * SL;
             else total = pair ? (long)N * 32 : (long)((K + SL - 1) / SL) * N * SL;
-            a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, q.kind, pair, blocks, total};
-            blocks += cdiv(total, 2048);
+            const int staged = (q.kind <= 1 && !pair) ? 1 : 0;
+            a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, q.kind, pair, blocks, total, staged};
+            blocks += staged ? ((K + SL - 1) / SL) * cdiv(N, 8) : cdiv(total, 2048);
         }
         if (prec == UNETR_PREC_BF16) hipLaunchKernelGGL((conv3_pack_grouped_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, a, SL);
         else hipLaunchKernelGGL((conv3_pack_grouped_kernel<float>), dim3(blocks), dim3(256), 0, st, a, SL);
