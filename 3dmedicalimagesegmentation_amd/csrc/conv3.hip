@@ -1721,8 +1721,11 @@ struct PkArgs { int n; PkProblem p[PK_MAX]; };
 
 template <class T>
 __global__ void __launch_bounds__(256) conv3_pack_grouped_kernel(PkArgs a, int SL) {
-    int pi = 0;
-    for (int i = 1; i < a.n; ++i) pi = ((int)blockIdx.x >= a.p[i].blk0) ? i : pi;
+    int pi = 0, hi_ = a.n - 1;                 // last problem whose first block <= blockIdx.x (binary search: a linear scan of the
+    while (pi < hi_) {                         // kernel-argument table cost every block a chain of ~64 dependent scalar loads)
+        const int mid = (pi + hi_ + 1) >> 1;
+        if ((int)blockIdx.x >= a.p[mid].blk0) pi = mid; else hi_ = mid - 1;
+    }
     const PkProblem& pr = a.p[pi];
     const float* __restrict__ w = pr.w;
     T* __restrict__ wp = (T*)pr.out;

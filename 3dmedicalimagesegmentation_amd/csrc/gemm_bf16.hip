@@ -556,7 +556,10 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
     __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
     int pi = 0;
     const int t = blockIdx.x;
-    for (int i = 1; i < ga.n; ++i) pi = (t >= ga.p[i].tile0) ? i : pi;
+    for (int hi_ = ga.n - 1; pi < hi_;) {      // last problem whose first tile <= t (binary search over the kernel-argument table)
+        const int mid = (pi + hi_ + 1) >> 1;
+        if (t >= ga.p[mid].tile0) pi = mid; else hi_ = mid - 1;
+    }
     const GwProblem& pr = ga.p[pi];
     const int lt = t - pr.tile0, tn = lt % pr.ntn, tk = lt / pr.ntn;
     const int n0 = tn * BT, k0 = tk * BT, M = pr.M;

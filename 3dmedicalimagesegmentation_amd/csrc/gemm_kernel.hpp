@@ -395,7 +395,10 @@ gemm_grouped_wgrad_kernel(GroupedArgs ga) {
     __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * 128];
     int pi = 0;
     const int t = blockIdx.x;
-    for (int i = 1; i < ga.n; ++i) pi = (t >= ga.p[i].tile0) ? i : pi;     // uniform scan, <= 48 entries
+    for (int hi_ = ga.n - 1; pi < hi_;) {      // last problem whose first tile <= t (binary search over the kernel-argument table)
+        const int mid = (pi + hi_ + 1) >> 1;
+        if (t >= ga.p[mid].tile0) pi = mid; else hi_ = mid - 1;
+    }
     const GroupedProblem& pr = ga.p[pi];
     const int lt = t - pr.tile0, tm = lt % pr.mtiles, tn = lt / pr.mtiles;
     // output rows = dy columns (N), output cols = x columns (K), reduction over the M tokens

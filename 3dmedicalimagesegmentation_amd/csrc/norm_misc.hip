@@ -188,8 +188,11 @@ struct ColsumArgs { int n; ColsumProblem p[CS_MAX]; };
 __global__ void __launch_bounds__(256)
 colsum_grouped_kernel(ColsumArgs a) {
     __shared__ f32x4 sm4[16][16];
-    int pi = 0;
-    for (int i = 1; i < a.n; ++i) pi = ((int)blockIdx.x >= a.p[i].blk0) ? i : pi;
+    int pi = 0, hi = a.n - 1;                  // last problem whose first block <= blockIdx.x (binary search: ~85 problems, 4000 blocks)
+    while (pi < hi) {
+        const int mid = (pi + hi + 1) >> 1;
+        if ((int)blockIdx.x >= a.p[mid].blk0) pi = mid; else hi = mid - 1;
+    }
     const ColsumProblem& pr = a.p[pi];
     const int n0 = ((int)blockIdx.x - pr.blk0) * 64;
     if (pr.vec == 2) {
@@ -198,7 +201,20 @@ colsum_grouped_kernel(ColsumArgs a) {
         const uint16_t* xb = (const uint16_t*)pr.x;
         float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (n < pr.N) {
-            for (int m = ph; m < pr.M; m += 32) {
+            // eight rows in flight per thread (one load per iteration cost a memory round trip per row: 14 of them for 432 rows)
+            int m = ph;
+            for (; m + 7 * 32 < pr.M; m += 8 * 32) {
+                u32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *(const u32x4*)(xb + (long)(m + 32 * u) * pr.ld + n);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bf16x8 tv = __builtin_bit_cast(bf16x8, t[u]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[e] += (float)tv[e];
+                }
+            }
+            for (; m < pr.M; m += 32) {
                 const bf16x8 t = __builtin_bit_cast(bf16x8, *(const u32x4*)(xb + (long)m * pr.ld + n));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s[e] += (float)t[e];
@@ -225,6 +241,12 @@ colsum_grouped_kernel(ColsumArgs a) {
         if (n < pr.N) {
             const float* px = pr.x + n;
             int m = ph;
+            for (; m + 7 * 16 < pr.M; m += 8 * 16) {          // eight rows in flight per thread
+                f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(px + (long)(m + 16 * u) * pr.ld);
+                s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
             for (; m + 48 < pr.M; m += 64) {
                 const f32x4 t0 = *(const f32x4*)(px + (long)m * pr.ld), t1 = *(const f32x4*)(px + (long)(m + 16) * pr.ld);
                 const f32x4 t2 = *(const f32x4*)(px + (long)(m + 32) * pr.ld), t3 = *(const f32x4*)(px + (long)(m + 48) * pr.ld);
