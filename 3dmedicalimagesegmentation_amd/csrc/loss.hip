@@ -32,6 +32,34 @@ dicece_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ la
     float accI[C], accP[C], accG[C], ce = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) { accI[c] = 0.f; accP[c] = 0.f; accG[c] = 0.f; }
+    // softmax / one-hot form on whole 4-voxel groups: one 16-byte load per channel and for the labels, all of an iteration's loads
+    // in flight together (one voxel per iteration was 16 dependent memory round trips per thread: 19 us for 35 MB)
+    const bool vec = !SIG && (V & 3) == 0 && ((((uintptr_t)logits) | ((uintptr_t)label)) & 15) == 0;
+    if (vec) {
+        for (long v = v0 + 4 * threadIdx.x; v < v1; v += 1024) {      // (LVPB and V are multiples of 4: whole groups)
+            f32x4 zv[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) zv[c] = *(const f32x4*)(logits + ((long)b * C + c) * V + v);
+            const f32x4 lv = *(const f32x4*)(label + (long)b * V + v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float z[C], mx = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { z[c] = zv[c][e]; mx = fmaxf(mx, z[c]); }
+                float se = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { z[c] = expf(z[c] - mx); se += z[c]; }
+                const float inv = 1.f / se;
+                const int lab = (int)lv[e];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float p = z[c] * inv;
+                    accP[c] += p;
+                    if (c == lab) { accI[c] += p; accG[c] += 1.f; ce -= logf(p); }
+                }
+            }
+        }
+    } else
     for (long v = v0 + threadIdx.x; v < v1; v += 256) {
         float z[C], mx = -3.0e38f;
 #pragma unroll
