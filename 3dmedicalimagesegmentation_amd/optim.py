@@ -132,7 +132,6 @@ class AdamW(torch.optim.Optimizer):
     # The gradients of the fused weights are never written: p.grad of those parameters names a stale arena slice.
     @torch.no_grad()
     def begin_fused_step(self, pattern):
-        import ctypes
         from . import _capi
         flat = self._flat
         if flat is None or len(self.param_groups) != 1 or flat.get("state") is None:
