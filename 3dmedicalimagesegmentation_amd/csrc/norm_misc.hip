@@ -1136,7 +1136,18 @@ in_stats_final_block_kernel(const float* __restrict__ part, int nchunk, long V, 
     __shared__ double sm[2][4];
     const int i = blockIdx.x, b = i / C, c = i - b * C, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
-    for (int k = threadIdx.x; k < nchunk; k += 256) {
+    int k = threadIdx.x;
+    for (; k + 3 * 256 < nchunk; k += 4 * 256) {          // four rows in flight per thread (up to 4096 partial rows per batch item)
+        float ps[4], pq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* p = part + ((long)b * nchunk + k + 256 * u) * 2 * C;
+            ps[u] = p[c]; pq[u] = p[C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)ps[u]; q += (double)pq[u]; }
+    }
+    for (; k < nchunk; k += 256) {
         const float* p = part + ((long)b * nchunk + k) * 2 * C;
         s += (double)p[c];
         q += (double)p[C + c];
