@@ -83,6 +83,38 @@ struct EpBf {
         }
         if (Cb) *(bf16x4*)(Cb + (tc_cout ? tc_off(m, n) : (long)m * ldcb + n)) = __builtin_convertvector(v, bf16x4);
     }
+    // store4 in two halves: the epilogue's READS (bias, GELU' argument, residual, accumulate target) of a row segment, and the
+    // arithmetic + stores.  The kernel requests the reads of ALL its tiles before the first store: the pointers of this struct may
+    // alias as far as the compiler knows, so inside store4 the loads of tile t+1 could not move above the stores of tile t and
+    // every tile of the epilogue paid its own memory round trip (the GELU' argument comes out of HBM: 5.3 MB per block)
+    struct Ops { f32x4 b, a, r, c; };
+    __device__ __forceinline__ Ops load4(int m, int n) const {
+        Ops o;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        o.b = bias ? *(const f32x4*)(bias + n) : z;
+        o.a = act == 2 ? *(const f32x4*)(aux + (long)m * ldaux + n) : z;
+        o.r = res ? *(const f32x4*)(res + (long)(m % res_mod) * ldr + n) : z;
+        o.c = (C && accumulate) ? *(const f32x4*)(C + (long)m * ldc + n) : z;
+        return o;
+    }
+    __device__ __forceinline__ void finish4(int m, int n, f32x4 v, const Ops& o) const {
+        v *= alpha;
+        if (bias) v += o.b;
+        if (pre) *(f32x4*)(pre + (long)m * ldc + n) = v;
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+        } else if (act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(o.a[e]);
+        }
+        if (res) v += o.r;
+        if (C) {
+            if (accumulate) v += o.c;
+            *(f32x4*)(C + (long)m * ldc + n) = v;
+        }
+        if (Cb) *(bf16x4*)(Cb + (tc_cout ? tc_off(m, n) : (long)m * ldcb + n)) = __builtin_convertvector(v, bf16x4);
+    }
 };
 
 // b_kn image swizzle: XOR applied to the 16-byte chunk index of reduction row r (chunk PAIRS move, a transposing read
@@ -222,6 +254,27 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
     // The MFMAs above ran with swapped operands, so the accumulator tile is C^T: lane (c, g) holds C[m = tile row c]
     // [n = 4g .. 4g+3] -- one 16-byte store (or 8-byte bf16 store) per tile instead of four 4-byte ones.
     const bool vec4 = ep.vec_ok;
+    if (vec4 && splits == 1) {
+        // (operand reads of every tile first -- clamped addresses for the tiles past the edge --, then arithmetic and stores)
+        EpBf::Ops ops[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int m = min(m0 + (wm * WM + i) * 16 + (lane & 15), M - 1);
+                const int n = min(n0 + (wn * WN + j) * 16 + 4 * (lane >> 4), N - 4);
+                ops[i][j] = ep.load4(m, n);
+            }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int m = m0 + (wm * WM + i) * 16 + (lane & 15);
+                const int n = n0 + (wn * WN + j) * 16 + 4 * (lane >> 4);
+                if (m < M && n < N) ep.finish4(m, n, acc[i][j], ops[i][j]);
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll

@@ -23,27 +23,52 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
     if (row >= M) return;
     const int nv = H >> 2;
     const f32x4* xr = (const f32x4*)(x + (long)row * H);
-    f32x4 v[LN_MAXV];
+    f32x4 v[LN_MAXV], gam[LN_MAXV], bet[LN_MAXV];
     float s = 0.f;
+    // every load of the row -- gamma / beta included -- is requested before the first use (as run-time loops over the slabs the
+    // split-K form made one memory round trip per slab and vector, one after the other)
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
-        int i = lane + 64 * j;
-        if (src.splits > 1) {
-            // the row arrives as split-K partial slabs of the GEMM that produces it: summed from 0.f in slab order, + bias,
-            // + residual -- the arithmetic of splitk_reduce_kernel + EpBf::store, whose launch this saves -- and written out
+        const int i = min(lane + 64 * j, nv - 1);
+        gam[j] = ((const f32x4*)gamma)[i];
+        bet[j] = ((const f32x4*)beta)[i];
+    }
+    if (src.splits > 1) {
+        // the row arrives as split-K partial slabs of the GEMM that produces it: summed from 0.f in slab order, + bias,
+        // + residual -- the arithmetic of splitk_reduce_kernel + EpBf::store, whose launch this saves -- and written out
+        f32x4 sl[LN_MAXV][4], bi[LN_MAXV], re[LN_MAXV];
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int i = min(lane + 64 * j, nv - 1);
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) sl[j][sp] = ((const f32x4*)(x + (sp < src.splits ? sp : 0) * src.slab + (long)row * H))[i];
+            bi[j] = src.bias ? ((const f32x4*)src.bias)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            re[j] = src.res ? ((const f32x4*)(src.res + (long)(row % src.res_mod) * src.ldr))[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int i = lane + 64 * j;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
             if (i < nv) {
-                for (int sp = 0; sp < src.splits; ++sp) t += ((const f32x4*)(x + sp * src.slab + (long)row * H))[i];
-                if (src.bias) t += ((const f32x4*)src.bias)[i];
-                if (src.res) t += ((const f32x4*)(src.res + (long)(row % src.res_mod) * src.ldr))[i];
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+                    if (sp < src.splits) t += sl[j][sp];
+                for (int sp = 4; sp < src.splits; ++sp) t += ((const f32x4*)(x + sp * src.slab + (long)row * H))[i];
+                if (src.bias) t += bi[j];
+                if (src.res) t += re[j];
                 ((f32x4*)(src.xout + (long)row * H))[i] = t;
             }
             v[j] = t;
-        } else {
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int i = lane + 64 * j;
             v[j] = i < nv ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
     }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
     const float mu = wave_sum(s) / (float)H;
     float q = 0.f;
 #pragma unroll
@@ -61,7 +86,8 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamm
     for (int j = 0; j < LN_MAXV; ++j) {
         int i = lane + 64 * j;
         if (i < nv) {
-            f32x4 g = ((const f32x4*)gamma)[i], b = ((const f32x4*)beta)[i], o;
+            const f32x4 g = gam[j], b = bet[j];
+            f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
             if (y) yr[i] = o;

@@ -671,12 +671,13 @@ def gemm_bf16_ln_fwd(A, B, M, N, K, C, gamma, beta, y_bf16, bias=None, res=None,
 
 
 def ln_ride_enabled():
-    """UNETR_AMD_LN_RIDE=1: norm1 of block i+1 is formed by the kernel that sums block i's last split-K GEMM
-    (unetr_gemm_bf16_ln_fwd) instead of its own launch.  Bit-identical and one launch less per block, but measured NEUTRAL
-    on MI355X at batch 2 (same box: 5.19-5.23 vs 5.19-5.20 ms/step): the row-owning reduce (108 workgroups, one wave per
-    row) is as much slower than the wide reduce (1296 workgroups) as the LayerNorm launch it saves.  Off by default; the
-    backward counterpart (unetr_gemm_bf16_ln_bwd), where the row-owning kernel existed anyway, is always on (-0.06 ms)."""
-    return os.environ.get("UNETR_AMD_LN_RIDE", "0") == "1"
+    """norm1 of block i+1 is formed by the kernel that sums block i's last split-K GEMM (unetr_gemm_bf16_ln_fwd) instead of
+    its own launch: bit-identical and one launch less per block.  On by default since round 3 (4.527 vs 4.544 ms/step in three
+    interleaved rounds on one box) -- it had measured neutral while the LayerNorm kernel walked the slabs in a run-time loop, one
+    memory round trip per slab and vector; with every load of the row requested up front the row-owning form wins.
+    UNETR_AMD_LN_RIDE=0 restores the separate split-K reduce + LayerNorm launches.  The backward counterpart
+    (unetr_gemm_bf16_ln_bwd) is always on."""
+    return os.environ.get("UNETR_AMD_LN_RIDE", "1") == "1"
 
 
 def _stash_ln(x, gamma, beta, xn, mean, rstd):
@@ -1106,7 +1107,7 @@ def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, h
         if not train:
             u = m1 = r1 = m2 = r2 = y1b = y2b = x.new_empty(0)
         x2 = torch.empty(M, hid, **f32)
-        if next_ln is not None and not fused:
+        if next_ln is not None and not fused and not emit_twin:      # (a tapped block writes the bf16 twin of x2 from its own epilogue)
             xn = bf16_like(x)
             mn, rn = gemm_bf16_ln_fwd(ab, weight_bf16(w2), M, hid, mlp, x2, next_ln[0], next_ln[1], xn, bias=b2, res=x1, ldr=hid)
             _stash_ln(x2, next_ln[0], next_ln[1], xn, mn, rn)
