@@ -255,24 +255,29 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
     // [n = 4g .. 4g+3] -- one 16-byte store (or 8-byte bf16 store) per tile instead of four 4-byte ones.
     const bool vec4 = ep.vec_ok;
     if (vec4 && splits == 1) {
-        // (operand reads of every tile first -- clamped addresses for the tiles past the edge --, then arithmetic and stores)
-        EpBf::Ops ops[WM][WN];
+        // (operand reads first -- clamped addresses for the tiles past the edge --, then arithmetic and stores: all tiles at once
+        // where a wave owns <= 4 of them, row of tiles by row of tiles in the larger variants, whose register budget is spoken for)
+        constexpr int RB = WM * WN <= 4 ? WM : 1;          // tile rows per batch
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+        for (int i0 = 0; i0 < WM; i0 += RB) {
+            EpBf::Ops ops[RB][WN];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int m = min(m0 + (wm * WM + i) * 16 + (lane & 15), M - 1);
-                const int n = min(n0 + (wn * WN + j) * 16 + 4 * (lane >> 4), N - 4);
-                ops[i][j] = ep.load4(m, n);
-            }
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+                for (int j = 0; j < WN; ++j) {
+                    const int m = min(m0 + (wm * WM + i0 + i) * 16 + (lane & 15), M - 1);
+                    const int n = min(n0 + (wn * WN + j) * 16 + 4 * (lane >> 4), N - 4);
+                    ops[i][j] = ep.load4(m, n);
+                }
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int m = m0 + (wm * WM + i) * 16 + (lane & 15);
-                const int n = n0 + (wn * WN + j) * 16 + 4 * (lane >> 4);
-                if (m < M && n < N) ep.finish4(m, n, acc[i][j], ops[i][j]);
-            }
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int m = m0 + (wm * WM + i0 + i) * 16 + (lane & 15);
+                    const int n = n0 + (wn * WN + j) * 16 + 4 * (lane >> 4);
+                    if (m < M && n < N) ep.finish4(m, n, acc[i0 + i][j], ops[i][j]);
+                }
+        }
         return;
     }
 #pragma unroll
