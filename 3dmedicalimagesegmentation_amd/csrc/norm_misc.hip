@@ -576,7 +576,18 @@ __global__ void in_bwd_final_kernel(const float* __restrict__ part, int nchunk, 
     if (i >= B * C) return;
     const int b = i / C, c = i - b * C;
     double s[3] = {0.0, 0.0, 0.0};
-    for (int k = lane; k < nchunk; k += 64) {
+    int k = lane;
+    for (; k + 3 * 64 < nchunk; k += 4 * 64) {             // four chunk rows in flight per lane (same summation order)
+        float t[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* p = part + ((long)b * nchunk + k + 64 * u) * 3 * C;
+            t[u][0] = p[c]; t[u][1] = p[C + c]; t[u][2] = p[2 * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[0] += (double)t[u][0]; s[1] += (double)t[u][1]; s[2] += (double)t[u][2]; }
+    }
+    for (; k < nchunk; k += 64) {
         const float* p = part + ((long)b * nchunk + k) * 3 * C;
         s[0] += (double)p[c]; s[1] += (double)p[C + c]; s[2] += (double)p[2 * C + c];
     }
@@ -885,6 +896,8 @@ outconv_bwd_small_kernel(const float* __restrict__ dl, const float* __restrict__
 #pragma unroll
         for (int e = 0; e < W; ++e) wsum[co][e] = 0.f;
     const long total = (long)B * V * cvn;
+    // (one voxel piece per iteration: batching two or four pieces' loads was tried -- 122 / 144 VGPRs instead of ~100, and the
+    // resident waves it costs are worth more to this streaming loop than the loads it puts in flight)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long vox = i / cvn;
         const int b = (int)(vox / V); const long v = vox - (long)b * V;
