@@ -728,10 +728,29 @@ transpose_kernel(const TS* __restrict__ src, long ld_s, long bs_s, TD* __restric
 }
 
 // out (fp32) and / or out16 (bf16: the GEMM operand of the bf16-storage path -- no fp32 patches + cast pass in between)
+// VEC: one channel, P and W multiples of 4, 16-byte aligned tensors, < 2^31 elements: four consecutive values of a patch row per
+// thread (one 16-byte load, 16 / 8-byte stores) with 32-bit index arithmetic -- element by element the kernel spent its time in
+// ~10 64-bit divisions per value
+template <bool VEC>
 __global__ void patch_gather_kernel(const float* __restrict__ x, float* __restrict__ out, uint16_t* __restrict__ out16, int B, int C, int D, int H, int W, int P) {
     const int gd = D / P, gh = H / P, gw = W / P;
     const long pd = (long)P * P * P * C;
     const long total = (long)B * gd * gh * gw * pd;
+    if constexpr (VEC) {
+        const unsigned total4 = (unsigned)(total >> 2), upd = (unsigned)pd, P4 = (unsigned)P >> 2;
+        for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
+            const unsigned i = i4 << 2, f = i % upd, tok = i / upd;
+            unsigned t = f >> 2;                                   // (C == 1: f = (p1 * P + p2) * P + p3, p3 a multiple of 4)
+            const unsigned p3 = (t % P4) << 2; t /= P4; const unsigned p2 = t % (unsigned)P, p1 = t / (unsigned)P;
+            unsigned u = tok;
+            const unsigned w3 = u % (unsigned)gw; u /= (unsigned)gw; const unsigned w2 = u % (unsigned)gh; u /= (unsigned)gh;
+            const unsigned w1 = u % (unsigned)gd, b = u / (unsigned)gd;
+            const f32x4 v = *(const f32x4*)(x + (((long)b * D + w1 * P + p1) * H + w2 * P + p2) * W + w3 * P + p3);
+            if (out) *(f32x4*)(out + i) = v;
+            if (out16) *(bf16x4*)(out16 + i) = __builtin_convertvector(v, bf16x4);
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long f = i % pd; long tok = i / pd;
         int c = (int)(f % C); long t = f / C; int p3 = (int)(t % P); t /= P; int p2 = (int)(t % P); int p1 = (int)(t / P);
@@ -1325,7 +1344,10 @@ extern "C" int unetr_nhwc_to_nchw(const void* x, long ldx, float* y, int B, int 
 extern "C" int unetr_patch_gather(const float* x, float* patches, void* patches_bf16, int B, int C, int D, int H, int W, int P, void* stream) {
     if (!x || (!patches && !patches_bf16) || P <= 0 || D % P || H % P || W % P) return UNETR_ERR_ARG;
     long total = (long)B * C * D * H * W;
-    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, (uint16_t*)patches_bf16, B, C, D, H, W, P);
+    const bool vec = C == 1 && P % 4 == 0 && W % 4 == 0 && total < (1L << 31) && (((uintptr_t)x | (uintptr_t)patches) & 15) == 0 &&
+                     ((uintptr_t)patches_bf16 & 7) == 0;
+    if (vec) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, x, patches, (uint16_t*)patches_bf16, B, C, D, H, W, P);
+    else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, (uint16_t*)patches_bf16, B, C, D, H, W, P);
     return unetr_check_launch();
 }
 
