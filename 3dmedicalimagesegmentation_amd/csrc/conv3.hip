@@ -1761,32 +1761,35 @@ __global__ void __launch_bounds__(256) conv3_pack_grouped_kernel(PkArgs a, int S
         }
         return;
     }
-    const long base = ((long)blockIdx.x - pr.blk0) * 2048;
+    // (32-bit index arithmetic: the host refuses packs of >= 2^31 elements; as 64-bit values every element paid several ~50-
+    // instruction divisions)
+    const unsigned base = ((unsigned)blockIdx.x - (unsigned)pr.blk0) * 2048u;
     for (int u = 0; u < 8; ++u) {
-        const long i = base + threadIdx.x + u * 256;
-        if (i >= pr.total) break;
+        const unsigned i = base + threadIdx.x + u * 256;
+        if (i >= (unsigned)pr.total) break;
         float v = 0.f;
         if (pr.kind == 4) {
             // 2x2x2 transposed conv, tap-major GEMM operand: out[ci][tap][co] = w[ci][co][tap] (torch ConvTranspose3d layout
             // [in, out, 2, 2, 2]); the problem's Cout field carries the layer's INPUT channels (dim 0 of w), Cin its output channels
-            const int tco = Cin, co = (int)(i % tco); const long t = i / tco; const int tap = (int)(t & 7); const long ci = t >> 3;
-            v = w[(ci * tco + co) * 8 + tap];
+            const unsigned tco = Cin, co = i % tco, t = i / tco, tap = t & 7, ci = t >> 3;
+            v = w[((long)ci * tco + co) * 8 + tap];
         } else if (pr.kind <= 1) {
             const int mode = pr.kind, K = mode ? Cout : Cin, N = mode ? Cin : Cout;
             if (pr.pair) {
-                const int kk = (int)(i & 31); const long t = i >> 5; const int n = (int)(t % N), tp = (int)(t / N);
+                const int kk = (int)(i & 31); const unsigned t = i >> 5; const int n = (int)(t % (unsigned)N), tp = (int)(t / (unsigned)N);
                 const int tap = 2 * tp + (kk >> 4), k = kk & 15;
                 if (tap < 27 && k < K) v = mode ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
             } else {
                 const int nslab = (K + SL - 1) / SL;
-                const int kk = (int)(i % SL); long t = i / SL; const int n = (int)(t % N); t /= N; const int slab = (int)(t % nslab), tap = (int)(t / nslab);
+                const int kk = (int)(i % (unsigned)SL); unsigned t = i / (unsigned)SL; const int n = (int)(t % (unsigned)N); t /= (unsigned)N;
+                const int slab = (int)(t % (unsigned)nslab), tap = (int)(t / (unsigned)nslab);
                 const int k = slab * SL + kk;
                 if (k < K) v = mode ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
             }
         } else {
             // 1x1x1: rows n, contraction k.  kind 2: n = co, k = ci, element w3[n][k];  kind 3: n = ci, k = co, element w3[k][n]
             const int K = pr.kind == 2 ? Cin : Cout, N = pr.kind == 2 ? Cout : Cin, RW = pr.pair ? 32 : SL;
-            const int kk = (int)(i % RW); const long t = i / RW; const int n = (int)(t % N), slab = (int)(t / N);
+            const int kk = (int)(i % (unsigned)RW); const unsigned t = i / (unsigned)RW; const int n = (int)(t % (unsigned)N), slab = (int)(t / (unsigned)N);
             const int k = pr.pair ? kk - 16 : slab * SL + kk;
             if (k >= 0 && k < K) v = pr.kind == 2 ? w[(long)n * K + k] : w[(long)k * N + n];
         }
@@ -2092,6 +2095,7 @@ extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, 
             if (q.kind == 4) {       // transposed-conv tap-major pack: always bf16 (the operand of unetr_gemm_bf16)
                 if (prec != UNETR_PREC_BF16) return UNETR_ERR_UNSUPPORTED;
                 const long total4 = 8L * q.Cin * q.Cout;
+                if (total4 >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;
                 a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, 4, 0, blocks, total4, 0};
                 blocks += cdiv(total4, 2048);
                 continue;
@@ -2101,6 +2105,7 @@ extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, 
             long total;
             if (q.kind <= 1) total = pair ? 14L * N * 32 : 27L * ((K + SL - 1) / SL) * N * SL;
             else total = pair ? (long)N * 32 : (long)((K + SL - 1) / SL) * N * SL;
+            if (total >= (1L << 31)) return UNETR_ERR_UNSUPPORTED;
             const int staged = (q.kind <= 1 && !pair) ? 1 : 0;
             a.p[i] = PkProblem{q.w, q.out, q.Cin, q.Cout, q.kind, pair, blocks, total, staged};
             blocks += staged ? ((K + SL - 1) / SL) * cdiv(N, 8) : cdiv(total, 2048);
