@@ -1013,31 +1013,6 @@ outconv_wgrad_generic_kernel(const float* __restrict__ dl, const T* __restrict__
         if ((int)threadIdx.x + k * 256 < np) part[(long)blockIdx.x * np + threadIdx.x + k * 256] = acc[k];
 }
 
-// the same sum straight from the per-workgroup partials in ONE launch (R <= a few thousand rows, N <= 256 columns: the 4-class
-// head has 68): block = 64 columns x 4 row phases, eight rows in flight per thread, fixed order
-__global__ void __launch_bounds__(256)
-outconv_reduce_kernel(const float* __restrict__ part, int R, int N, int n0, float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ float sm[4][64];
-    const int tx = threadIdx.x & 63, ph = threadIdx.x >> 6, n = blockIdx.x * 64 + tx;
-    float s = 0.f;
-    if (n < N) {
-        int r = ph;
-        for (; r + 28 < R; r += 32) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = part[(long)(r + 4 * u) * N + n];
-            s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-        }
-        for (; r < R; r += 4) s += part[(long)r * N + n];
-    }
-    sm[ph][tx] = s;
-    __syncthreads();
-    if (ph == 0 && n < N) {
-        const float t = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
-        if (n < n0) out0[n] = t; else out1[n - n0] = t;
-    }
-}
-
 // out0[n] = sum_r part[r][n] for n < n0, out1[n - n0] for the rest (bias gradient, then weight gradient)
 __global__ void outconv_final_kernel(const float* __restrict__ part, int R, int N, int n0, float* __restrict__ out0, float* __restrict__ out1) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1420,9 +1395,7 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, 
     float* ws2 = (float*)((char*)ws + part_al);
     size_t ws2_bytes = ws_bytes - part_al;
     // dbias (and dw) = column sums of the [nblk, np] partials (ws2 holds the colsum's own partials)
-    if (np <= 256) {         // (one launch: the partial matrix is nblk x np floats = 278 KB for the 4-class head)
-        hipLaunchKernelGGL(outconv_reduce_kernel, dim3(cdiv(np, 64)), dim3(256), 0, st, ws, nblk, np, Cout, dbias, dw);
-    } else {
+    {
         int RB = std::max(1, std::min(cdiv(nblk, 64), 256));
         if ((size_t)RB * np * sizeof(float) > ws2_bytes) return UNETR_ERR_WORKSPACE;
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(np, 64), RB), dim3(256), 0, st, ws, (long)np, nblk, np, ws2, RB);
