@@ -2,16 +2,21 @@
 AdamW step -> zero_grad) as ONE object that owns how it is launched on an MI355X:
 
 * single GPU: the whole step -- forward, loss, backward, AdamW -- is captured into one hipGraph and replayed (no per-step
-  host work, no host sync: AdamW's step counters live on the device, the loss stays a device scalar).
+  host work, no host sync: AdamW's step counters live on the device, the loss stays a device scalar).  ``fuse_update``: AdamW
+  of the ViT weight matrices is applied in the epilogue of the grouped weight-gradient launch that ends backward (their
+  gradients are never stored); one table-driven launch updates the remaining parameters.  Same bits as the separate launch.
 * data parallel (one process per GPU, RCCL over xGMI; new capability, the reference is single-GPU): backward runs in the
   five passes of ``UNETR.forward_staged`` and the sum-all-reduce of each pass's gradient range (``UNETR.stage_ranges``)
-  is issued on a side HIP stream as soon as that pass has been launched, so it runs underneath the passes that follow
-  (conv-side gradients under ViT blocks 11..8, those under blocks 7..4, ...).  What is left when backward ends -- the
-  last range (block 0 + patch embedding, 41 MB of the 370 MB), cut into ``tail_pieces`` -- overlaps with the AdamW kernels of the ranges already reduced: the optimizer
-  kernel reads the summed gradients straight from the communication buffer and averages on the fly, so there is no copy
-  back and no scaling pass.  Pass 0 (with forward and loss) and passes 1-4 are separate hipGraphs sharing one memory pool;
-  the collectives are ordinary eager RCCL calls between graph launches, nothing depends on capturing a collective.
-  Gradients travel in fp32 by default (the same sum the single-GPU arithmetic would do), bf16 on request.
+  is issued on a side HIP stream as soon as that pass has FINISHED -- the launching thread runs one graph ahead and waits for
+  the event behind the pass before (``handover="host"``: no stream waits on an unfinished event of another stream) -- so it
+  runs underneath the passes that follow (conv-side gradients under ViT blocks 11..8, those under blocks 7..4, ...).  What
+  is left when backward ends -- the last range (block 0 + patch embedding, 41 MB of the 370 MB), cut into ``tail_pieces`` --
+  overlaps with the AdamW kernels of the ranges already reduced: the optimizer kernel reads the summed gradients straight
+  from the communication buffer and averages on the fly, so there is no copy back and no scaling pass.  Every pass that
+  hands a range over ends a hipGraph (pass 0 shares one with pass 1: 4 graphs, one memory pool); the collectives are
+  ordinary eager RCCL calls between graph launches, nothing depends on capturing a collective.  Gradients travel in fp32
+  by default (the same sum the single-GPU arithmetic would do), bf16 on request -- then the weight-gradient launch writes the
+  bf16 gradients of the ViT weights straight into the communication buffer (``fuse_comm``).
 
 ``bench.py`` and ``tests/test_model_gpu.py`` both drive the step through this class, so what is measured is what is tested.
 """

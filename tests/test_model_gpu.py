@@ -582,7 +582,7 @@ def test_c2_bench_path_bf16_parity(pkg, dev):
 @pytest.mark.parametrize("size", ["c1", "c2"])
 def test_staged_backward_equals_single_pass(pkg, dev, size):
     """The data-parallel launch form (forward_staged + 5 backward passes, per-pass reduce slots, AdamW per reduced piece,
-    5 hipGraphs) must give the SAME parameters as the single-graph step: same kernels, same order of every floating-point
+    4 hipGraphs, hand-over through the host or by stream wait) must give the SAME parameters as the single-graph step: same kernels, same order of every floating-point
     sum (the only fan-out sums have two terms).  Run on one rank (the all-reduce of a 1-rank job is the identity).
     size c2 = BASELINE configs[2]'s per-rank workload exactly (96^3, hidden 768, 4 classes, bf16, batch 2, fp32 gradient
     communication): the launch form the 8-GPU bench runs, held bit for bit to the single-GPU step of configs[1]."""
