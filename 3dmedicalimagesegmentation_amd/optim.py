@@ -166,6 +166,7 @@ class AdamW(torch.optim.Optimizer):
             raise RuntimeError("fused step: the set of parameters that received gradients differs from the planned pattern")
         gbase = flat["grad"].data_ptr()
         done = set(fz["done"])
+        self.fused_parameters = len(done)          # how many parameters the weight-gradient launch updated itself in this step
         for i, (p, o, has) in enumerate(zip(params, flat["offsets"], pattern)):
             if has and i not in done and p.grad.data_ptr() != gbase + o * 4:
                 raise RuntimeError("fused step: a gradient was produced outside the arena")

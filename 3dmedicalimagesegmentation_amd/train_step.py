@@ -349,7 +349,8 @@ class TrainStep:
         if self.graphs is None:
             return "eager"
         if not self.dp:
-            return "hipGraph(fwd+loss+bwd+AdamW" + (", AdamW of the ViT weights in the weight-gradient epilogue)" if self.fuse else ")")
+            fused = self.fuse and getattr(self.opt, "fused_parameters", 0) > 0     # (fp32 mode has no bf16-storage weight-gradient launch to ride on)
+            return "hipGraph(fwd+loss+bwd+AdamW" + (", AdamW of the ViT weights in the weight-gradient epilogue)" if fused else ")")
         if self.one_graph:
             return (f"hipGraph(fwd+loss+bwd in {self.npass} passes; AdamW per pass on a side-stream branch underneath the passes that follow)")
         return (f"{len(self.graphs)} hipGraphs ({self.npass} backward passes: fwd+loss+conv side | ViT passes 1-{self.npass - 1}), "
