@@ -1032,8 +1032,10 @@ class PatchEmbedFn(torch.autograd.Function):
         pd = C * patch ** 3
         hid = w.shape[0]
         ctx.pb = None
-        if _bf16_path(prec, pd):
-            # the bf16 GEMM operand straight from the gather kernel (no fp32 patch matrix, no cast pass)
+        if _bf16_path(prec, pd) and (B * L) % 8 == 0 and hid % 8 == 0:
+            # the bf16 GEMM operand straight from the gather kernel (no fp32 patch matrix, no cast pass).  Only where backward's
+            # weight gradient can take the bf16 grouped launch (wgrad_or_defer: rows and both widths multiples of 8): its fp32
+            # fallback needs the fp32 patch matrix this branch does not keep (e.g. 48^3 at batch 1: 27 token rows)
             z = torch.empty(B * L, hid, dtype=torch.float32, device=x_in.device)
             ctx.pb = torch.empty(B * L, pd, dtype=torch.bfloat16, device=x_in.device)
             patches = x_in.new_empty(0)

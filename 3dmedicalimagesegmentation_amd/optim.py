@@ -139,6 +139,15 @@ class AdamW(torch.optim.Optimizer):
         group = self.param_groups[0]
         params = group["params"]
         pattern = tuple(bool(f) for f in pattern)
+        # everything that can be checked BEFORE backward is checked here: the epilogue updates the ViT weights during backward,
+        # so a failure found afterwards (finish_fused_step) leaves the model half-updated
+        for p, has in zip(params, pattern):
+            if has and p.grad is not None:
+                raise RuntimeError("fused step: a planned parameter already carries .grad (its gradient would be accumulated outside "
+                                   "the arena); call zero_grad(set_to_none=True) before the step")
+            if self.state.get(p):
+                raise RuntimeError("fused step: this optimizer has per-tensor AdamW state (an earlier step() took the per-tensor path); "
+                                   "the arena moments would silently restart from zero")
         if self._flat_state is None:
             self._flat_state = (torch.zeros_like(flat["param"]), torch.zeros_like(flat["param"]))
         steps = self._advance_steps(0, params, pattern, flat["param"].device)
@@ -155,6 +164,8 @@ class AdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def finish_fused_step(self):
+        """A RuntimeError raised here is fatal for the step: the weight-gradient epilogue has already updated the fused weights
+        and the step counters have advanced, the remaining parameters have not stepped -- reload a checkpoint."""
         import ctypes
         flat, fz = self._flat, self._fused
         flat["state"].fuse = None
@@ -171,14 +182,18 @@ class AdamW(torch.optim.Optimizer):
             if has and i not in done and p.grad.data_ptr() != gbase + o * 4:
                 raise RuntimeError("fused step: a gradient was produced outside the arena")
         rest = tuple(has and i not in done for i, has in enumerate(pattern))
-        key = (pattern, tuple(sorted(done)))
+        # a run shares ONE step counter (its first parameter's): the runs depend on which neighbours have equal step counts, so
+        # their boundaries are part of the key (alternating patterns -- the feat / recon passes of the ranking pre-training --
+        # make counts diverge between two uses of the same pattern)
+        runs = self._flat_runs(params, rest)
+        key = (pattern, tuple(sorted(done)), tuple((i, j) for i, j, _, _ in runs))
         cache = getattr(self, "_range_tables", None)
         if cache is None:
             cache = self._range_tables = {}
         ent = cache.get(key)
         if ent is None:
             rows, blocks = [], 0
-            for i, j, lo, hi in self._flat_runs(params, rest):
+            for i, j, lo, hi in runs:
                 rows.append((lo, hi, i, blocks))
                 blocks += (hi - lo + 4095) // 4096
             table = torch.tensor(rows, dtype=torch.int64, device=flat["param"].device) if rows else None

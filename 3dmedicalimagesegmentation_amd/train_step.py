@@ -164,6 +164,7 @@ class TrainStep:
                 gbase = flat["grad"].data_ptr()
                 index = {gbase + o * 4: i for i, (o, has) in enumerate(zip(flat["offsets"], self._plan["pattern"])) if has}
                 self._comm_fuse = dict(kind="bf16out", grad=gbase, out=self.comm_buf.data_ptr(), total=flat["param"].numel(), index=index, done=[])
+            self._comm_fuse["done"].clear()               # what THIS step's weight-gradient launches write into the communication buffer
             self.flat["state"].fuse = self._comm_fuse
         self.loss = self.crit(logits, self.y)
         self._backward()
@@ -175,6 +176,12 @@ class TrainStep:
             torch.autograd.backward(roots, [leaf.grad for r, leaf in st if leaf.grad is not None])
         if k == self.npass - 1 and self._comm_fuse is not None and self.flat["state"].fuse is self._comm_fuse:
             self.flat["state"].fuse = None             # the last pass of the step has queued its weight-gradient launch
+            # the cast tables skip exactly the ranges the epilogue wrote when they were built: a step whose fused set differs (a
+            # problem dropping off the bf16 grouped path) would send stale bf16 values through the all-reduce
+            done = frozenset(self._comm_fuse["done"])
+            for (lo, hi), ent in self._cast_tables.items():
+                if ent[3] != frozenset(i for i in done if lo <= self.flat["offsets"][i] < hi):
+                    raise RuntimeError("data-parallel step: the set of gradients written by the weight-gradient epilogue changed between steps")
 
     def _reduce_and_update(self, k, after=None):
         """Pass k has been launched on the current stream (after: the event recorded behind it -- the host waits for it here and
@@ -234,8 +241,9 @@ class TrainStep:
                     blocks += (o - cur + 8191) // 8192
                 cur = max(cur, o + numel.get(o, 0))
             table = torch.tensor(rows, dtype=torch.int64, device=flat["param"].device) if rows else None
-            ent = self._cast_tables[(lo, hi)] = (table, len(rows), blocks)
-        table, nr, blocks = ent
+            ent = self._cast_tables[(lo, hi)] = (table, len(rows), blocks,
+                                                 frozenset(i for i in set(self._comm_fuse["done"]) if lo <= flat["offsets"][i] < hi))
+        table, nr, blocks = ent[:3]
         if nr:
             Fn.call("unetr_cast_bf16_ranges", self.flat["grad"].data_ptr(), self.comm_buf.data_ptr(), table.data_ptr(), nr, blocks,
                     torch.cuda.current_stream().cuda_stream)

@@ -81,6 +81,33 @@ def test_c1_bf16_bounded(pkg, dev):
         assert c > 0.97, (k, c)
 
 
+@pytest.mark.parametrize("flat", [False, True])
+def test_bf16_token_rows_not_multiple_of_8(pkg, dev, flat):
+    """bf16 mode at 48^3 / batch 1: 27 token rows.  The forward GEMMs have no row-count requirement, but the bf16 grouped weight
+    gradient needs rows % 8 == 0 -- such a shape must take the fp32 weight-gradient route end to end (the patch embedding once
+    kept no fp32 patch matrix for it and raised in backward), with and without the flat arenas."""
+    cfg = dict(C1, img_size=(48, 48, 48))
+    from oracle.unetr_oracle import oracle_dice_ce_terms, synthetic_volume
+    ref, hip = _pair(pkg, dev, cfg)
+    hip.precision = "bf16"
+    if flat:
+        hip.use_flat_buffers()
+    x, y = synthetic_volume(1, 1, 48, 2, seed=11)
+    _, logits_r = ref(x.double())
+    d_r, c_r = oracle_dice_ce_terms(logits_r, y.double())
+    (d_r + c_r).backward()
+    _, logits = hip(x.to(dev))
+    pkg.DiceCELoss(to_onehot_y=True, softmax=True)(logits, y.to(dev)).backward()
+    torch.cuda.synchronize()
+    assert relerr(logits, logits_r) < 5e-2
+    gr, gh = dict(ref.named_parameters()), dict(hip.named_parameters())
+    for k in ("vit.patch_embedding.patch_embeddings.1.weight", "vit.patch_embedding.position_embeddings", "vit.blocks.0.attn.qkv.weight",
+              "vit.blocks.11.mlp.linear2.weight", "decoder2.conv_block.conv2.conv.weight"):
+        assert gh[k].grad is not None and cosine(gh[k].grad, gr[k].grad) > 0.97, k
+    if flat:
+        pkg.functional.clear_grad_sinks()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_c1_fourteen_classes(pkg, dev, precision):
     """The reference's DEFAULT head -- n_classes = 14 (BTCV, unetr_segmentation_3d.py:303) -- forward + DiceCE + backward in both

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_fused", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd", "tconv_fwd", "tconv_dgrad", "tconv_wgrad"])
+    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_fused", "conv3_dgrad_fused", "conv3_wgrad3", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd", "tconv_fwd", "tconv_dgrad", "tconv_wgrad"])
     ap.add_argument("--cin", type=int, default=16)
     ap.add_argument("--cout", type=int, default=16)
     ap.add_argument("--size", type=int, default=96)
@@ -55,6 +55,19 @@ def main():
             nbytes = esz * v * (a.cin + 2 * a.cout) + 4.0 * (w.numel() + w3.numel())
             flops = 2.0 * v * a.cin * a.cout * 28
             label = f"conv3_fused(+IN sums +1x1) {a.cin}->{a.cout} @ {S}^3 B={B} {a.prec}"
+        elif a.kernel == "conv3_dgrad_fused":  # residual-block input gradient: conv3x3x3^T(dc1) + conv1x1x1^T(dc3) in one launch
+            w3 = (torch.randn(a.cout, a.cin, 1, 1, 1, generator=g) * 0.2).to(dev)
+            dy3 = torch.randn(B, S, S, S, a.cout, generator=g).to(dev).to(adt)
+            dxo = torch.empty(B, S, S, S, a.cin, device=dev, dtype=adt)
+            fn = lambda: Fn.conv3_dgrad_fused(dy, dy3, w, w3, dxo, dims, prec)
+            nbytes = esz * v * (a.cin + 2 * a.cout) + 4.0 * (w.numel() + w3.numel())
+            flops = 2.0 * v * a.cin * a.cout * 28
+        elif a.kernel == "conv3_wgrad3":       # weight gradients of the 3x3x3 conv and of the 1x1x1 branch sharing its input
+            dy3 = torch.randn(B, S, S, S, a.cout, generator=g).to(dev).to(adt)
+            dw3 = torch.empty(a.cout, a.cin, 1, 1, 1, device=dev)
+            fn = lambda: Fn.conv3_wgrad(x, a.cin, dy, a.cout, dims, a.cin, a.cout, prec, dy3=dy3, out3=dw3)
+            nbytes = esz * v * (a.cin + 2 * a.cout) + 4.0 * w.numel()
+            flops = 2.0 * v * a.cin * a.cout * 28
         elif a.kernel == "conv3_fwd":
             fn = lambda: Fn.conv3(x, a.cin, w, dims, prec)
         elif a.kernel == "conv3_dgrad":
