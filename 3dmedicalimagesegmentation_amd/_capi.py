@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
-ABI_VERSION = 8        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 9        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -107,6 +107,10 @@ _SIGNATURES = {
     "unetr_conv3_pack_weight": [P, P, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd": [P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_fwd_fused": [P, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
+    "unetr_conv3_fwd_parts": [P, c_long, P, P, c_long, P, P, P, c_long, P, ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_conv3_dgrad_stats": [P, c_long, P, P, c_long, P, c_long, P, P, ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_instnorm_apply_fin": [P, c_long, P, c_int, P, c_long, P, c_int, P, P, c_float, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
+    "unetr_instnorm_bwd_apply_fin": [P, c_long, P, c_long, P, P, c_long, P, P, c_int, c_int, P, c_long, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
     "unetr_conv3_dgrad_fused": [P, c_long, P, P, c_long, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_pack_grouped": [ctypes.POINTER(PackProblem), c_int, c_int, P],
     "unetr_conv3_pack_1x1": [P, P, c_int, c_int, c_int, P],

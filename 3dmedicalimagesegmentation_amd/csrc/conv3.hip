@@ -19,12 +19,14 @@
 // workgroup walks many voxel tiles; per-workgroup partial sums are reduced in a fixed order.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/unetr_hip.h"
 
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define LDS_AS __attribute__((address_space(3)))
 
 constexpr int TZ = 4, TY = 4, TX = 16;          // output tile
@@ -507,9 +509,14 @@ __device__ __forceinline__ void stats_add(const f32x4 (&acc)[4][NTB], const bool
             s1[j] += v; s2[j] += v * v;
         }
 }
+// One partial row per WORKGROUP: the four waves' sums meet in LDS (fixed order: wave 0 + 1 + 2 + 3) -- the consumers of these
+// rows re-reduce them in their own prologue (norm_misc.hip: in_fin_*), so the row count is what every consumer block pays for.
+// Every wave of a workgroup walks the same tiles, so a flush (batch item changes / end of the walk) is workgroup-uniform and
+// may hold barriers.  sred: NTB * 128 floats of LDS.
 template <int NTB>
-__device__ __forceinline__ void stats_flush(f32x4 (&s1)[NTB], f32x4 (&s2)[NTB], float* __restrict__ prow, int Cout, int ch0, int r) {
-    // sum over the 16 voxel columns (lanes with equal g), lane r == 0 of each group writes its four channels
+__device__ __forceinline__ void stats_flush(f32x4 (&s1)[NTB], f32x4 (&s2)[NTB], float* __restrict__ prow, int Cout, int n0, int r, int g, int wv,
+                                            float* sred) {
+    // sum over the 16 voxel columns (lanes with equal g), lane r == 0 of each group holds its four channels
 #pragma unroll
     for (int j = 0; j < NTB; ++j) {
         f32x4 a = s1[j], q = s2[j];
@@ -517,8 +524,24 @@ __device__ __forceinline__ void stats_flush(f32x4 (&s1)[NTB], f32x4 (&s2)[NTB], 
         for (int o = 1; o < 16; o <<= 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] += __shfl_xor(a[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
-        if (r == 0) { *(f32x4*)(prow + ch0 + j * 16) = a; *(f32x4*)(prow + Cout + ch0 + j * 16) = q; }
+        if (r == 0) { *(f32x4*)(sred + (wv * 2 + 0) * NTB * 16 + j * 16 + 4 * g) = a; *(f32x4*)(sred + (wv * 2 + 1) * NTB * 16 + j * 16 + 4 * g) = q; }
         s1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * NTB * 16) {
+        const int t = threadIdx.x, which = t / (NTB * 16), ch = t - which * (NTB * 16);
+        const float v = ((sred[(0 * 2 + which) * NTB * 16 + ch] + sred[(1 * 2 + which) * NTB * 16 + ch]) + sred[(2 * 2 + which) * NTB * 16 + ch]) +
+                        sred[(3 * 2 + which) * NTB * 16 + ch];
+        prow[which * Cout + n0 + ch] = v;
+    }
+    __syncthreads();
+}
+// this workgroup's row of every batch item starts at zero (a workgroup only flushes the batch items its tiles touch)
+template <int NTB>
+__device__ __forceinline__ void stats_zero_rows(float* __restrict__ part, int nb, long srows, int Cout, int n0) {
+    if ((int)threadIdx.x < 2 * NTB * 16) {
+        const int t = threadIdx.x, which = t / (NTB * 16), ch = t - which * (NTB * 16);
+        for (int bb = 0; bb < nb; ++bb) part[(((long)bb * srows) + blockIdx.x) * 2 * Cout + which * Cout + n0 + ch] = 0.f;
     }
 }
 
@@ -534,6 +557,10 @@ __device__ __forceinline__ void stats_flush(f32x4 (&s1)[NTB], f32x4 (&s2)[NTB], 
 //   the 1x1x1 branch) multiplied by a 1x1x1 weight matrix in the tile epilogue: dx = conv3x3x3^T(dc1) + conv1x1x1^T(dc3) in
 //   one pass, instead of a GEMM writing dx followed by an accumulating conv that re-reads it.  x3 fragments are loaded
 //   straight from global memory in MFMA operand shape (16 voxels x one 16-byte chunk per lane group).
+// FUSE == 5 (data gradient in front of an InstanceNorm's backward): besides y = conv(x) the kernel emits the two per-channel
+//   sums the InstanceNorm backward of the tensor this gradient belongs to needs -- sum(g) and sum(g * n) with n = the normalised
+//   forward value a * xn + o (xn = y3: the pre-norm tensor, same shape / pitch as y; a, o from the statistics wp3 = [B][Cout][2]
+//   (mean, rstd)) and g = y * lrelu'(n) -- as partial rows `part`, so the separate reduction pass over (y, xn) disappears.
 // WL (slab mode only) = number of slab-weight images kept in LDS, filled by LDS-DMA (27 x NTB KB each: lane (r, g) of the
 // (tap, j) piece holds the 16 bytes that same lane feeds to the MFMA, so the fragment read is a linear ds_read_b128).
 //   WL 1: Cin <= one slab -- the weights are loaded once per workgroup and serve every tile it walks;
@@ -592,8 +619,11 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
 #pragma unroll
         for (int j = 0; j < NTB; ++j) w3res[j] = *(const u32x4*)(wp3 + ((long)(nt0 + j) * 16 + r) * 64 + g * 16);
     }
-    constexpr bool STATS = FUSE >= 1 && FUSE <= 3;
+    constexpr bool BST = FUSE == 5;
+    constexpr bool STATS = (FUSE >= 1 && FUSE <= 3) || BST;
+    __shared__ float sred[STATS ? NTB * 128 : 1];
     f32x4 rs1[STATS ? NTB : 1], rs2[STATS ? NTB : 1], rt1[any3 ? NTB : 1], rt2[any3 ? NTB : 1];
+    f32x4 bsa[BST ? NTB : 1], bso[BST ? NTB : 1];      // FUSE 5: n = xn * bsa + bso for this lane's channels of the current batch item
     if constexpr (STATS) {
 #pragma unroll
         for (int j = 0; j < NTB; ++j) { rs1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; rs2[j] = rs1[j]; }
@@ -603,22 +633,11 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         for (int j = 0; j < NTB; ++j) { rt1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; rt2[j] = rt1[j]; }
     }
     int cur_b = -1;
-    const long srows = (long)gridDim.x * 4;       // partial rows per batch item
+    const long srows = (long)gridDim.x;           // partial rows per batch item: one per workgroup
     if constexpr (STATS) {
-        // this wave's rows of every batch item start at zero (a wave only flushes the batch items its tiles touch)
         const int nb = ntiles / (ntx * nty * ntz);
-        if (g == 0) {
-            for (int bb = 0; bb < nb; ++bb) {
-                float* p0 = part + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + nt0 * 16 + r;
-#pragma unroll
-                for (int j = 0; j < NTB; ++j) { p0[j * 16] = 0.f; p0[Cout + j * 16] = 0.f; }
-                if constexpr (any3) {
-                    float* p3 = part3 + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + nt0 * 16 + r;
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) { p3[j * 16] = 0.f; p3[Cout + j * 16] = 0.f; }
-                }
-            }
-        }
+        stats_zero_rows<NTB>(part, nb, srows, Cout, nt0 * 16);
+        if constexpr (any3) stats_zero_rows<NTB>(part3, nb, srows, Cout, nt0 * 16);
     }
 
     const int ylane = r * (int)ldy + nt0 * 16 + 4 * g;      // this lane's element offset inside an output row of 16 voxels
@@ -690,10 +709,20 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
         if constexpr (STATS) {
             if (b != cur_b) {
                 if (cur_b >= 0) {
-                    stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
-                    if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
+                    stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, nt0 * 16, r, g, wv, sred);
+                    if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, nt0 * 16, r, g, wv, sred);
                 }
                 cur_b = b;
+                if constexpr (BST) {
+                    const float* sa = (const float*)wp3 + ((long)b * Cout + nt0 * 16 + 4 * g) * 2;
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float mu = sa[(j * 16 + e) * 2], rs = sa[(j * 16 + e) * 2 + 1];
+                            bsa[j][e] = rs; bso[j][e] = -mu * rs;
+                        }
+                }
             }
         }
 
@@ -712,9 +741,27 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                 }
             }
         };
+        // FUSE 5: this lane's pre-norm values xn of the tile's output positions (4 channels x 4 rows x NTB), requested before the
+        // MFMA phase and kept packed until the epilogue
+        typedef typename std::conditional<sizeof(YT) == 2, u32x2, f32x4>::type XnRaw;
+        XnRaw xnr[BST ? 4 : 1][BST ? NTB : 1];
+        auto xn_load = [&]() {
+            if constexpr (BST) {
+                const int zo_ = z0 + wv, xo_ = x0 + r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int yo_ = y0 + i;
+                    const bool ok = zo_ < D && yo_ < H && xo_ < W;
+                    const YT* q = (const YT*)y3 + (ok ? ((((long)b * D + zo_) * H + yo_) * W + xo_) * ldy3 + nt0 * 16 + 4 * g : 0);
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) xnr[i][j] = *(const XnRaw*)(q + j * 16);
+                }
+            }
+        };
         for (int slab = 0; slab < nslab; ++slab) {
           if constexpr (DMAW) {
             if constexpr (FUSE == 4) x3_load(0, z0, y0, x0, b, w3f0, av0);
+            if constexpr (BST) xn_load();
           } else {
             __syncthreads();                       // everyone is done reading the previous window
             if constexpr (XM == 2) halo_store_planned<P, NCH>(R, plan, halo);    // (waits for the prefetched loads)
@@ -743,6 +790,7 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                 // (requested behind the window prefetch: in flight during the MFMA phase, consumed in the tile epilogue -- loaded
                 // there, every tile waited a global round trip for them)
                 if constexpr (FUSE == 4) { if (slab == 0) x3_load(0, z0, y0, x0, b, w3f0, av0); }
+                if constexpr (BST) { if (slab == nslab - 1) xn_load(); }
             }
           }
             if constexpr (PAIR) {
@@ -945,7 +993,22 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                     for (int j = 0; j < NTB; ++j)
                         if (okv[i]) Io<YT>::st4(yrow[i] + j * 16, acc[i][j]);
             }
-            if constexpr (STATS) stats_add<NTB>(acc, okv, rs1, rs2);
+            if constexpr (STATS && !BST) stats_add<NTB>(acc, okv, rs1, rs2);
+            if constexpr (BST) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) {
+                        f32x4 xn;
+                        if constexpr (sizeof(YT) == 2) xn = __builtin_convertvector(__builtin_bit_cast(bf16x4, xnr[i][j]), f32x4);
+                        else xn = __builtin_bit_cast(f32x4, xnr[i][j]);
+                        const f32x4 n = xn * bsa[j] + bso[j];
+                        f32x4 ge;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ge[e] = n[e] > 0.f ? acc[i][j][e] : 0.01f * acc[i][j][e];
+                        if (okv[i]) { rs1[j] += ge; rs2[j] += ge * n; }
+                    }
+            }
             if constexpr (has3) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -983,8 +1046,8 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
     }
     if constexpr (STATS) {
         if (cur_b >= 0) {
-            stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
-            if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, nt0 * 16 + 4 * g, r);
+            stats_flush<NTB>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, nt0 * 16, r, g, wv, sred);
+            if constexpr (any3) stats_flush<NTB>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, nt0 * 16, r, g, wv, sred);
         }
     }
 }
@@ -1035,16 +1098,12 @@ conv3_c1_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wp
     // InstanceNorm partial sums (see stats_add / stats_flush)
     f32x4 rs1[1] = {{0.f, 0.f, 0.f, 0.f}}, rs2[1] = {{0.f, 0.f, 0.f, 0.f}}, rt1[1] = {{0.f, 0.f, 0.f, 0.f}}, rt2[1] = {{0.f, 0.f, 0.f, 0.f}};
     int cur_b = -1;
-    const long srows = (long)gridDim.x * 4;
+    const long srows = (long)gridDim.x;
+    __shared__ float sred[128];
     {
         const int nb = ntiles / (ntx * nty * ntz);
-        if (g == 0) {
-            for (int bb = 0; bb < nb; ++bb) {
-                float* p0 = part + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + r;
-                p0[0] = 0.f; p0[Cout] = 0.f;
-                if (has3) { float* p3 = part3 + (((long)bb * srows) + blockIdx.x * 4 + wv) * 2 * Cout + r; p3[0] = 0.f; p3[Cout] = 0.f; }
-            }
-        }
+        stats_zero_rows<1>(part, nb, srows, Cout, 0);
+        if (has3) stats_zero_rows<1>(part3, nb, srows, Cout, 0);
     }
     const long item = (long)D * H * W;
     // this thread's window pieces of tile (b_, z_, y_, x_): image values, 0 outside the volume
@@ -1072,8 +1131,8 @@ conv3_c1_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wp
         const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
         if (b != cur_b) {
             if (cur_b >= 0) {
-                stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
-                if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
+                stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
+                if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
             }
             cur_b = b;
         }
@@ -1119,8 +1178,8 @@ conv3_c1_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wp
         tx = ax; ty = ay; tz = az; b = ab;
     }
     if (cur_b >= 0) {
-        stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
-        if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x * 4 + wv) * 2 * Cout, Cout, 4 * g, r);
+        stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
+        if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
     }
 }
 
@@ -1813,7 +1872,8 @@ int pack_t(const float* w, void* wp, int Cin, int Cout, int mode, hipStream_t st
     return unetr_check_launch();
 }
 
-struct FuseArgs { float* part; const void* wp3; void* y3; long ldy3; float* part3; int rows; int k3; };   // k3 > 0: FUSE 4 (y3 = second input)
+// k3 > 0: FUSE 4 (y3 = second input); bst: FUSE 5 (y3 = the pre-norm tensor xn, wp3 = its statistics, part = backward-statistics rows)
+struct FuseArgs { float* part; const void* wp3; void* y3; long ldy3; float* part3; int rows; int k3; int bst = 0; };
 
 // x_f32: the input tensor is fp32 even in bf16 mode (the image in front of encoder1: <= 16 channels, pair layout only)
 template <class P>
@@ -1846,7 +1906,7 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
             if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) cap = std::min<long>(cap, atoi(e)); }
             if (cap < spatial) cap = std::max<long>(8, cap / 8 * 8);
             const unsigned gx = (unsigned)std::min<long>(spatial, cap);
-            fz->rows = (int)gx * 4;
+            fz->rows = (int)gx;
             hipLaunchKernelGGL(conv3_c1_fwd_kernel, dim3(gx), dim3(256), 0, st, (const float*)x, (const uint16_t*)wp, (uint16_t*)y, ldy, D, H, W,
                                ntx, nty, ntz, (int)spatial, fz->part, (const uint16_t*)fz->wp3, (uint16_t*)fz->y3, fz->part3);
             return unetr_check_launch();
@@ -1889,6 +1949,7 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
 #define LAUNCH_PIPE_W(NTB_, PAIR_, WL_)                                                                                           \
     do {                                                                                                                          \
         if (fz && fz->k3 > 0) { LAUNCH_PIPE_V(NTB_, PAIR_, 4, WL_); break; }                                                      \
+        if (fz && fz->bst) { LAUNCH_PIPE_V(NTB_, PAIR_, 5, WL_); break; }                                                         \
         if constexpr (!(PAIR_)) {                                                                                                 \
             if (fz && fz->wp3 && late1x1) { LAUNCH_PIPE_V(NTB_, false, 3, WL_); break; }                                          \
         }                                                                                                                         \
@@ -1904,7 +1965,7 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
         else { if (wl == 1) LAUNCH_PIPE_W(NTB_, false, 1); else LAUNCH_PIPE_W(NTB_, false, 2); }                                   \
     } while (0)
         const bool late1x1 = Cin <= 4 * P::CH;      // single-slab window: the 1x1x1 product is formed after the tile (FUSE 3)
-        if (fz && fz->k3 == 0) fz->rows = (int)pgrid.x * 4;      // (workgroup, wave) partial rows per batch item, zeroed in-kernel
+        if (fz && fz->k3 == 0) fz->rows = (int)pgrid.x;          // one partial row per workgroup and batch item, zeroed in-kernel
         if constexpr (P::CH == 8) {
             if (pair) {
                 if (ntb == 1) LAUNCH_PIPE(1, true); else LAUNCH_PIPE(2, true);
@@ -2061,7 +2122,7 @@ extern "C" int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack,
     if ((w3pack != nullptr) != (y3 != nullptr) || (w3pack != nullptr) != (stats3 != nullptr)) return UNETR_ERR_ARG;
     if (Cout % 16 || (w3pack && ldy3 != ldy)) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int max_rows = 1024 * 4;                                           // (workgroup, wave) partial rows per batch item
+    const int max_rows = UNETR_CONV3_MAX_ROWS;                               // one partial row per workgroup and batch item
     const size_t per = (size_t)B * max_rows * 2 * Cout;
     if (!ws || per * (w3pack ? 2 : 1) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
     FuseArgs fz{ws, w3pack, y3, ldy3, w3pack ? ws + per : nullptr, 0, 0};
@@ -2074,6 +2135,50 @@ extern "C" int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack,
     if (w3pack) rc = unetr_instnorm_stats_finalize2(ws, ws + per, fz.rows, B, V, Cout, eps, stats, stats3, stream);      // one launch for both sets
     else rc = unetr_instnorm_stats_finalize(ws, fz.rows, B, V, Cout, eps, stats, stream);
     return rc;
+}
+
+// The same launch WITHOUT the statistics finalize: the partial rows (part / part3: [B][rows][2][Cout] floats, caller-allocated for
+// UNETR_CONV3_MAX_ROWS rows) are handed to the consumer, which reduces them in its own prologue (unetr_instnorm_apply_fin).
+extern "C" int unetr_conv3_fwd_parts(const void* x, long ldx, const void* wpack, void* y, long ldy, float* part,
+                                     const void* w3pack, void* y3, long ldy3, float* part3, int* rows_out,
+                                     int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32, void* stream) {
+    if (!x || !wpack || !y || !part || !rows_out || B <= 0) return UNETR_ERR_ARG;
+    if ((w3pack != nullptr) != (y3 != nullptr) || (w3pack != nullptr) != (part3 != nullptr)) return UNETR_ERR_ARG;
+    if (Cout % 16 || (w3pack && ldy3 != ldy)) return UNETR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    FuseArgs fz{part, w3pack, y3, ldy3, part3, 0, 0};
+    int rc;
+    if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz, x_f32);
+    else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
+    else return UNETR_ERR_ARG;
+    if (rc) return rc;
+    if (fz.rows <= 0 || fz.rows > UNETR_CONV3_MAX_ROWS) return UNETR_ERR_WORKSPACE;
+    *rows_out = fz.rows;
+    return UNETR_OK;
+}
+
+// Data gradient dx = conv3x3x3^T(dy; w) of a conv whose INPUT went through InstanceNorm + LeakyReLU (MONAI UnetResBlock: conv2
+// reads lrelu(IN(c1))), with the backward statistics of that norm formed in the epilogue: part [B][rows][2][Cin] floats holds
+// per-workgroup partial sums of g and g * n (g = dx * lrelu'(n), n = (xn - mean) * rstd from stats [B][Cin][2]); xn has the
+// shape / pitch class of dx.  The consumer (unetr_instnorm_bwd_apply_fin) reduces the rows in its prologue.
+extern "C" int unetr_conv3_dgrad_stats(const void* dy, long lddy, const void* wpack_dgrad, void* dx, long lddx,
+                                       const void* xn, long ldxn, const float* stats, float* part, int* rows_out,
+                                       int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream) {
+    if (!dy || !wpack_dgrad || !dx || !xn || !stats || !part || !rows_out || B <= 0) return UNETR_ERR_ARG;
+    if (Cin % 16) return UNETR_ERR_UNSUPPORTED;
+    const int al = prec == UNETR_PREC_BF16 ? 7 : 15;
+    if (((uintptr_t)xn & al) || (ldxn & 3)) return UNETR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    FuseArgs fz{part, stats, const_cast<void*>(xn), ldxn, nullptr, 0, 0, 1};
+    int rc;
+    // the data gradient is the forward kernel with contraction over the conv's Cout channels and Cin outputs
+    if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(dy, lddy, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
+    else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(dy, lddy, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
+    else return UNETR_ERR_ARG;
+    if (rc) return rc;
+    if (fz.rows <= 0 || fz.rows > UNETR_CONV3_MAX_ROWS) return UNETR_ERR_WORKSPACE;
+    *rows_out = fz.rows;
+    return UNETR_OK;
 }
 
 extern "C" size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec) {

@@ -701,6 +701,195 @@ in_bwd_apply_hoist_kernel(const T* __restrict__ dy, long lddy, const T* __restri
     }
 }
 
+// ---- finalisation folded into the consumer ------------------------------------------------------------------------------
+// The tiny finalize launches (partial rows -> per-(batch item, channel) statistics) cost ~5 us each inside the captured step
+// and there were twenty of them.  Here every consumer block reduces the partial rows of ITS batch item in its prologue:
+// part[nrows][NSP][C] floats -> sums of columns (s, c), accumulated in double in a fixed order (thread = (column, row phase),
+// 8 rows in flight per thread, phases added in order through LDS), so every block of a launch forms the same bits.  The rows sit
+// in L2 (written by the launch before); a block reads nrows * NSP * C * 4 bytes (<= 64 KB for the network's layers).
+// red: 256 doubles of LDS; out: NSP * C doubles of LDS (sums, not yet divided).  C * NSP <= IN_FIN_MAXCOL.
+constexpr int IN_FIN_MAXCOL = 3 * 128;
+constexpr int IN_FIN_NT = 1024;         // threads of a FIN block: ONE block per CU, so that a CU pulls its batch item's rows once
+// columns [0, ncol) of part (and, when part2 != nullptr, columns [ncol, 2 ncol) of the combined result from part2, which has
+// nrows2 rows of the same width): out[col] = sum over rows, double, fixed order
+__device__ __forceinline__ void in_fin_sums(const float* __restrict__ part, int nrows, const float* __restrict__ part2, int nrows2, int ncol,
+                                            double* red, double* out) {
+    const int tcol = part2 ? 2 * ncol : ncol;
+    const int cpb = tcol < IN_FIN_NT ? tcol : IN_FIN_NT, nph = IN_FIN_NT / cpb;
+    const int lc = threadIdx.x % cpb, ph = threadIdx.x / cpb;
+    for (int c0 = 0; c0 < tcol; c0 += cpb) {
+        const int col = c0 + lc;
+        double s = 0.0;
+        if (ph < nph && col < tcol) {
+            const bool second = col >= ncol;
+            const float* __restrict__ p = second ? part2 + (col - ncol) : part + col;
+            const int nr = second ? nrows2 : nrows;
+            int k = ph;
+            for (; k + 15 * nph < nr; k += 16 * nph) {
+                float t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = p[(long)(k + u * nph) * ncol];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += (double)t[u];
+            }
+            for (; k + 3 * nph < nr; k += 4 * nph) {
+                float t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = p[(long)(k + u * nph) * ncol];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += (double)t[u];
+            }
+            for (; k < nr; k += nph) s += (double)p[(long)k * ncol];
+        }
+        if (ph < nph) red[ph * cpb + lc] = s;
+        __syncthreads();
+        if (ph == 0 && col < tcol) {
+            double t = 0.0;
+            for (int q = 0; q < nph; ++q) t += red[q * cpb + lc];
+            out[col] = t;
+        }
+        __syncthreads();
+    }
+}
+// (mean, rstd) from the sums of one statistics set: sums[0..C) = sum, sums[C..2C) = sum of squares -> st[C][2] (LDS); block
+// x == 0 also writes them to stats_out_b[C][2] for the consumers that come later (the backward kernels)
+__device__ __forceinline__ void in_fin_stats(const double* sums, int C, long V, float eps, float* st, float* __restrict__ stats_out_b) {
+    for (int c = threadIdx.x; c < C; c += IN_FIN_NT) {
+        const double mu = sums[c] / (double)V;
+        double var = sums[C + c] / (double)V - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)eps));
+        st[2 * c] = m; st[2 * c + 1] = r;
+        if (blockIdx.x == 0 && stats_out_b) { stats_out_b[2 * c] = m; stats_out_b[2 * c + 1] = r; }
+    }
+}
+
+// in_apply_hoist_kernel with the statistics finalize in its prologue (forward): pa / pb = partial rows of x / x2
+template <class T, bool DUAL, int U>
+__global__ void __launch_bounds__(IN_FIN_NT)
+in_apply_fin_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ pa, int rows_a, const T* __restrict__ x2, long ldx2,
+                    const float* __restrict__ pb, int rows_b, float* __restrict__ stats_a, float* __restrict__ stats_b, float eps,
+                    T* __restrict__ y, long ldy, long V, long vpb, int C, int lrelu) {
+    constexpr int W = Io<T>::W;
+    __shared__ double red[IN_FIN_NT];
+    __shared__ double sums[4 * 128];
+    __shared__ float sta[2 * 128], stb[DUAL ? 2 * 128 : 2];
+    const int cvn = C / W, nphase = IN_FIN_NT / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    const T* px2 = DUAL ? x2 + ((long)b * V) * ldx2 + W * cv : nullptr;
+    T* py = y + ((long)b * V) * ldy + W * cv;
+    in_fin_sums(pa + (long)b * rows_a * 2 * C, rows_a, DUAL ? pb + (long)b * rows_b * 2 * C : nullptr, rows_b, 2 * C, red, sums);
+    in_fin_stats(sums, C, V, eps, sta, stats_a + (long)b * C * 2);
+    if (DUAL) in_fin_stats(sums + 2 * C, C, V, eps, stb, stats_b + (long)b * C * 2);
+    __syncthreads();
+    float a1[W], o1[W], a2[DUAL ? W : 1];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        a1[e] = sta[2 * (W * cv + e) + 1]; o1[e] = -sta[2 * (W * cv + e)] * a1[e];
+        if (DUAL) { a2[e] = stb[2 * (W * cv + e) + 1]; o1[e] -= stb[2 * (W * cv + e)] * a2[e]; }
+    }
+    const float slope = lrelu ? 0.01f : 1.f;
+    for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+        u32x4 rt[U], rt2[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long vv = v + (long)u * nphase;
+            live[u] = vv < v1;
+            const long vc = live[u] ? vv : v;
+            rt[u] = *(const u32x4*)(px + vc * ldx);
+            rt2[u] = DUAL ? *(const u32x4*)(px2 + vc * ldx2) : rt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float t[W], t2[W], o[W];
+            Io<T>::unpack(rt[u], t);
+            if (DUAL) Io<T>::unpack(rt2[u], t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float n = fmaf(t[e], a1[e], o1[e]);
+                if (DUAL) n = fmaf(t2[e], a2[e], n);
+                o[e] = n > 0.f ? n : slope * n;
+            }
+            if (live[u]) Io<T>::stw(py + (v + (long)u * nphase) * ldy, o);
+        }
+    }
+}
+
+// in_bwd_apply_hoist_kernel with in_bwd_final_kernel folded into its prologue: part = [B][nrows][NSP][C] partial sums of
+// (g, g n1[, g n2]) from in_bwd_reduce_kernel (NSP 3) or from the epilogue of the conv that produced dy (NSP 2, single form)
+template <class T, bool DUAL, int U>
+__global__ void __launch_bounds__(IN_FIN_NT)
+in_bwd_apply_fin_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
+                        const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, const float* __restrict__ part, int nrows, int NSP,
+                        T* __restrict__ dx, long lddx, T* __restrict__ dx2, long lddx2, long V, long vpb, int C, int lrelu) {
+    constexpr int W = Io<T>::W;
+    __shared__ double red[IN_FIN_NT];
+    __shared__ double sums[IN_FIN_MAXCOL];
+    const int cvn = C / W, nphase = IN_FIN_NT / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    in_fin_sums(part + (long)b * nrows * NSP * C, nrows, nullptr, 0, NSP * C, red, sums);
+    const float* s1 = sa + ((long)b * C + W * cv) * 2;
+    const float* s2 = DUAL ? sb + ((long)b * C + W * cv) * 2 : nullptr;
+    float a1[W], o1[W], k0[W], k1[W], a2[DUAL ? W : 1], o2[DUAL ? W : 1], q0[DUAL ? W : 1], q2[DUAL ? W : 1];
+    const double iv = 1.0 / (double)V;
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const int c = W * cv + e;
+        const float m0 = (float)(sums[c] * iv), m1 = (float)(sums[C + c] * iv);
+        a1[e] = s1[2 * e + 1]; o1[e] = -s1[2 * e] * a1[e];
+        k0[e] = a1[e] * m0; k1[e] = a1[e] * m1;
+        if (DUAL) {
+            const float m2 = (float)(sums[2 * C + c] * iv);
+            a2[e] = s2[2 * e + 1]; o2[e] = -s2[2 * e] * a2[e];
+            q0[e] = a2[e] * m0; q2[e] = a2[e] * m2;
+        }
+    }
+    const float slope = lrelu ? 0.01f : 1.f;
+    const T* pg = dy + ((long)b * V) * lddy + W * cv;
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    const T* px2 = DUAL ? x2 + ((long)b * V) * ldx2 + W * cv : nullptr;
+    T* pd = dx + ((long)b * V) * lddx + W * cv;
+    T* pd2 = DUAL ? dx2 + ((long)b * V) * lddx2 + W * cv : nullptr;
+    for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+        u32x4 rg[U], rt[U], rt2[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long vv = v + (long)u * nphase;
+            live[u] = vv < v1;
+            const long vc = live[u] ? vv : v;
+            rg[u] = *(const u32x4*)(pg + vc * lddy);
+            rt[u] = *(const u32x4*)(px + vc * ldx);
+            rt2[u] = DUAL ? *(const u32x4*)(px2 + vc * ldx2) : rt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float g[W], t[W], t2[W], o[W], p[W];
+            Io<T>::unpack(rg[u], g);
+            Io<T>::unpack(rt[u], t);
+            if (DUAL) Io<T>::unpack(rt2[u], t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float n1 = fmaf(t[e], a1[e], o1[e]);
+                const float n2 = DUAL ? fmaf(t2[e], a2[e], o2[e]) : 0.f;
+                const float ge = (n1 + n2) > 0.f ? g[e] : slope * g[e];
+                o[e] = fmaf(a1[e], ge, -k0[e]) - k1[e] * n1;
+                if (DUAL) p[e] = fmaf(a2[e], ge, -q0[e]) - q2[e] * n2;
+            }
+            if (live[u]) {
+                Io<T>::stw(pd + (v + (long)u * nphase) * lddx, o);
+                if (DUAL) Io<T>::stw(pd2 + (v + (long)u * nphase) * lddx2, p);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ layout moves
 // per batch: src [R, Ccols] (pitch lds_) -> dst [Ccols, R] (pitch ldd)
 template <class TS, class TD>
@@ -1282,6 +1471,64 @@ extern "C" int unetr_instnorm_apply(const void* x, long ldx, const float* sa, co
     return unetr_check_launch();
 }
 
+// blocks of the FIN kernels: every block re-reduces its batch item's partial rows (up to 128 KB), and a CU pulls ~70 GB/s from
+// L2: with the plain passes' 8 blocks of 256 threads per CU that prologue cost more than the 5 us finalize launch it replaces
+// (measured, round 4) -- so ONE block of 1024 threads per CU, more voxels in flight per thread
+static const long IN_FIN_BLOCKS = 256;        // one 1024-thread block per CU
+static inline bool in_fin_ok(int C, int W, int nsp) {
+    const int cvn = C / W;
+    return C % W == 0 && cvn >= 1 && cvn <= IN_FIN_NT && (cvn & (cvn - 1)) == 0 && C <= 128 && nsp * C <= IN_FIN_MAXCOL;
+}
+
+/* y = lrelu?(norm(x) [+ norm(x2)]) with the statistics formed in the kernel's prologue from the partial rows of the conv(s) that
+ * produced x / x2 (unetr_conv3_fwd_parts); stats_a / stats_b [B][C][2] are written for the later consumers */
+extern "C" int unetr_instnorm_apply_fin(const void* x, long ldx, const float* part_a, int rows_a, const void* x2, long ldx2,
+                                        const float* part_b, int rows_b, float* stats_a, float* stats_b, float eps,
+                                        void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream) {
+    if (!x || !part_a || !stats_a || !y || rows_a <= 0 || B <= 0 || V <= 0 || (x2 && (!part_b || !stats_b || rows_b <= 0))) return UNETR_ERR_ARG;
+    const int W = act16 ? 8 : 4;
+    if (!in_fin_ok(C, W, 2) || (ldx % W) || (ldy % W) || (x2 && (ldx2 % W)) || B > 65535) return UNETR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)x2) & 15) != 0) return UNETR_ERR_UNSUPPORTED;
+    const int cvn = C / W;
+    long vpb; int nchunk;
+    hipStream_t st = (hipStream_t)stream;
+    if (x2) {
+        in_chunks(V, B, 2 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
+        ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_fin_kernel<AT, true, 2>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, st, (const AT*)x, ldx, part_a, rows_a,
+                                               (const AT*)x2, ldx2, part_b, rows_b, stats_a, stats_b, eps, (AT*)y, ldy, V, vpb, C, lrelu));
+    } else {
+        in_chunks(V, B, 4 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
+        ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_fin_kernel<AT, false, 4>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, st, (const AT*)x, ldx, part_a, rows_a,
+                                               (const AT*)x2, ldx2, part_b, rows_b, stats_a, stats_b, eps, (AT*)y, ldy, V, vpb, C, lrelu));
+    }
+    return unetr_check_launch();
+}
+
+/* second half of unetr_instnorm_bwd with the finalize of the partial sums in the kernel's prologue: part [B][nrows][nsp][C]
+ * (nsp 3: rows of in_bwd_reduce_kernel; nsp 2: single form, rows written by unetr_conv3_dgrad_stats) */
+extern "C" int unetr_instnorm_bwd_apply_fin(const void* dy, long lddy, const void* x, long ldx, const float* sa,
+                                            const void* x2, long ldx2, const float* sb, const float* part, int nrows, int nsp,
+                                            void* dx, long lddx, void* dx2, long lddx2, int B, long V, int C, int lrelu, int act16, void* stream) {
+    if (!dy || !x || !sa || !dx || !part || nrows <= 0 || (x2 && (!sb || !dx2)) || (nsp != 2 && nsp != 3) || (x2 && nsp != 3)) return UNETR_ERR_ARG;
+    const int W = act16 ? 8 : 4;
+    if (!in_fin_ok(C, W, nsp) || B > 65535) return UNETR_ERR_UNSUPPORTED;
+    if ((lddy % W) || (ldx % W) || (lddx % W) || (x2 && ((ldx2 % W) || (lddx2 % W)))) return UNETR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)x2 | (uintptr_t)dx | (uintptr_t)dx2) & 15) != 0) return UNETR_ERR_UNSUPPORTED;
+    const int cvn = C / W;
+    long vpb; int nchunk;
+    hipStream_t st = (hipStream_t)stream;
+    if (x2) {
+        in_chunks(V, B, 1 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
+        ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_apply_fin_kernel<AT, true, 1>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
+                                               (const AT*)x2, ldx2, sb, part, nrows, nsp, (AT*)dx, lddx, (AT*)dx2, lddx2, V, vpb, C, lrelu));
+    } else {
+        in_chunks(V, B, 2 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
+        ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_apply_fin_kernel<AT, false, 2>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, st, (const AT*)dy, lddy, (const AT*)x, ldx, sa,
+                                               (const AT*)x2, ldx2, sb, part, nrows, nsp, (AT*)dx, lddx, (AT*)dx2, lddx2, V, vpb, C, lrelu));
+    }
+    return unetr_check_launch();
+}
+
 extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const float* sa,
                                   const void* x2, long ldx2, const float* sb, void* dx, long lddx, void* dx2, long lddx2,
                                   int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, int act16, void* stream) {
@@ -1308,6 +1555,14 @@ extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long
                                                                  (const AT*)x, ldx, sa, (const AT*)x2, ldx2, sb, V, vpb, C, lrelu, ws))
     if (x2) IN_RED(true, UD); else IN_RED(false, US);
 #undef IN_RED
+    // the finalize of the partial sums rides in the prologue of the apply kernel where that form exists (UNETR_IN_FIN=0: the
+    // separate finalize launch, kept for A/B measurements and as the route for shapes the folded form declines)
+    const char* fe = getenv("UNETR_IN_FIN");
+    const bool fin_on = !(fe && atoi(fe) == 0);
+    if (fin_on) {
+        const int rc = unetr_instnorm_bwd_apply_fin(dy, lddy, x, ldx, sa, x2, ldx2, sb, ws, nchunk, 3, dx, lddx, dx2, lddx2, B, V, C, lrelu, act16, stream);
+        if (rc != UNETR_ERR_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL(in_bwd_final_kernel, dim3(B * C), dim3(64), 0, st, ws, nchunk, V, C, B, sums);
     long total = (long)B * V * (C / W);
     const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)x2 | (uintptr_t)dx | (uintptr_t)dx2) & 15) == 0;

@@ -807,6 +807,86 @@ def conv3_fused(x, ldx, w, w3, dims, prec):
     return c, st, c3, st3
 
 
+CONV3_MAX_ROWS = 1024        # = UNETR_CONV3_MAX_ROWS (include/unetr_hip.h)
+
+
+def in_fuse_level():
+    """UNETR_AMD_IN_FUSE (tuning / A-B hook), a bit mask: 1 = the forward statistics finalize rides in the prologue of the apply
+    kernel (no finalize launches in the forward of a residual block), 2 = the backward statistics of a block's first norm are
+    formed in the epilogue of the data-gradient conv that produces its gradient (no reduction pass, no finalize launch)."""
+    return int(os.environ.get("UNETR_AMD_IN_FUSE", "3"))
+
+
+def conv3_parts(x, ldx, w, w3, dims, prec):
+    """conv3_fused without the statistics finalize: returns (c, part, c3, part3, rows) -- part* = InstanceNorm partial rows
+    [B, rows, 2, Cout] that instnorm_apply_fin reduces in its prologue -- or None when the shape takes another route."""
+    B, D, H, W = dims
+    cout, cin = w.shape[0], w.shape[1]
+    if _use_gemm_conv() or cout % 16 != 0 or cout > 128 or int(os.environ.get("UNETR_AMD_CONV_FUSE", "2")) < 2:
+        return None
+    dev = x.device
+    wp = conv_pack_get(w, 0, prec)
+    adt = act_dtype(prec)
+    x_f32 = int(prec == _capi.PREC_BF16 and x.dtype == torch.float32)
+    c = torch.empty(B, D, H, W, cout, dtype=adt, device=dev)
+    part = torch.empty(B, CONV3_MAX_ROWS, 2, cout, dtype=torch.float32, device=dev)
+    wp3 = c3 = part3 = None
+    if w3 is not None:
+        wp3 = conv_pack_get(w3, 2, prec)
+        c3 = torch.empty(B, D, H, W, cout, dtype=adt, device=dev)
+        part3 = torch.empty(B, CONV3_MAX_ROWS, 2, cout, dtype=torch.float32, device=dev)
+    rows = ctypes.c_int(0)
+    rc = call_rc("unetr_conv3_fwd_parts", x.data_ptr(), ldx, wp.data_ptr(), c.data_ptr(), cout, part.data_ptr(), _p(wp3), _p(c3), cout,
+                 _p(part3), ctypes.byref(rows), B, D, H, W, cin, cout, prec, x_f32, _stream())
+    if rc != 0:
+        return None
+    return c, part, c3, part3, rows.value
+
+
+def instnorm_apply_fin(x, part, rows, B, V, C, lrelu, x2=None, part_b=None, rows_b=0, out=None, ldo=None):
+    """instnorm_apply with the statistics formed in the kernel's prologue from partial rows; returns (y, stats, stats_b) or None"""
+    y = torch.empty_like(x) if out is None else out
+    sa = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    sb = torch.empty(B, C, 2, dtype=torch.float32, device=x.device) if x2 is not None else None
+    rc = call_rc("unetr_instnorm_apply_fin", x.data_ptr(), C, part.data_ptr(), rows, _p(x2), C, _p(part_b), rows_b, sa.data_ptr(), _p(sb),
+                 IN_EPS, y.data_ptr(), C if out is None else ldo, B, V, C, int(lrelu), _a16(x), _stream())
+    if rc != 0:
+        return None
+    return y, sa, sb
+
+
+def stats_from_parts(part, rows, B, V, C):
+    stats = torch.empty(B, C, 2, dtype=torch.float32, device=part.device)
+    call("unetr_instnorm_stats_finalize", part.data_ptr(), rows, B, V, C, IN_EPS, stats.data_ptr(), _stream())
+    return stats
+
+
+def conv3_dgrad_stats(dy, w, xn, stats, dims, prec):
+    """da = conv3x3x3^T(dy; w) together with the partial sums of the InstanceNorm backward of xn's norm (the norm whose
+    lrelu'd output the conv read): returns (da, part, rows) or None when the shape takes the unfused route"""
+    B, D, H, W = dims
+    cout, cin = w.shape[0], w.shape[1]
+    if _use_gemm_conv() or cin % 16 != 0 or cin > 128 or xn.stride(-2) != cin:
+        return None
+    wp = conv_pack_get(w, 1, prec)
+    da = torch.empty(B, D, H, W, cin, dtype=act_dtype(prec), device=dy.device)
+    part = torch.empty(B, CONV3_MAX_ROWS, 2, cin, dtype=torch.float32, device=dy.device)
+    rows = ctypes.c_int(0)
+    rc = call_rc("unetr_conv3_dgrad_stats", dy.data_ptr(), cout, wp.data_ptr(), da.data_ptr(), cin, xn.data_ptr(), cin, stats.data_ptr(),
+                 part.data_ptr(), ctypes.byref(rows), B, D, H, W, cin, cout, prec, _stream())
+    if rc != 0:
+        return None
+    return da, part, rows.value
+
+
+def instnorm_bwd_apply_fin(dy, lddy, x, sa, part, rows, nsp, B, V, C, lrelu):
+    """dx of y = lrelu?(norm(x)) from dy and the partial sums `part` [B, rows, nsp, C]; None when unsupported"""
+    dx = torch.empty_like(x)
+    rc = call_rc("unetr_instnorm_bwd_apply_fin", dy.data_ptr(), lddy, x.data_ptr(), C, sa.data_ptr(), None, 0, None, part.data_ptr(), rows, nsp,
+                 dx.data_ptr(), C, None, 0, B, V, C, int(lrelu), _a16(x), _stream())
+    return dx if rc == 0 else None
+
+
 def conv3_dgrad_fused(dc1, dc3, w1, w3, dx, dims, prec):
     """dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3) in one launch (the input gradient of a residual block);
     returns False when the shape has to take the two-kernel route."""
@@ -951,7 +1031,10 @@ def tconv_fwd(x, ldx, w, dims, cin, cout, prec, out=None, ldo=None):
             o32 = torch.empty(B, 2 * D, 2 * H, 2 * W, cout, dtype=torch.float32, device=x.device)
             call("unetr_tconv_fwd", x32.data_ptr(), cin, w.data_ptr(), o32.data_ptr(), cout, B, D, H, W, cin, cout, prec,
                  ws.data_ptr(), ws.numel() * 4, _stream())
-            out[..., :cout].copy_(o32) if out.shape[-1] != cout else out.copy_(o32)
+            # (through the row-copy kernel, not Tensor.copy_: `out` may be a view handed out by TconvFn.forward -- the skip half of
+            # a concatenation buffer -- and a torch in-place op on it inside a custom Function invalidates the view's grad_fn)
+            o16 = o32.to(adt)
+            call("unetr_copy_rows", out.data_ptr(), ldo, o16.data_ptr(), cout, B * 8 * D * H * W, cout, 0, _a16(out), _stream())
         else:
             call("unetr_tconv_fwd", *args)
     return out, None
@@ -1272,6 +1355,10 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec, to_cat=False):
     """MONAI UnetResBlock (instance norm, in != out): lrelu(IN(conv2(lrelu(IN(conv1 x)))) + IN(conv3 x))."""
     B, D, H, W = dims
     V = D * H * W
+    if in_fuse_level() & 1:
+        r = _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat)
+        if r is not None:
+            return r
     f1 = conv3_fused(x, ldx, w1, w3, dims, prec)
     if f1 is not None:
         c1, s1, c3, s3 = f1
@@ -1303,6 +1390,31 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec, to_cat=False):
     return out, (c1, s1, a1, c2, s2, c3, s3)
 
 
+def _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat):
+    """the same block in FOUR launches: both convs leave their InstanceNorm sums as partial rows and the two apply kernels form
+    the statistics in their prologues (no finalize launches); None when a shape declines (the caller takes the route above)"""
+    B, D, H, W = dims
+    V = D * H * W
+    f1 = conv3_parts(x, ldx, w1, w3, dims, prec)
+    if f1 is None:
+        return None
+    c1, p1, c3, p3, rows1 = f1
+    r1 = instnorm_apply_fin(c1, p1, rows1, B, V, cout, True)
+    if r1 is None:
+        return None
+    a1, s1, _ = r1
+    f2 = conv3_parts(a1, cout, w2, None, dims, prec)
+    if f2 is None:
+        return None
+    c2, p2, _, _, rows2 = f2
+    half = skip_half(dims, cout, prec, x.device)[1] if to_cat else None
+    r2 = instnorm_apply_fin(c2, p2, rows2, B, V, cout, True, x2=c3, part_b=p3, rows_b=rows1, out=half, ldo=2 * cout if to_cat else None)
+    if r2 is None:
+        return None
+    out, s2, s3 = r2
+    return out, (c1, s1, a1, c2, s2, c3, s3)
+
+
 def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_dx):
     B, D, H, W = dims
     V = D * H * W
@@ -1314,8 +1426,16 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     dw3 = g3 if g3 is not None else torch.empty(cout, cin, 1, 1, 1, dtype=torch.float32, device=x.device)
     # conv2
     dw2 = conv3_wgrad(a1, cout, dc2, cout, dims, cout, cout, prec, out=_gout(w2))
-    da1 = conv3(dc2, cout, w2, dims, prec, mode=1)
-    dc1, _ = instnorm_bwd(da1, cout, c1, s1, B, V, cout, True)
+    dc1 = None
+    if in_fuse_level() & 2:
+        # the backward sums of the first norm come out of the data-gradient conv's epilogue: no reduction pass over (da1, c1)
+        f = conv3_dgrad_stats(dc2, w2, c1, s1, dims, prec)
+        if f is not None:
+            da1, bpart, brows = f
+            dc1 = instnorm_bwd_apply_fin(da1, cout, c1, s1, bpart, brows, 2, B, V, cout, True)
+    if dc1 is None:
+        da1 = conv3(dc2, cout, w2, dims, prec, mode=1)
+        dc1, _ = instnorm_bwd(da1, cout, c1, s1, B, V, cout, True)
     dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=_gout(w1), dy3=dc3, out3=dw3)
     dx = None
     if need_dx:

@@ -33,7 +33,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 8
+#define UNETR_ABI_VERSION 9
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -244,6 +244,20 @@ int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack, void* y, l
                           int B, int D, int H, int W, int Cin, int Cout, int prec,
                           int x_f32 /* bf16 mode: x is the fp32 image (<= 16 channels), not a bf16 feature map */,
                           float* ws, size_t ws_bytes, void* stream);
+/* The same launch without the statistics finalize: the InstanceNorm partial sums stay as rows part / part3 [B][rows][2][Cout]
+ * (caller-allocated for UNETR_CONV3_MAX_ROWS rows; *rows_out = the rows this launch wrote, one per workgroup) and are reduced by
+ * their consumer in its own prologue (unetr_instnorm_apply_fin) -- no finalize launch. */
+#define UNETR_CONV3_MAX_ROWS 1024
+int unetr_conv3_fwd_parts(const void* x, long ldx, const void* wpack, void* y, long ldy, float* part,
+                          const void* w3pack, void* y3, long ldy3, float* part3, int* rows_out,
+                          int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32, void* stream);
+/* Data gradient dx[.,Cin] = conv3x3x3^T(dy[.,Cout]; w) of a conv whose input was lrelu(InstanceNorm(xn)) (UnetResBlock.conv2,
+ * unetr.py:90-98 / :135-174 via MONAI), with the backward statistics of that norm formed in the epilogue: part [B][rows][2][Cin]
+ * = per-workgroup sums of g and g*n, g = dx * lrelu'(n), n = (xn - mean) * rstd from stats [B][Cin][2].  Replaces the separate
+ * reduction pass of unetr_instnorm_bwd over (dx, xn); consumed by unetr_instnorm_bwd_apply_fin(nsp = 2). */
+int unetr_conv3_dgrad_stats(const void* dy, long lddy, const void* wpack_dgrad, void* dx, long lddx,
+                            const void* xn, long ldxn, const float* stats, float* part, int* rows_out,
+                            int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream);
 size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec);
 int unetr_conv3_pack_1x1(const float* w3 /* [Cout,Cin] */, void* w3pack, int Cin, int Cout, int prec, void* stream);
 /* Data gradient of the residual block's input in one launch: dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3)
@@ -274,6 +288,17 @@ int unetr_instnorm_stats(const void* x, long ld, int B, long V, int C, float eps
 /* y = lrelu?(norm(x;sa) [+ norm(x2;sb)]) */
 int unetr_instnorm_apply(const void* x, long ldx, const float* sa, const void* x2, long ldx2, const float* sb,
                          void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream);
+/* unetr_instnorm_apply with the statistics finalize folded into the kernel's prologue: part_a / part_b = the partial rows
+ * [B][rows][2][C] of the conv launches that produced x / x2; stats_a / stats_b [B][C][2] are WRITTEN (for the backward kernels).
+ * "unsupported" for C > 128 or unaligned rows: the caller then runs unetr_instnorm_stats_finalize + unetr_instnorm_apply. */
+int unetr_instnorm_apply_fin(const void* x, long ldx, const float* part_a, int rows_a, const void* x2, long ldx2,
+                             const float* part_b, int rows_b, float* stats_a, float* stats_b, float eps,
+                             void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream);
+/* the apply half of unetr_instnorm_bwd reading partial sums part [B][nrows][nsp][C] (nsp 2: rows of unetr_conv3_dgrad_stats,
+ * single form only; nsp 3: the reduction pass's rows) and finalizing them in its prologue */
+int unetr_instnorm_bwd_apply_fin(const void* dy, long lddy, const void* x, long ldx, const float* sa,
+                                 const void* x2, long ldx2, const float* sb, const float* part, int nrows, int nsp,
+                                 void* dx, long lddx, void* dx2, long lddx2, int B, long V, int C, int lrelu, int act16, void* stream);
 /* backward of y = lrelu?(norm(x) [+ norm(x2)]): writes dx (and dx2). */
 int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const float* sa,
                        const void* x2, long ldx2, const float* sb, void* dx, long lddx, void* dx2, long lddx2,

@@ -914,3 +914,130 @@ def test_gemm_ln_fwd_fused_equals_three_steps(pkg, dev, M, N, K):
     mean, rstd = Fn.gemm_bf16_ln_fwd(A, W, M, N, K, c, gam, bet, yb, bias=bias, res=res, ldr=N)
     assert torch.equal(c, c_ref) and torch.equal(yb, yb_ref)
     assert torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+
+
+# ----------------------------------------------------------------------------- round 4: InstanceNorm work folded into its neighbours
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,dims3,cin,cout,with3", [(2, (8, 8, 16), 16, 16, True), (1, (9, 7, 19), 1, 16, True), (2, (6, 10, 20), 32, 16, True),
+                                                     (1, (12, 12, 12), 64, 32, True), (2, (4, 4, 16), 256, 128, True), (2, (20, 12, 40), 16, 16, False),
+                                                     (3, (16, 16, 32), 32, 64, True)])
+def test_instnorm_finalize_in_apply_prologue(pkg, dev, prec, B, dims3, cin, cout, with3):
+    """The statistics finalize folded into the apply kernel (unetr_conv3_fwd_parts + unetr_instnorm_apply_fin) == the separate
+    finalize launch (unetr_conv3_fwd_fused + unetr_instnorm_apply): same conv outputs bit for bit, statistics and the applied
+    tensor equal up to the summation order of the partial rows."""
+    Fn = pkg.functional
+    D, H, W = dims3
+    V = D * H * W
+    image = cin < 8
+    x = g(B, D, H, W, cin, seed=1) if image else rq(g(B, D, H, W, cin, seed=1), prec)
+    xd = x.to(dev) if image else act(x, prec, dev)
+    w, w3 = g(cout, cin, 3, 3, 3, seed=2, scale=0.2).to(dev), (g(cout, cin, 1, 1, 1, seed=3, scale=0.5).to(dev) if with3 else None)
+    c, st, c3, st3 = Fn.conv3_fused(xd, cin, w, w3, (B, D, H, W), prec)
+    r = Fn.conv3_parts(xd, cin, w, w3, (B, D, H, W), prec)
+    assert r is not None
+    c_p, part, c3_p, part3, rows = r
+    assert torch.equal(c, c_p) and (not with3 or torch.equal(c3, c3_p))
+    assert 0 < rows <= Fn.CONV3_MAX_ROWS
+    ref1 = Fn.instnorm_apply(c, st, B, V, cout, True)
+    got = Fn.instnorm_apply_fin(c_p, part, rows, B, V, cout, True)
+    assert got is not None
+    y, sa, _ = got
+    assert relerr(sa[..., 0], st[..., 0]) < 1e-5 + (st[..., 0].abs().max().item() < 1e-3) and relerr(sa[..., 1], st[..., 1]) < 1e-5
+    assert relerr(y, ref1) < (1e-5 if prec == 0 else 8e-3)
+    if with3:
+        ref2 = Fn.instnorm_apply(c, st, B, V, cout, True, x2=c3, sb=st3)
+        y2, sa2, sb2 = Fn.instnorm_apply_fin(c_p, part, rows, B, V, cout, True, x2=c3_p, part_b=part3, rows_b=rows)
+        assert relerr(sb2[..., 1], st3[..., 1]) < 1e-5 and torch.equal(sa2, sa)
+        assert relerr(y2, ref2) < (1e-5 if prec == 0 else 8e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,dims3,C,cout,max_wg", [(2, (8, 8, 16), 16, 16, 0), (1, (9, 7, 19), 16, 16, 0), (2, (6, 10, 20), 32, 32, 0), (1, (12, 12, 12), 64, 64, 0),
+                                                   (2, (4, 4, 16), 128, 128, 0), (3, (16, 16, 32), 16, 16, 8), (2, (20, 12, 40), 32, 32, 8)])
+def test_conv3_dgrad_with_backward_statistics(pkg, dev, monkeypatch, prec, B, dims3, C, cout, max_wg):
+    """Data-gradient conv with the InstanceNorm backward sums in its epilogue + the apply kernel that finalizes them in its
+    prologue == plain data-gradient conv + unetr_instnorm_bwd (reduction pass, finalize launch, apply pass), and both == autograd
+    of lrelu(instance_norm(c1)) fed through conv2.  max_wg > 0: few persistent workgroups, several batch items per workgroup
+    (the partial rows are flushed at batch boundaries)."""
+    Fn = pkg.functional
+    if max_wg:
+        monkeypatch.setenv("UNETR_TEST_MAX_WG", str(max_wg))
+    D, H, W = dims3
+    V = D * H * W
+    dims = (B, D, H, W)
+    c1 = rq(g(B, C, D, H, W, seed=1) * 1.3 + 0.2, prec)
+    w2 = g(cout, C, 3, 3, 3, seed=2, scale=0.2)
+    dc2 = rq(g(B, cout, D, H, W, seed=3), prec)
+    c1r = c1.clone().requires_grad_(True)
+    a1 = F.leaky_relu(F.instance_norm(c1r, eps=1e-5), 0.01)
+    F.conv3d(a1, w2, padding=1).backward(dc2)
+    c1d, dc2d, w2d = act(cl(c1), prec, dev), act(cl(dc2), prec, dev), w2.to(dev)
+    s1 = Fn.instnorm_stats(c1d, C, B, V, C)
+    # unfused
+    da1 = Fn.conv3(dc2d, cout, w2d, dims, prec, mode=1)
+    dc1_u, _ = Fn.instnorm_bwd(da1, C, c1d, s1, B, V, C, True)
+    # fused
+    f = Fn.conv3_dgrad_stats(dc2d, w2d, c1d, s1, dims, prec)
+    assert f is not None
+    da1_f, part, rows = f
+    assert torch.equal(da1_f, da1)
+    dc1_f = Fn.instnorm_bwd_apply_fin(da1_f, C, c1d, s1, part, rows, 2, B, V, C, True)
+    assert dc1_f is not None
+    tol = 3e-5 if prec == 0 else 2e-2
+    assert relerr(dc1_f, dc1_u) < (2e-5 if prec == 0 else 1e-2)          # (bf16: the fused sums see the fp32 accumulators, not their bf16 image)
+    assert relerr(ncdhw(dc1_f.float().cpu()), c1r.grad) < tol
+    assert relerr(ncdhw(dc1_u.float().cpu()), c1r.grad) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,S,C", [(2, 12, 16), (1, 20, 32), (2, 6, 128), (2, 24, 64)])
+def test_instnorm_bwd_folded_finalize(pkg, dev, monkeypatch, prec, B, S, C):
+    """unetr_instnorm_bwd with the finalize of its partial sums in the apply kernel's prologue (default) == with the separate
+    finalize launch (UNETR_IN_FIN=0), single and dual form"""
+    Fn = pkg.functional
+    V = S ** 3
+    x, x2, dy = rq(g(B, C, S, S, S, seed=1) * 1.5 + 0.3, prec), rq(g(B, C, S, S, S, seed=2) * 0.7 - 0.2, prec), rq(g(B, C, S, S, S, seed=3), prec)
+    xd, x2d, dyd = act(cl(x), prec, dev), act(cl(x2), prec, dev), act(cl(dy), prec, dev)
+    sa, sb = Fn.instnorm_stats(xd, C, B, V, C), Fn.instnorm_stats(x2d, C, B, V, C)
+    dx, dx2 = Fn.instnorm_bwd(dyd, C, xd, sa, B, V, C, True, x2=x2d, sb=sb)
+    dx1, _ = Fn.instnorm_bwd(dyd, C, xd, sa, B, V, C, True)
+    monkeypatch.setenv("UNETR_IN_FIN", "0")
+    dxu, dx2u = Fn.instnorm_bwd(dyd, C, xd, sa, B, V, C, True, x2=x2d, sb=sb)
+    dx1u, _ = Fn.instnorm_bwd(dyd, C, xd, sa, B, V, C, True)
+    t = 1e-5 if prec == 0 else 8e-3
+    assert relerr(dx, dxu) < t and relerr(dx2, dx2u) < t and relerr(dx1, dx1u) < t
+    xr, x2r = x.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    F.leaky_relu(F.instance_norm(xr, eps=1e-5) + F.instance_norm(x2r, eps=1e-5), 0.01).backward(dy)
+    t2 = 2e-5 if prec == 0 else 5e-3
+    assert relerr(ncdhw(dx.float().cpu()), xr.grad) < t2 and relerr(ncdhw(dx2.float().cpu()), x2r.grad) < t2
+    xr1 = x.clone().requires_grad_(True)
+    F.leaky_relu(F.instance_norm(xr1, eps=1e-5), 0.01).backward(dy)
+    assert relerr(ncdhw(dx1.float().cpu()), xr1.grad) < t2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 16), 32, 16), (1, (12, 12, 12), 64, 32), (2, (6, 6, 6), 256, 128), (2, (16, 16, 16), 1, 16)])
+def test_resblock_in_fusion_levels(pkg, dev, monkeypatch, prec, B, dims3, cin, cout):
+    """MONAI UnetResBlock forward + backward with the InstanceNorm work folded into its neighbours (UNETR_AMD_IN_FUSE=3)
+    against the round-3 launch sequence (=0): outputs and all four gradients agree to rounding"""
+    Fn = pkg.functional
+    D, H, W = dims3
+    image = cin < 8
+    x0 = g(B, D, H, W, cin, seed=1) if image else rq(g(B, D, H, W, cin, seed=1), prec)
+    w = [g(cout, cin, 3, 3, 3, seed=2, scale=0.2), g(cout, cout, 3, 3, 3, seed=3, scale=0.2), g(cout, cin, 1, 1, 1, seed=4, scale=0.5)]
+    dout = act(rq(g(B, D, H, W, cout, seed=5), prec), prec, dev)
+    res = {}
+    for level in ("0", "3"):
+        monkeypatch.setenv("UNETR_AMD_IN_FUSE", level)
+        xd = (x0.to(dev) if image else act(x0, prec, dev)).requires_grad_(not image)
+        ws = [t.to(dev).requires_grad_(True) for t in w]
+        out = Fn.ResBlockFn.apply(xd, ws[0], ws[1], ws[2], prec)
+        out.backward(dout)
+        res[level] = [out.detach().float()] + [t.grad.float() for t in ws] + ([] if image else [xd.grad.float()])
+    tol = 2e-4 if prec == 0 else 3e-2
+    for a, b in zip(res["0"], res["3"]):
+        assert relerr(a, b) < tol
