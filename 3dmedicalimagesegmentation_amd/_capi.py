@@ -8,10 +8,12 @@ import os
 from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunetr_hip.so")
+# UNETR_AMD_LIB: an alternative build of the same ABI (diagnostic builds such as `make x3droplo`); the product loads libunetr_hip.so
+LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
+PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
 ABI_VERSION = 9        # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",

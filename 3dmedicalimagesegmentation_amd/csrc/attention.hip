@@ -102,16 +102,17 @@ __device__ __forceinline__ void prod_T(AccArr<P, DH>& out, f32x4 x0, f32x4 x1, c
     if constexpr (!C::BF) {
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
+            // (4-byte image elements -- fp32 or split words --: four element reads per operand chunk; PrecF32::mma is the four
+            // K = 4 MFMAs of before)
+            u32x4 a0, a1;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float a0 = *(const float*)(img_c + (4 * g + t) * C::PC + (dt * 16 + c) * 4);
-                out[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x0[t], out[dt], 0, 0, 0);
+                a0[t] = *(const uint32_t*)(img_c + (4 * g + t) * C::PC + (dt * 16 + c) * 4);
+                a1[t] = *(const uint32_t*)(img_c + (16 + 4 * g + t) * C::PC + (dt * 16 + c) * 4);
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float a1 = *(const float*)(img_c + (16 + 4 * g + t) * C::PC + (dt * 16 + c) * 4);
-                out[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x1[t], out[dt], 0, 0, 0);
-            }
+            const float xa[4] = {x0[0], x0[1], x0[2], x0[3]}, xb[4] = {x1[0], x1[1], x1[2], x1[3]};
+            P::mma(out[dt], a0, P::pack(xa));
+            P::mma(out[dt], a1, P::pack(xb));
         }
     } else {
         float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
@@ -427,6 +428,10 @@ int launch_bwd(const float* qkv, const float* out, const float* dout, const floa
         if (dh == 32) return CALL(PrecBF16, 32);                                              \
         if (dh == 64) return CALL(PrecBF16, 64);                                              \
         if (dh == 128) return CALL(PrecBF16, 128);                                            \
+    } else if (prec == UNETR_PREC_BF16X3) {                                                   \
+        if (dh == 32) return CALL(PrecBF16x3, 32);                                            \
+        if (dh == 64) return CALL(PrecBF16x3, 64);                                            \
+        if (dh == 128) return CALL(PrecBF16x3, 128);                                          \
     }                                                                                         \
     return UNETR_ERR_UNSUPPORTED;
 

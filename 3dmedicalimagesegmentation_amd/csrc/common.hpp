@@ -5,6 +5,7 @@
 //   PrecF32  : chunk = 4 x f32, contraction on v_mfma_f32_16x16x4_f32  (bit-exact fp32 fma chains;
 //              the parity mode that must hold 1e-3 against the CPU oracle)
 //   PrecBF16 : chunk = 8 x bf16, contraction on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; perf mode)
+//   PrecBF16x3: fp32 storage, operands split into bf16 (hi, lo) pairs, two bf16 MFMAs per chunk pair (below)
 // In both modes a "k-block" is 4 chunks (64 bytes) per row: lane group g = lane>>4 owns chunk g, and the
 // A and B operands use the same lane->k map, so any k permutation inside a k-block cancels out.
 #pragma once
@@ -26,6 +27,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define UNETR_PREC_F32 0
 #define UNETR_PREC_BF16 1
+#define UNETR_PREC_BF16X3 2
 
 static inline int unetr_check_launch() {
     hipError_t e = hipGetLastError();
@@ -39,6 +41,8 @@ struct PrecF32 {
         return __builtin_bit_cast(u32x4, t);
     }
     // acc(16x16) += A(16 x 16k) * B(16k x 16): lane group g holds k = 4g+t in element t
+    // 16 bytes as they sit in a tensor of this mode's storage type -> operand chunk
+    static __device__ __forceinline__ u32x4 from_raw(u32x4 r) { return r; }
     static __device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
         f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
@@ -55,10 +59,56 @@ struct PrecBF16 {
         bf16x8 b = __builtin_convertvector(t, bf16x8);
         return __builtin_bit_cast(u32x4, b);
     }
+    static __device__ __forceinline__ u32x4 from_raw(u32x4 r) { return r; }
     static __device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                       acc, 0, 0, 0);
     }
+};
+
+// PrecBF16x3 : the tolerance-grade mode that is not bound by the fp32 matrix rate.  fp32 STORAGE everywhere (as PrecF32); an
+//   operand element a travels as ONE 32-bit word [hi | lo << 16] with hi = bf16(a), lo = bf16(a - hi) (a = hi + lo to 2^-17
+//   relative), so every loader, LDS layout and transposing read of the fp32 instantiation moves it unchanged (CH = 4 words per
+//   16-byte chunk).  The contraction runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the 8 bf16 slots a lane group
+//   feeds are its 4 words' (hi, lo) pairs, so MFMA([a_hi, a_hi], [b_hi, b_lo]) + MFMA([a_lo, a_lo], [b_hi, b_lo]) adds
+//   a_hi b_hi + a_hi b_lo + a_lo b_hi + a_lo b_lo per element -- the three products of the classic bf16x3 split plus the lo-lo
+//   term, which the slot layout gives for free.  Two 16-cycle MFMAs per 16 contraction elements against four 32-cycle fp32 MFMAs:
+//   a quarter of the bf16 rate, four times the fp32 rate; products carry ~16 mantissa bits.
+struct PrecBF16x3 {
+    static constexpr int CH = 4;
+    static __device__ __forceinline__ uint32_t split(float a) {
+        const __bf16 h = (__bf16)a;
+#ifdef UNETR_X3_DROP_LO
+        // diagnostic build only (make x3droplo; tools/decompose_bf16_error.py): the lo halves are zero, i.e. bf16 x 1 operands with
+        // fp32 storage and fp32 accumulation -- what separates "bf16 operands" from "bf16 storage" in the error of the bf16 mode
+        return (uint32_t)__builtin_bit_cast(uint16_t, h);
+#endif
+        const __bf16 l = (__bf16)(a - (float)h);
+        return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* v) { return (u32x4){split(v[0]), split(v[1]), split(v[2]), split(v[3])}; }
+    static __device__ __forceinline__ u32x4 from_raw(u32x4 r) {
+        const f32x4 f = __builtin_bit_cast(f32x4, r);
+        return (u32x4){split(f[0]), split(f[1]), split(f[2]), split(f[3])};
+    }
+    static __device__ __forceinline__ void mma(f32x4& acc, u32x4 a, u32x4 b) {
+        u32x4 ah, al;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ah[e] = __builtin_amdgcn_perm(a[e], a[e], 0x01000100u);      // [hi, hi]
+            al[e] = __builtin_amdgcn_perm(a[e], a[e], 0x03020302u);      // [lo, lo]
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+// one contraction element per lane (the K = 4 shape of v_mfma_f32_16x16x4_f32: lane group g supplies element g): kernels that
+// feed the fp32 MFMA element by element collect FOUR steps into one chunk for the policies whose MFMA wants a whole chunk
+template <class P> struct ElemMma {
+    static constexpr bool PER_ELEMENT = false;
+};
+template <> struct ElemMma<PrecF32> {
+    static constexpr bool PER_ELEMENT = true;
 };
 
 // XOR-swizzled LDS tile of 128-byte rows (8 chunks): conflict-free for the 16x16 fragment read
@@ -186,7 +236,7 @@ template <> struct ActOf<PrecBF16> { typedef uint16_t type; };
 template <class P>
 __device__ __forceinline__ u32x4 act_chunk(const typename ActOf<P>::type* p, bool ok) {
     const u32x4 w = *(const u32x4*)p;
-    return ok ? w : (u32x4){0u, 0u, 0u, 0u};
+    return ok ? P::from_raw(w) : (u32x4){0u, 0u, 0u, 0u};
 }
 // LayerNorm backward whose dy arrives as split-K partial slabs (norm_misc.hip; used by unetr_gemm_bf16_ln_bwd in gemm_bf16.hip)
 int unetr_layernorm_bwd_partials(const float* dy, int splits, long slab, const float* x, const float* gamma, const float* mean,

@@ -59,6 +59,7 @@ __device__ __forceinline__ int lay_off(int hv, int ch, int pitch) {
 template <class P> struct ElemOf;
 template <> struct ElemOf<PrecF32> { typedef float type; };
 template <> struct ElemOf<PrecBF16> { typedef uint16_t type; };
+template <> struct ElemOf<PrecBF16x3> { typedef uint32_t type; };      // packed weights: one split word [hi | lo << 16] per element
 
 __device__ __forceinline__ uint16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
@@ -67,6 +68,7 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 template <class T> __device__ __forceinline__ T cvt_elem(float f);
 template <> __device__ __forceinline__ float cvt_elem<float>(float f) { return f; }
 template <> __device__ __forceinline__ uint16_t cvt_elem<uint16_t>(float f) { return f2bf(f); }
+template <> __device__ __forceinline__ uint32_t cvt_elem<uint32_t>(float f) { return PrecBF16x3::split(f); }
 
 // ------------------------------------------------------------------------------------- weight packing
 // fwd  (mode 0): wp[tap][slab][n = co][k = ci % SL]           source w[co][ci][tap]
@@ -1194,7 +1196,7 @@ __global__ void conv3_pack_1x1_kernel(const float* __restrict__ w3, T* __restric
         const int kk = (int)(i % RW); const long t = i / RW; const int n = (int)(t % Cout), slab = (int)(t / Cout);
         const int ci = pair ? kk - 16 : slab * SL + kk;
         const float v = (ci >= 0 && ci < Cin) ? (transposed ? w3[(long)ci * Cout + n] : w3[(long)n * Cin + ci]) : 0.f;
-        if constexpr (sizeof(T) == 2) wp3[i] = f2bf(v); else wp3[i] = v;
+        wp3[i] = cvt_elem<T>(v);
     }
 }
 
@@ -1540,25 +1542,25 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
                     }
                 }
             } else {
-                // f32: k-block = 16 voxels; lane (c, g) holds voxels 4g+t for channel c
-                float av[4], av3[4];
+                // 4-byte elements (fp32, or the split words of PrecBF16x3): k-block = 16 voxels; lane (c, g) holds voxels 4g+t for
+                // channel c -- four element reads form one operand chunk (PrecF32::mma is exactly the four K = 4 MFMAs)
+                u32x4 av, av3 = {0u, 0u, 0u, 0u};
                 int hb[4];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     int v = kb * 16 + 4 * g + tt;
-                    av[tt] = *(const float*)(yimg + v * C::PY + c * 4);
-                    av3[tt] = HAS3 ? *(const float*)(y3img + v * C::PY + c * 4) : 0.f;
+                    av[tt] = *(const uint32_t*)(yimg + v * C::PY + c * 4);
+                    if constexpr (HAS3) av3[tt] = *(const uint32_t*)(y3img + v * C::PY + c * 4);
                     hb[tt] = (((v >> 6) * HY + ((v >> 4) & 3)) * HX + (v & 15)) * C::PX + c * 4;
                 }
 #pragma unroll
                 for (int ui = 0; ui < WG_UPW; ++ui) {
                     if (wv + 4 * ui < nunits) {
                         const bool ext = (ui == WG_UPW - 1 && wv + 4 * ui >= WG_UNITS);
+                        u32x4 bv;
 #pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) {
-                            float bv = *(const float*)(ximg + hb[tt] + uoff[ui]);
-                            acc[0][ui] = __builtin_amdgcn_mfma_f32_16x16x4f32(ext ? av3[tt] : av[tt], bv, acc[0][ui], 0, 0, 0);
-                        }
+                        for (int tt = 0; tt < 4; ++tt) bv[tt] = *(const uint32_t*)(ximg + hb[tt] + uoff[ui]);
+                        P::mma(acc[0][ui], ext ? av3 : av, bv);
                     }
                 }
             }
@@ -2100,6 +2102,7 @@ extern "C" int unetr_conv3_pack_weight(const float* w, void* wpack, int Cin, int
     if (!w || !wpack || Cin <= 0 || Cout <= 0) return UNETR_ERR_ARG;
     if (prec == UNETR_PREC_BF16) return pack_t<PrecBF16>(w, wpack, Cin, Cout, mode, (hipStream_t)stream);
     if (prec == UNETR_PREC_F32) return pack_t<PrecF32>(w, wpack, Cin, Cout, mode, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16X3) return pack_t<PrecBF16x3>(w, wpack, Cin, Cout, mode, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 
@@ -2109,6 +2112,7 @@ extern "C" int unetr_conv3_fwd(const void* x, long ldx, const void* wpack, void*
     if (Cout % 16) return UNETR_ERR_UNSUPPORTED;
     if (prec == UNETR_PREC_BF16) return fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, accumulate, B, D, H, W, Cin, Cout, (hipStream_t)stream);
     if (prec == UNETR_PREC_F32) return fwd_t<PrecF32>(x, ldx, wpack, y, ldy, accumulate, B, D, H, W, Cin, Cout, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16X3) return fwd_t<PrecBF16x3>(x, ldx, wpack, y, ldy, accumulate, B, D, H, W, Cin, Cout, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 
@@ -2129,6 +2133,7 @@ extern "C" int unetr_conv3_fwd_fused(const void* x, long ldx, const void* wpack,
     int rc;
     if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz, x_f32);
     else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
+    else if (prec == UNETR_PREC_BF16X3) rc = fwd_t<PrecBF16x3>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
     else return UNETR_ERR_ARG;
     if (rc) return rc;
     const long V = (long)D * H * W;
@@ -2150,6 +2155,7 @@ extern "C" int unetr_conv3_fwd_parts(const void* x, long ldx, const void* wpack,
     int rc;
     if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz, x_f32);
     else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
+    else if (prec == UNETR_PREC_BF16X3) rc = fwd_t<PrecBF16x3>(x, ldx, wpack, y, ldy, 0, B, D, H, W, Cin, Cout, st, &fz);
     else return UNETR_ERR_ARG;
     if (rc) return rc;
     if (fz.rows <= 0 || fz.rows > UNETR_CONV3_MAX_ROWS) return UNETR_ERR_WORKSPACE;
@@ -2174,6 +2180,7 @@ extern "C" int unetr_conv3_dgrad_stats(const void* dy, long lddy, const void* wp
     // the data gradient is the forward kernel with contraction over the conv's Cout channels and Cin outputs
     if (prec == UNETR_PREC_BF16) rc = fwd_t<PrecBF16>(dy, lddy, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
     else if (prec == UNETR_PREC_F32) rc = fwd_t<PrecF32>(dy, lddy, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
+    else if (prec == UNETR_PREC_BF16X3) rc = fwd_t<PrecBF16x3>(dy, lddy, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
     else return UNETR_ERR_ARG;
     if (rc) return rc;
     if (fz.rows <= 0 || fz.rows > UNETR_CONV3_MAX_ROWS) return UNETR_ERR_WORKSPACE;
@@ -2187,7 +2194,7 @@ extern "C" size_t unetr_conv3_packed_1x1_bytes(int Cin, int Cout, int prec) {
 }
 
 extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, int prec, void* stream) {
-    if (!probs || n <= 0 || (prec != UNETR_PREC_BF16 && prec != UNETR_PREC_F32)) return UNETR_ERR_ARG;
+    if (!probs || n <= 0 || (prec != UNETR_PREC_BF16 && prec != UNETR_PREC_F32 && prec != UNETR_PREC_BF16X3)) return UNETR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int SL = prec == UNETR_PREC_BF16 ? 32 : 16;
     for (int base = 0; base < n; base += PK_MAX) {
@@ -2216,6 +2223,7 @@ extern "C" int unetr_conv3_pack_grouped(const unetr_pack_problem* probs, int n, 
             blocks += staged ? ((K + SL - 1) / SL) * cdiv(N, 8) : cdiv(total, 2048);
         }
         if (prec == UNETR_PREC_BF16) hipLaunchKernelGGL((conv3_pack_grouped_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, a, SL);
+        else if (prec == UNETR_PREC_BF16X3) hipLaunchKernelGGL((conv3_pack_grouped_kernel<uint32_t>), dim3(blocks), dim3(256), 0, st, a, SL);
         else hipLaunchKernelGGL((conv3_pack_grouped_kernel<float>), dim3(blocks), dim3(256), 0, st, a, SL);
     }
     return unetr_check_launch();
@@ -2227,6 +2235,9 @@ static int pack_1x1(const float* w3, void* w3pack, int K, int N, int prec, int a
         const int pair = (allow_pair && use_pair<PrecBF16>(K) && conv_pipe_enabled()) ? 1 : 0;
         hipLaunchKernelGGL((conv3_pack_1x1_kernel<uint16_t>), dim3(cdiv((long)((K + 31) / 32) * N * 32, 256)), dim3(256), 0, st, w3,
                            (uint16_t*)w3pack, K, N, pair, 32, transposed);
+    } else if (prec == UNETR_PREC_BF16X3) {
+        hipLaunchKernelGGL((conv3_pack_1x1_kernel<uint32_t>), dim3(cdiv((long)((K + 15) / 16) * N * 16, 256)), dim3(256), 0, st, w3,
+                           (uint32_t*)w3pack, K, N, 0, 16, transposed);
     } else if (prec == UNETR_PREC_F32) {
         hipLaunchKernelGGL((conv3_pack_1x1_kernel<float>), dim3(cdiv((long)((K + 15) / 16) * N * 16, 256)), dim3(256), 0, st, w3,
                            (float*)w3pack, K, N, 0, 16, transposed);
@@ -2259,6 +2270,7 @@ extern "C" int unetr_conv3_dgrad_fused(const void* dc1, long ld1, const void* wp
     // the data gradient is the same kernel with contraction over the block's Cout channels and Cin outputs
     if (prec == UNETR_PREC_BF16) return fwd_t<PrecBF16>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
     if (prec == UNETR_PREC_F32) return fwd_t<PrecF32>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
+    if (prec == UNETR_PREC_BF16X3) return fwd_t<PrecBF16x3>(dc1, ld1, wpack_dgrad, dx, lddx, 0, B, D, H, W, Cout, Cin, st, &fz);
     return UNETR_ERR_ARG;
 }
 
@@ -2269,6 +2281,7 @@ extern "C" int unetr_conv3_wgrad(const void* x, long ldx, const void* dy, long l
     if (!x || !dy || !dw || B <= 0 || ((dy3 != nullptr) != (dw3 != nullptr))) return UNETR_ERR_ARG;
     if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, x_f32);
     if (prec == UNETR_PREC_F32) return wgrad_t<PrecF32>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16X3) return wgrad_t<PrecBF16x3>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 

@@ -493,6 +493,7 @@ template <class AL, class BL, class EP>
 int launch_prec(int prec, int M, int N, int K, int batch, AL al, BL bl, EP ep, float* ws, size_t ws_bytes, hipStream_t st) {
     if (prec == UNETR_PREC_BF16) return launch_gemm<PrecBF16>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
     if (prec == UNETR_PREC_F32) return launch_gemm<PrecF32>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
+    if (prec == UNETR_PREC_BF16X3) return launch_gemm<PrecBF16x3>(M, N, K, batch, al, bl, ep, ws, ws_bytes, st);
     return UNETR_ERR_ARG;
 }
 

@@ -58,6 +58,8 @@ extern "C" int unetr_gemm_grouped_wgrad(const unetr_grouped_problem* probs, int 
             hipLaunchKernelGGL((gemm_grouped_wgrad_kernel<PrecBF16, 4, 4, 2, 2>), dim3(tiles), dim3(256), 0, st, ga);
         else if (prec == UNETR_PREC_F32)
             hipLaunchKernelGGL((gemm_grouped_wgrad_kernel<PrecF32, 4, 4, 2, 2>), dim3(tiles), dim3(256), 0, st, ga);
+        else if (prec == UNETR_PREC_BF16X3)
+            hipLaunchKernelGGL((gemm_grouped_wgrad_kernel<PrecBF16x3, 4, 4, 2, 2>), dim3(tiles), dim3(256), 0, st, ga);
         else
             return UNETR_ERR_ARG;
     }

@@ -30,6 +30,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <class P> struct Elem;
 template <> struct Elem<PrecF32> { typedef float type; };
 template <> struct Elem<PrecBF16> { typedef uint16_t type; };
+template <> struct Elem<PrecBF16x3> { typedef float type; };
 
 constexpr int TV = 64;   // input voxels per tile
 
@@ -137,19 +138,20 @@ tconv2_wgrad_kernel(const typename Elem<P>::type* __restrict__ x, long ldx, cons
         } else {
 #pragma unroll 2
             for (int kb = 0; kb < TV / 16; ++kb) {
+                // 4-byte elements (fp32 / split words): four element reads per operand chunk (PrecF32::mma = the four K = 4 MFMAs)
+                u32x4 av[RT], bv[CTW];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int v = kb * 16 + 4 * g + tt;
-                    float av[RT], bv[CTW];
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) av[i] = *(const float*)(ximg + v * PXI + (i * 16 + c) * 4);
+                    for (int i = 0; i < RT; ++i) av[i][tt] = *(const uint32_t*)(ximg + v * PXI + (i * 16 + c) * 4);
 #pragma unroll
-                    for (int j = 0; j < CTW; ++j) bv[j] = *(const float*)(yimg + v * PYI + ((wv * CTW + j) * 16 + c) * 4);
-#pragma unroll
-                    for (int i = 0; i < RT; ++i)
-#pragma unroll
-                        for (int j = 0; j < CTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < CTW; ++j) bv[j][tt] = *(const uint32_t*)(yimg + v * PYI + ((wv * CTW + j) * 16 + c) * 4);
                 }
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CTW; ++j) P::mma(acc[i][j], av[i], bv[j]);
             }
         }
     }
@@ -469,6 +471,7 @@ extern "C" int unetr_tconv2_wgrad(const void* x, long ldx, const void* dy, long 
         return wgrad2<PrecBF16>((const uint16_t*)x, ldx, (const uint16_t*)dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     }
     if (prec == UNETR_PREC_F32) return wgrad2<PrecF32>((const float*)x, ldx, (const float*)dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16X3) return wgrad2<PrecBF16x3>((const float*)x, ldx, (const float*)dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 
@@ -482,6 +485,7 @@ extern "C" int unetr_tconv2_fwd(const void* x, long ldx, const float* w, void* y
         return fwd2<PrecBF16>((const uint16_t*)x, ldx, w, (uint16_t*)y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     }
     if (prec == UNETR_PREC_F32) return fwd2<PrecF32>((const float*)x, ldx, w, (float*)y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16X3) return fwd2<PrecBF16x3>((const float*)x, ldx, w, (float*)y, ldy, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 
@@ -497,6 +501,7 @@ extern "C" int unetr_tconv2_dgrad(const void* dy, long lddy, const float* w, voi
         return dgrad2<PrecBF16>((const uint16_t*)dy, lddy, w, (uint16_t*)dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     }
     if (prec == UNETR_PREC_F32) return dgrad2<PrecF32>((const float*)dy, lddy, w, (float*)dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    if (prec == UNETR_PREC_BF16X3) return dgrad2<PrecBF16x3>((const float*)dy, lddy, w, (float*)dx, ldx, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     return UNETR_ERR_ARG;
 }
 

@@ -33,7 +33,7 @@ except ImportError:
     _pkg = importlib.import_module(os.path.basename(_here))
     _capi, Fn = _pkg._capi, _pkg.functional
 
-_PRECISIONS = {"fp32": _capi.PREC_F32, "bf16": _capi.PREC_BF16}
+_PRECISIONS = {"fp32": _capi.PREC_F32, "bf16": _capi.PREC_BF16, "bf16x3": _capi.PREC_BF16X3}
 
 
 def default_precision() -> str:

@@ -46,7 +46,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="volumes per GPU (default 2; c4: 1; c5: 4)")
     ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
     ap.add_argument("--no-flat", action="store_true", help="per-tensor grads/AdamW instead of the flat arenas (N=1 only)")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (staged backward + per-pass all-reduce slots) on one rank")
@@ -63,6 +63,7 @@ def parse(argv=None):
                     "370 MB per step, more than the backward passes it has to hide under -- DESIGN.md section 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 (tolerance-grade) leg reported as parity_mode")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-oracle steps (after 3 warm-up steps; SURVEY 8d)")
     ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=5, help="timed windows of exactly --steps steps each; the reported ms_per_step / value are "
@@ -295,6 +296,12 @@ def run_supervised(args, pkg, dev, rank, world, dist, ddp_on, synthetic_volume):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, cfg, batch, first_loss)
         log("cpu baseline done")
+    if rank == 0 and world == 1 and args.config == "c2" and args.precision == "bf16" and not args.no_parity_mode and not args.no_roofline:
+        try:
+            out["parity_mode"] = parity_mode(args, pkg, dev, cfg, batch, synthetic_volume)
+        except Exception as e:  # noqa: BLE001
+            out["parity_mode"] = {"error": f"{type(e).__name__}: {e}"}
+        log("parity mode done")
     return out
 
 
@@ -405,6 +412,52 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
                        "graph_capture_error": graph_err}}
 
 
+_CPU_REF = {}
+
+
+def parity_mode(args, pkg, dev, cfg, batch, synthetic_volume):
+    """The tolerance-grade mode next to the bf16 headline: the same step in bf16x3 mode (fp32 storage, operands split into bf16
+    hi/lo pairs inside the kernels, fp32 accumulation) -- its ms/step, and the relative error of the logits at the initial
+    weights (seed 1234, same volumes) against the CPU oracle's, for this mode and for the benched bf16 mode (north_star: 1e-3)."""
+    import torch
+    x, y = synthetic_volume(batch, 1, cfg["img_size"][0], 4, seed=1234)
+    x, y = x.to(dev), y.to(dev)
+    ref = _CPU_REF.get("logits0")
+    errs = {}
+    for mode in ("bf16x3", args.precision):
+        torch.manual_seed(1234)
+        m = pkg.UNETRLogits(**cfg).to(dev)
+        m.precision = mode
+        with torch.no_grad():
+            lg = m(x)
+        if ref is not None:
+            errs[mode] = float(((lg.float().cpu() - ref).abs().max() / ref.abs().max()).item())
+        del m, lg
+    torch.manual_seed(1234)
+    model = pkg.UNETRLogits(**cfg).to(dev)
+    model.precision = "bf16x3"
+    flat = model.use_flat_buffers()
+    opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
+    step = pkg.TrainStep(model, pkg.DiceCELoss(to_onehot_y=True, softmax=True), opt, x, y, use_graph=not args.no_graph, fuse_update=False)
+    first = float(step.first_loss.item())
+    for _ in range(3):
+        step.run()
+    torch.cuda.synchronize()
+    wins = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step.run()
+        torch.cuda.synchronize()
+        wins.append((time.perf_counter() - t0) / 10 * 1e3)
+    pkg.functional.clear_grad_sinks(flat["state"])
+    return {"mode": "bf16x3", "dtype": "fp32 storage, bf16 (hi, lo) split operands, fp32 accumulate", "ms_per_step": round(sorted(wins)[1], 4),
+            "volumes_per_s": round(batch / (sorted(wins)[1] * 1e-3), 2), "first_step_loss": first, "tolerance": 1e-3,
+            "logits_rel_err_vs_cpu_oracle": errs.get("bf16x3"),
+            "bench_mode_logits_rel_err_vs_cpu_oracle": errs.get(args.precision),
+            "note": "logits at the initial weights, max |diff| / max |ref| against the CPU oracle (null without the cpu_baseline leg)"}
+
+
 def cpu_baseline(args, cfg, batch, gpu_first_loss):
     """The CPU oracle (plain PyTorch fp32, the reference's operator graph) on this host's cores: 1 warm-up + --cpu-steps
     timed steps at the bench batch.  Its first-step loss (same seed-1234 weights and data as the GPU run) is reported next
@@ -427,6 +480,9 @@ def cpu_baseline(args, cfg, batch, gpu_first_loss):
     else:
         steps, warm = args.cpu_steps, max(1, args.cpu_warmup)
     x, y = synthetic_volume(batch, 1, size, 4, seed=1234)
+    if size <= 96:
+        with torch.no_grad():                       # logits at the initial weights: what parity_mode() holds the GPU modes to
+            _CPU_REF["logits0"] = ref(x)[1].clone()
     l0 = float(oracle_train_step(ref, opt, x, y))  # first warm-up step; also the first-step loss
     t1 = time.perf_counter()
     for _ in range(warm - 1):

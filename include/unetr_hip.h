@@ -11,7 +11,9 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no host synchronisation;
  *   - return value 0 = ok, non-zero = UNETR_ERR_* (the Python shim raises RuntimeError);
  *   - `prec`: 0 = fp32 (v_mfma_f32_16x16x4_f32, bit-exact fp32 fma chains), 1 = bf16 operands with fp32
- *     accumulation (v_mfma_f32_16x16x32_bf16);
+ *     accumulation (v_mfma_f32_16x16x32_bf16), 2 = "bf16x3": fp32 storage like prec 0, every operand element split into a
+ *     bf16 (hi, lo) pair inside the kernels and contracted with two bf16 MFMAs per chunk pair (hi*hi + hi*lo + lo*hi + lo*lo,
+ *     fp32 accumulation): ~16-bit products at four times the fp32 matrix rate -- the tolerance-grade mode (1e-3 on logits);
  *   - ACTIVATION STORAGE: on the conv side (3x3x3 / 1x1x1 / transposed convs, InstanceNorm, concat copies, out conv)
  *     every feature map and feature-map gradient is stored in the precision mode's activation type: fp32 with prec 0,
  *     **bf16 with prec 1** (half the HBM bytes of passes that are bandwidth-bound; statistics, weights, partial sums,

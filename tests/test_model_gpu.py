@@ -71,6 +71,23 @@ def test_c1_fp32_parity(pkg, dev):
         assert (p.grad is None) == (gh[k].grad is None), k
 
 
+def test_c1_bf16x3_parity(pkg, dev):
+    """the second tolerance-grade mode (bf16x3: fp32 storage, operands split into bf16 hi/lo pairs, fp32 accumulation) at config[0]
+    against the fp64 oracle: 1e-3 on logits / enc4 / Dice / CE (measured 2e-5 / 7e-6 / 2e-7 / 5e-7).  Gradients: this geometry
+    normalises over 2^3 voxels at its bottleneck, which amplifies the ~2^-17 product error of the split by ~1e3 on everything
+    upstream of it (measured 1-2e-2 element-wise where the fp32 mode has ~1e-3), so they are held by direction and a looser
+    element bound; the full-size geometry (12^3 voxels at the bottleneck) holds cosine 0.9999 (test_c2_full_size_fp32_parity)."""
+    outs, gr, gh = _run(pkg, dev, C1, 2, "bf16x3")
+    errs = {k: relerr(a, b) for k, (a, b) in outs.items()}
+    print(errs)
+    for k, e in errs.items():
+        assert e < 1e-3, (k, e)
+    gerr = {k: (relerr(gh[k].grad, gr[k].grad), cosine(gh[k].grad, gr[k].grad)) for k in GRAD_KEYS}
+    print(gerr)
+    for k, (e, c) in gerr.items():
+        assert e < 5e-2 and c > 0.9995, (k, e, c)
+
+
 def test_c1_bf16_bounded(pkg, dev):
     outs, gr, gh = _run(pkg, dev, C1, 1, "bf16")
     for k, (a, b) in outs.items():
@@ -283,12 +300,14 @@ C2 = dict(in_channels=1, out_channels=4, img_size=(96, 96, 96), feature_size=16,
           num_heads=12, pos_embed="perceptron", norm_name="instance", res_block=True)
 
 
-def test_c2_full_size_fp32_parity(pkg, dev):
-    """BASELINE config[1] geometry (96^3, hidden 768, 12 heads, 4 classes) at batch 1, fp32 mode, against the fp32 CPU
-    oracle: logits / enc4 / Dice / CE within north_star's 1e-3; gradients by cosine (the fp32 oracle is itself noisy)."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_c2_full_size_fp32_parity(pkg, dev, precision):
+    """BASELINE config[1] geometry (96^3, hidden 768, 12 heads, 4 classes) at batch 1 against the fp32 CPU oracle: logits / enc4 /
+    Dice / CE within north_star's 1e-3; gradients by cosine (the fp32 oracle is itself noisy).  Both tolerance-grade modes: fp32
+    (exact fp32 MFMA chains) and bf16x3 (fp32 storage, split bf16 operands: ~16-bit products at four times the fp32 matrix rate)."""
     from oracle.unetr_oracle import oracle_dice_ce_terms, synthetic_volume
     ref, hip = _pair(pkg, dev, C2, ref_dtype=torch.float32)
-    hip.precision = "fp32"
+    hip.precision = precision
     x, y = synthetic_volume(1, 1, 96, 4, seed=11)
     enc4_r, logits_r = ref(x)
     d_r, c_r = oracle_dice_ce_terms(logits_r, y)

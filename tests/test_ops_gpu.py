@@ -26,7 +26,7 @@ def act(t, prec, dev):
     return t.to(dev).bfloat16() if prec == 1 else t.to(dev)
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(432, 768, 768), (37, 50, 44), (432, 2304, 768), (8, 128, 4096), (1000, 16, 32), (300, 32, 256),
                                    (4096, 128, 64), (16, 300, 5000), (16, 16, 70000), (16, 40, 3000), (24, 200, 2000)])
 def test_gemm_nt_nn_tn(pkg, dev, prec, M, N, K):
@@ -236,7 +236,7 @@ def test_gemm_bf16_epilogues(pkg, dev):
     assert torch.equal(Fn.cast_bf16(odd.to(dev)).cpu(), odd.bfloat16())
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 def test_gemm_epilogues(pkg, dev, prec):
     Fn = pkg.functional
     M, N, K, L = 432, 512, 256, 216
@@ -286,7 +286,7 @@ def _attn_ref(qkv, B, L, heads, dh):
     return torch.einsum("bhxy,bhyd->bhxd", att, v).permute(0, 2, 1, 3).reshape(B * L, hd)
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,L,heads,dh", [(2, 216, 12, 64), (1, 8, 4, 32), (1, 1000, 2, 64), (2, 100, 3, 128), (1, 33, 2, 32)])
 def test_attention(pkg, dev, prec, B, L, heads, dh):
     Fn = pkg.functional
@@ -311,7 +311,7 @@ def ncdhw(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,S,cin,cout", [(2, 6, 768, 32), (1, 5, 32, 16), (2, 12, 64, 64), (2, 6, 768, 128), (2, 12, 128, 64),
                                           # shapes the dedicated tconv2 kernels take (>= 2048 input voxels, small channel counts):
                                           (2, 16, 32, 16), (1, 17, 16, 8), (1, 13, 64, 32), (1, 16, 48, 24), (2, 12, 32, 32), (1, 14, 16, 64)])
@@ -339,7 +339,7 @@ def test_tconv(pkg, dev, prec, B, S, cin, cout):
     assert cat[..., cout:].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 8), 1, 16), (1, (5, 6, 7), 8, 16), (2, (12, 12, 12), 32, 16), (1, (4, 4, 4), 64, 32),
                                               (1, (6, 5, 4), 4, 16)])
 def test_conv3(pkg, dev, prec, B, dims3, cin, cout):
@@ -358,7 +358,7 @@ def test_conv3(pkg, dev, prec, B, dims3, cin, cout):
     assert relerr(Fn.conv_wgrad(xd, cin, dyd, cout, dims, cin, cout, 3, prec), wr.grad) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,dims3,cin,cout,with3", [(2, (8, 8, 16), 16, 16, True), (1, (9, 7, 19), 1, 16, True), (2, (6, 10, 20), 32, 16, True),
                                                      (1, (12, 12, 12), 64, 32, True), (1, (5, 6, 7), 16, 32, False), (2, (4, 4, 16), 256, 128, True),
                                                      (1, (10, 9, 33), 4, 16, True), (2, (20, 12, 40), 1, 16, True), (2, (8, 8, 32), 1, 16, False)])
@@ -393,7 +393,7 @@ def test_conv3_fused_stats_and_1x1(pkg, dev, prec, B, dims3, cin, cout, with3):
         assert c3 is None and st3 is None
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 16), 32, 16), (1, (9, 7, 19), 16, 16), (1, (6, 10, 20), 64, 32), (1, (5, 6, 7), 16, 32),
                                               (2, (4, 4, 16), 256, 128), (1, (10, 9, 33), 48, 16)])
 def test_conv3_dgrad_fused(pkg, dev, prec, B, dims3, cin, cout):
@@ -424,7 +424,7 @@ def test_tr16_probe(pkg, dev):
             assert out[lane, q].item() == (grp * 4 + q) * 64 + i, (lane, q)
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 8), 1, 16), (1, (5, 6, 7), 8, 16), (2, (12, 12, 12), 32, 16), (1, (4, 4, 4), 64, 32),
                                               (1, (6, 5, 20), 4, 16), (1, (12, 12, 12), 256, 128), (1, (9, 17, 33), 16, 16), (1, (8, 8, 16), 48, 48)])
 def test_conv3_halo(pkg, dev, monkeypatch, prec, B, dims3, cin, cout):
@@ -699,7 +699,7 @@ def test_ranking_losses_large_vs_reference_fixture(pkg, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(37, 50, 44), (432, 768, 770), (70, 33, 4100), (16, 16, 70001)])
 def test_gemm_padding_lanes_ignore_inf_nan(pkg, dev, prec, M, N, K):
     """Ragged M / N / K: the loaders fetch out-of-range lanes from a clamped address (element (0,0), row 0 or column 0 of
@@ -953,7 +953,7 @@ def test_instnorm_finalize_in_apply_prologue(pkg, dev, prec, B, dims3, cin, cout
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,dims3,C,cout,max_wg", [(2, (8, 8, 16), 16, 16, 0), (1, (9, 7, 19), 16, 16, 0), (2, (6, 10, 20), 32, 32, 0), (1, (12, 12, 12), 64, 64, 0),
                                                    (2, (4, 4, 16), 128, 128, 0), (3, (16, 16, 32), 16, 16, 8), (2, (20, 12, 40), 32, 32, 8)])
 def test_conv3_dgrad_with_backward_statistics(pkg, dev, monkeypatch, prec, B, dims3, C, cout, max_wg):
@@ -1019,7 +1019,7 @@ def test_instnorm_bwd_folded_finalize(pkg, dev, monkeypatch, prec, B, S, C):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,dims3,cin,cout", [(2, (8, 8, 16), 32, 16), (1, (12, 12, 12), 64, 32), (2, (6, 6, 6), 256, 128), (2, (16, 16, 16), 1, 16)])
 def test_resblock_in_fusion_levels(pkg, dev, monkeypatch, prec, B, dims3, cin, cout):
     """MONAI UnetResBlock forward + backward with the InstanceNorm work folded into its neighbours (UNETR_AMD_IN_FUSE=3)
