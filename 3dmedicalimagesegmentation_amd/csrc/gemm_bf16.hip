@@ -798,6 +798,26 @@ __global__ void __launch_bounds__(256) add_cast_bf16_kernel(const float* __restr
     }
 }
 
+// bf16x3 weight gradients on the bf16 kernels: dW = dY^T X with dY = dYh + dYl, X = Xh + Xl (bf16 halves of the fp32 values) is
+// [dYh; dYh; dYl]^T [Xh; Xl; Xh] -- the same contraction over THREE times the rows.  This kernel writes one such stack from an
+// fp32 [M, C] matrix: second == 0: rows [hi; hi; lo] (the dY side), second == 1: rows [hi; lo; hi] (the X side).
+__global__ void __launch_bounds__(256) split_stack_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n8, long plane, int second) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const f32x4 a = ((const f32x4*)src)[2 * i], b = ((const f32x4*)src)[2 * i + 1];
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}, r[8];
+        const u32x4 hi = PrecBF16::pack(v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[2 * e] = v[2 * e] - __builtin_bit_cast(float, hi[e] << 16);
+            r[2 * e + 1] = v[2 * e + 1] - __builtin_bit_cast(float, hi[e] & 0xffff0000u);
+        }
+        const u32x4 lo = PrecBF16::pack(r);
+        ((u32x4*)dst)[i] = hi;
+        ((u32x4*)(dst + plane))[i] = second ? lo : hi;
+        ((u32x4*)(dst + 2 * plane))[i] = second ? hi : lo;
+    }
+}
+
 __global__ void __launch_bounds__(256) cast_bf16_tail_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long beg, long n) {
     const long i = beg + blockIdx.x * 256L + threadIdx.x;
     if (i < n) { __bf16 h = (__bf16)src[i]; dst[i] = __builtin_bit_cast(uint16_t, h); }
@@ -918,6 +938,15 @@ extern "C" int unetr_cast_bf16(const float* src, void* dst, long n, void* stream
     const long n8 = al ? n / 8 : 0;
     if (n8) hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(n8, 256), 4096)), dim3(256), 0, st, src, (uint16_t*)dst, n8);
     if (n8 * 8 < n) hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3(cdiv(n - n8 * 8, 256)), dim3(256), 0, st, src, (uint16_t*)dst, n8 * 8, n);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_split_stack_bf16(const float* src, void* dst, long rows, long cols, int second, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return UNETR_ERR_ARG;
+    const long n = rows * cols;
+    if ((n & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(split_stack_kernel, dim3((unsigned)std::min<long>(cdiv(n / 8, 256), 4096)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst,
+                       n / 8, n, second);
     return unetr_check_launch();
 }
 

@@ -200,6 +200,24 @@ def _launch_deferred(wq, cq, wbq=(), prec=0, fuse=None):
             arr[i].dy, arr[i].x, arr[i].dw = dyb.data_ptr(), xb.data_ptr(), out.data_ptr()
             arr[i].M, arr[i].N, arr[i].K = dyb.shape[0], dyb.shape[1], xb.shape[1]
         call("unetr_gemm_bf16_grouped_wgrad", arr, len(wbq), _stream())
+    if wq and prec == _capi.PREC_BF16X3 and os.environ.get("UNETR_AMD_X3_WGRAD_STACK", "1") != "0":
+        # bf16x3: dW = dY^T X over (hi, lo) halves is the bf16 kernel's contraction over three times the rows of the stacks
+        # [dYh; dYh; dYl] / [Xh; Xl; Xh] (two streaming split launches per problem) -- the generic fp32-storage grouped kernel spends
+        # 2.2 ms per step on these 76 GF, the bf16 kernel 0.2 ms per 432 rows; with an optimizer epilogue armed it rides here too
+        rest, stacked = [], []
+        for dy, x, out in wq:
+            M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+            if (M * N) % 8 or (M * K) % 8 or (3 * M) % 8 or N % 8 or K % 8 or not dy.is_contiguous() or not x.is_contiguous():
+                rest.append((dy, x, out))
+                continue
+            dys = torch.empty(3 * M, N, dtype=torch.bfloat16, device=dy.device)
+            xs = torch.empty(3 * M, K, dtype=torch.bfloat16, device=dy.device)
+            call("unetr_split_stack_bf16", dy.data_ptr(), dys.data_ptr(), M, N, 0, _stream())
+            call("unetr_split_stack_bf16", x.data_ptr(), xs.data_ptr(), M, K, 1, _stream())
+            stacked.append((dys, xs, out))
+        wq = rest
+        if stacked:
+            _launch_deferred((), (), stacked, prec, fuse)
     if wq:
         arr = (_capi.GroupedProblem * len(wq))()
         for i, (dy, x, out) in enumerate(wq):

@@ -438,7 +438,7 @@ def parity_mode(args, pkg, dev, cfg, batch, synthetic_volume):
     model.precision = "bf16x3"
     flat = model.use_flat_buffers()
     opt = pkg.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, flat=flat)
-    step = pkg.TrainStep(model, pkg.DiceCELoss(to_onehot_y=True, softmax=True), opt, x, y, use_graph=not args.no_graph, fuse_update=False)
+    step = pkg.TrainStep(model, pkg.DiceCELoss(to_onehot_y=True, softmax=True), opt, x, y, use_graph=not args.no_graph, fuse_update=True)
     first = float(step.first_loss.item())
     for _ in range(3):
         step.run()

@@ -256,6 +256,31 @@ def test_flat_buffers_match_per_tensor_path(pkg, dev):
     pkg.functional.clear_grad_sinks()
 
 
+def test_bf16x3_flat_arena_weight_gradients(pkg, dev):
+    """bf16x3 mode with the flat arenas: the ViT weight gradients run on the bf16 grouped kernel over (hi, lo) row stacks
+    (functional._launch_deferred) -- same gradients as the per-tensor path's generic split-operand GEMM, to rounding"""
+    from oracle.unetr_oracle import synthetic_volume
+    torch.manual_seed(3)
+    a = pkg.UNETRLogits(**C1).to(dev)
+    b = pkg.UNETRLogits(**C1).to(dev)
+    b.load_state_dict(a.state_dict())
+    a.precision = b.precision = "bf16x3"
+    flat = b.use_flat_buffers()
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    x, y = synthetic_volume(2, 1, 32, 2, seed=5)
+    x, y = x.to(dev), y.to(dev)
+    la = crit(a(x), y); la.backward()
+    lb = crit(b(x), y); lb.backward()
+    assert torch.equal(la, lb)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for k, p in pa.items():
+        if p.grad is None:
+            assert pb[k].grad is None, k
+        else:
+            assert relerr(pb[k].grad, p.grad) < 1e-4, k
+    pkg.functional.clear_grad_sinks(flat["state"])
+
+
 @pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
 def test_data_parallel_arena_update(pkg, dev, comm_dtype):
     """The N>1 update of bench.py on one device: AdamW.step_reduced reads the 'all-reduced' gradient SUM of a simulated
