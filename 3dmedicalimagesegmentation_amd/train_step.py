@@ -53,8 +53,15 @@ def split_range(flat, lo, hi, pieces):
 class TrainStep:
     def __init__(self, model, criterion, optimizer, x, y, *, use_graph=True, data_parallel=False, process_group=None,
                  comm_dtype=torch.float32, tail_pieces=2, warmup=2, overlap_update=False, fuse_update=False, fuse_comm=True,
-                 handover="host"):
-        """fuse_update (single GPU, flat arenas): AdamW of the ViT Linear weights (92 % of the parameters) is applied in the
+                 handover="host", loss_fn=None, freeze_encoder=False, extra_cuts=()):
+        """loss_fn(enc4, logits) -> scalar loss: replaces ``criterion(logits, y)`` (the ranking pre-training step,
+        unetr_ranking_pretraining_3d.py:259-262, takes its loss from enc4 in the "feat" stage and from the logits in the "recon"
+        stage); the model must then return the (enc4, logits) tuple.  freeze_encoder: the forward of this step runs
+        ``model(x, freeze_encoder=True)`` (:262): only the decoder side receives gradients -- in the data-parallel form backward is then
+        ONE pass whose communication pieces are the arena runs that received a gradient.  extra_cuts: arena offsets at which AdamW
+        launches must be split besides the communication-piece boundaries -- steps with different gradient patterns that share an
+        optimizer (feat / recon) advance the step counters of different parameter sets, and a launch applies ONE counter to its run.
+        fuse_update (single GPU, flat arenas): AdamW of the ViT Linear weights (92 % of the parameters) is applied in the
         epilogue of the grouped weight-gradient launch that ends backward -- their gradients are never stored or re-read (8 of
         34 bytes per weight) and the optimizer's streaming hides under that launch's MFMA work; one table-driven AdamW launch
         covers the rest.  Same bits as the unfused step.  ``p.grad`` of the fused weights is NOT valid afterwards.
@@ -71,6 +78,12 @@ class TrainStep:
         side stream is a branch: the bandwidth-bound optimizer kernels hide under the latency-bound ViT backward chain."""
         flat = getattr(model, "_flat", None)
         self.model, self.crit, self.opt, self.x, self.y = model, criterion, optimizer, x, y
+        self.loss_fn = loss_fn
+        self.frozen = bool(freeze_encoder)
+        if self.frozen and loss_fn is None:
+            raise ValueError("freeze_encoder needs loss_fn(enc4, logits): the frozen forward returns the tuple")
+        if self.frozen and overlap_update:
+            raise ValueError("overlap_update is the staged form: not available with freeze_encoder")
         self.flat = flat
         self.fuse = bool(fuse_update) and not data_parallel and not overlap_update
         if self.fuse and flat is None:
@@ -106,15 +119,23 @@ class TrainStep:
         if self.dp:
             self.comm_stream = torch.cuda.Stream()
             self.comm_buf = None if self.in_place else torch.zeros(flat["total"], dtype=comm_dtype, device=flat["grad"].device)
-            ranges = model.stage_ranges()
-            # per backward pass.  The conv side's 16 MB wait for pass 1 and travel with its range: one hand-over to the
-            # communication stream less per step (each costs the main stream ~70 us), nothing lost in overlap
-            self.pieces = [[], [ranges[0], ranges[1]]] + [[r] for r in ranges[2:-1]] + [split_range(flat, *ranges[-1], tail_pieces)]
-            self.npass = len(self.pieces)
-            self._first_k = next(k for k, st in enumerate(self.pieces) if st)
-            self.cuts = sorted({lo for st in self.pieces for lo, _ in st} | {hi for st in self.pieces for _, hi in st})
+            if self.frozen:
+                # one backward pass; its pieces = the arena runs that receive a gradient, known after the first eager step
+                self.pieces, self.npass, self._first_k = [[]], 1, 0
+                self.cuts = sorted(set(extra_cuts))
+            else:
+                ranges = model.stage_ranges()
+                # per backward pass.  The conv side's 16 MB wait for pass 1 and travel with its range: one hand-over to the
+                # communication stream less per step (each costs the main stream ~70 us), nothing lost in overlap
+                self.pieces = [[], [ranges[0], ranges[1]]] + [[r] for r in ranges[2:-1]] + [split_range(flat, *ranges[-1], tail_pieces)]
+                self.npass = len(self.pieces)
+                self._first_k = next(k for k, st in enumerate(self.pieces) if st)
+                self.cuts = sorted({lo for st in self.pieces for lo, _ in st} | {hi for st in self.pieces for _, hi in st} | set(extra_cuts))
             self._plan = None         # the AdamW launches: planned from the gradient pattern of the first (eager) step
             self._steps = None
+        # (gradient attributes another step object left behind -- a captured step never runs its closing zero_grad in Python -- would
+        # be read as part of THIS step's gradient pattern)
+        optimizer.zero_grad(set_to_none=True)
         # eager warm-up: allocates workspaces, optimizer state, RCCL communicators -- all of which must exist before capture
         self.side = side = side_stream(x.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -128,12 +149,18 @@ class TrainStep:
         torch.cuda.synchronize()
         if use_graph:
             self._capture()
+            if self.dp:
+                optimizer.zero_grad(set_to_none=True)      # the captured passes attached arena views as .grad; replays never read them
 
     # ------------------------------------------------------------------------------------------- single GPU
+    def _loss_of(self, enc4, logits):
+        return self.loss_fn(enc4, logits) if self.loss_fn is not None else self.crit(logits, self.y)
+
     def _fwd_loss(self):
-        out = self.model(self.x)
-        logits = out[1] if isinstance(out, tuple) else out
-        return self.crit(logits, self.y)
+        out = self.model(self.x, freeze_encoder=True) if self.frozen else self.model(self.x)
+        if self.loss_fn is not None and not isinstance(out, tuple):
+            raise RuntimeError("loss_fn(enc4, logits) needs a model that returns the (enc4, logits) tuple (UNETR, not UNETRLogits)")
+        return self._loss_of(*out) if isinstance(out, tuple) else self.crit(out, self.y)
 
     def _backward(self):
         # (the seed gradient is a persistent device scalar: loss.backward() alone launches a fill for it every step)
@@ -157,7 +184,11 @@ class TrainStep:
 
     # ---------------------------------------------------------------------------------------- data parallel
     def _pass0(self):
-        _, logits, self.stages = self.model.forward_staged(self.x)
+        if self.frozen:
+            enc4, logits = self.model(self.x, freeze_encoder=True)
+            self.stages = []
+        else:
+            enc4, logits, self.stages = self.model.forward_staged(self.x)
         if self.fuse_comm and self._plan is not None:
             if self._comm_fuse is None:
                 flat = self.flat
@@ -166,8 +197,10 @@ class TrainStep:
                 self._comm_fuse = dict(kind="bf16out", grad=gbase, out=self.comm_buf.data_ptr(), total=flat["param"].numel(), index=index, done=[])
             self._comm_fuse["done"].clear()               # what THIS step's weight-gradient launches write into the communication buffer
             self.flat["state"].fuse = self._comm_fuse
-        self.loss = self.crit(logits, self.y)
+        self.loss = self._loss_of(enc4, logits)
         self._backward()
+        if self.npass == 1 and self._comm_fuse is not None and self.flat["state"].fuse is self._comm_fuse:
+            self.flat["state"].fuse = None             # (single-pass form: there is no later pass to disarm the epilogue)
 
     def _pass(self, k):
         st = self.stages[k - 1]
@@ -253,6 +286,8 @@ class TrainStep:
         as AdamW launches that never straddle a communication piece"""
         self._plan = self.opt.plan_reduced(cuts=self.cuts)
         runs = self._plan["runs"]
+        if self.frozen:
+            self.pieces = [[(r[2], r[3]) for r in runs]]
         self._runs_of = {(lo, hi): [k for k, r in enumerate(runs) if lo <= r[2] and r[3] <= hi] for st in self.pieces for lo, hi in st}
         covered = sorted(k for ks in self._runs_of.values() for k in ks)
         assert covered == list(range(len(runs))), "every AdamW run must lie inside exactly one communication piece"
@@ -271,7 +306,10 @@ class TrainStep:
             for k in range(self.npass):
                 self._reduce_and_update(k)
         elif tuple(p.grad is not None for p in self.opt.param_groups[0]["params"]) != self._plan["pattern"]:
-            raise RuntimeError("data-parallel step: the set of parameters that receive gradients changed between steps")
+            now = [p.grad is not None for p in self.opt.param_groups[0]["params"]]
+            diff = [(i, bool(a), bool(b)) for i, (a, b) in enumerate(zip(now, self._plan["pattern"])) if bool(a) != bool(b)]
+            raise RuntimeError("data-parallel step: the set of parameters that receive gradients changed between steps "
+                               f"(parameter index, has a gradient now, had one when the step was planned): {diff[:12]}")
         self.opt.zero_grad(set_to_none=True)
 
     def _eager_step(self):
@@ -361,5 +399,7 @@ class TrainStep:
             return "hipGraph(fwd+loss+bwd+AdamW" + (", AdamW of the ViT weights in the weight-gradient epilogue)" if fused else ")")
         if self.one_graph:
             return (f"hipGraph(fwd+loss+bwd in {self.npass} passes; AdamW per pass on a side-stream branch underneath the passes that follow)")
+        if self.frozen:
+            return "1 hipGraph (fwd+loss+bwd, encoder frozen), all-reduce of the decoder's gradient runs on a side stream, AdamW per reduced piece"
         return (f"{len(self.graphs)} hipGraphs ({self.npass} backward passes: fwd+loss+conv side | ViT passes 1-{self.npass - 1}), "
                 "per-pass all-reduce on a side stream, AdamW per reduced piece")

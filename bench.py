@@ -107,6 +107,10 @@ def stub_rank(args, rank, world, real_stdout):
     n = 1 << 16
     bounds = [0, n // 8, n // 2, 3 * n // 4, n]
     ranges = [(bounds[i], bounds[i + 1]) for i in (3, 2, 1, 0)]
+    # --config c5: the six passes of the ranking pre-training step -- per slice axis a "feat" pass (every range but the decoder's
+    # share of the conv side, in backward order) and a "recon" pass (encoder frozen: the decoder's share only, ONE piece)
+    dec = (bounds[3] + (n - bounds[3]) // 2, n)
+    passes = [ranges] if args.config != "c5" else [[(bounds[3], dec[0])] + ranges[1:], [dec]] * 3
     torch.manual_seed(0)
     param = torch.randn(n)
     grad = torch.zeros(n)
@@ -115,13 +119,14 @@ def stub_rank(args, rank, world, real_stdout):
         if it == args.warmup:
             dist.barrier()
             t0 = time.perf_counter()
-        works = []
-        for lo, hi in ranges:
-            grad[lo:hi] = torch.sin(param[lo:hi]) * (rank + 1)           # this rank's "backward pass" over the range
-            works.append((lo, hi, dist.all_reduce(grad[lo:hi], async_op=True)))
-        for lo, hi, w in works:
-            w.wait()
-            param[lo:hi] -= 1e-2 * grad[lo:hi] / world
+        for prs in passes:
+            works = []
+            for lo, hi in prs:
+                grad[lo:hi] = torch.sin(param[lo:hi]) * (rank + 1)           # this rank's "backward pass" over the range
+                works.append((lo, hi, dist.all_reduce(grad[lo:hi], async_op=True)))
+            for lo, hi, w in works:
+                w.wait()
+                param[lo:hi] -= 1e-2 * grad[lo:hi] / world
     dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64)
@@ -133,7 +138,8 @@ def stub_rank(args, rank, world, real_stdout):
     out = {"metric": "stub steps/sec (CPU, gloo)", "value": round(world * args.steps / t.item(), 3), "unit": "steps/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t.item() / args.steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "stub: 4 gradient ranges, async all-reduce per range, update in completion order"},
+           "config": {"workload": ("stub: 4 gradient ranges, async all-reduce per range, update in completion order" if args.config != "c5" else
+                                   "stub c5: 3 x (feat pass: 4 ranges in backward order + recon pass: 1 decoder range), async all-reduce per range")},
            "rccl_world": dist.get_world_size(), "backend": "gloo", "ranks_agree": bool(lo_.item() == hi_.item())}
     dist.barrier()
     dist.destroy_process_group()
@@ -327,14 +333,6 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
         pkg.functional.invalidate_weight_shadows()
         flat["shadow"].copy_(flat["param"])
 
-    def reduce_grads():
-        """data parallel (volumes are independent, the loss of a rank was divided by the world size): sum-all-reduce, in place,
-        of every contiguous arena run that received a gradient in this pass (the frozen-encoder passes touch the decoder only)"""
-        params = opt.param_groups[0]["params"]
-        pattern = tuple(p.grad is not None for p in params)
-        for _, _, lo, hi in opt._flat_runs(params, pattern):
-            dist.all_reduce(flat["grad"][lo:hi], op=dist.ReduceOp.SUM)
-
     patterns = {}          # stage -> which parameters receive gradients (recorded by the first, unfused, step)
 
     def step():
@@ -351,11 +349,7 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
                 loss = pkg.ranking_loss(inp, axis, init_idx, 0.1, kind="ranking")
                 if fused:
                     opt.begin_fused_step(patterns[stage])      # (after the forward, which drops any stale arming)
-                if dist is not None:
-                    (loss / world).backward()
-                    reduce_grads()
-                    opt.step()
-                elif fused:
+                if fused:
                     # (the optimizer is armed: AdamW of the ViT weights rides on the weight-gradient launch that
                     # ends this backward pass -- the three "feat" passes; the frozen-encoder passes update the conv side only)
                     loss.backward()
@@ -369,12 +363,35 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
                 last = loss
         return last
 
-    for _ in range(2):
-        loss = step()
-    torch.cuda.synchronize()
     launch, graph_err = "eager launches", None
-    run = step
-    if not args.no_graph and flat is not None and dist is None:      # (collectives are eager calls: N > 1 runs eagerly)
+    if dist is not None:
+        # data parallel: every one of the six passes is a TrainStep in its data-parallel launch form -- "feat": backward in the five
+        # passes of UNETR.forward_staged, each pass's gradient range all-reduced (async) on the communication stream underneath the
+        # passes that follow, AdamW per reduced piece; "recon" (encoder frozen: decoder gradients only): one backward pass, its
+        # gradient runs all-reduced and stepped piece by piece.  Volumes are independent: the sum is averaged in the optimizer kernel.
+        bf16_comm = args.precision == "bf16" and not args.fp32_comm and (args.bf16_comm or world > 1)
+        comm_dtype = torch.bfloat16 if bf16_comm else torch.float32
+        stages = []
+        for axis in (2, 3, 4):
+            for stage in ("feat", "recon"):
+                idx = 1 if stage == "feat" else 7          # enc4 is 12^3: partition size 3; logits are 96^3: partition size 24
+                fn = (lambda e, l, a=axis, i=idx: pkg.ranking_loss(e, a, i, 0.1, kind="ranking")) if stage == "feat" else \
+                     (lambda e, l, a=axis, i=idx: pkg.ranking_loss(l, a, i, 0.1, kind="ranking"))
+                stages.append(pkg.TrainStep(model, None, opt, x, None, use_graph=not args.no_graph, data_parallel=True, comm_dtype=comm_dtype,
+                                            fuse_comm=bool(args.fuse_comm), handover=args.handover, loss_fn=fn,
+                                            freeze_encoder=stage == "recon", warmup=2))
+        launch = f"6 data-parallel TrainSteps ({stages[0].launch} | recon: {stages[1].launch}), gradient communication in {comm_dtype}".replace("torch.", "")
+
+        def run():
+            for st in stages:
+                st.run()
+            return stages[-1].loss
+    else:
+        for _ in range(2):
+            loss = step()
+        torch.cuda.synchronize()
+        run = step
+    if not args.no_graph and flat is not None and dist is None:      # (collectives are eager calls between graph launches: see TrainStep)
         # the six passes (each forward + loss + backward + AdamW, with its own gradient pattern) as ONE hipGraph
         try:
             side = pkg.train_step.side_stream(dev)
@@ -396,18 +413,33 @@ def run_c5(args, pkg, dev, rank, world, dist=None):
             opt.zero_grad(set_to_none=True)
     for _ in range(max(1, args.warmup)):
         loss = run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # as run_supervised: windows of EXACTLY --steps steps between barrier + device synchronisation, MAX over ranks, median window
+    wins = []
+    for _ in range(max(1, args.windows)):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = run()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        wins.append(dt)
+    dt = sorted(wins)[len(wins) // 2]
     return {"metric": "ranking pre-training volumes/sec (96^3)", "value": round(world * 4 * 6 * args.steps / dt, 3), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "windows": len(wins), "ms_per_step_min": round(min(wins) / args.steps * 1e3, 4), "ms_per_step_max": round(max(wins) / args.steps * 1e3, 4),
             "config": {"workload": "configs[4]: ranking pre-training, [4,1,96^3] batch, 3 slice axes x (feat + recon) = 6 "
-                                   f"fwd/BT-loss/bwd/AdamW passes per step, {launch}"
-                                   + ("" if dist is None else ", gradients summed over ranks after every backward pass (fp32, in place)"),
+                                   f"fwd/BT-loss/bwd/AdamW passes per step, {launch}",
                        "final_loss": float(loss.item()),
                        "graph_capture_error": graph_err}}
 

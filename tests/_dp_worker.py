@@ -21,6 +21,30 @@ C2 = dict(in_channels=1, out_channels=4, img_size=(96, 96, 96), feature_size=16,
 cfg, S, ncls, lr = (C2, 96, 4, 1e-4) if size == "c2" else (C1, 32, 2, 1e-3)
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
 dev = torch.device("cuda:0")
+if size == "c5":
+    # BASELINE configs[4] in its data-parallel form at the plumbing geometry: per rank a [4, 1, 32^3] batch (2 volumes x 2 views),
+    # one "feat" pass (loss on enc4, staged backward, per-pass all-reduce) and one "recon" pass (encoder frozen, loss on the logits,
+    # one backward pass whose gradient runs are the communication pieces) per round, as bench.py --config c5 --gpus N builds them
+    torch.manual_seed(11)
+    m = pkg.UNETR(**C1).to(dev)
+    m.precision = "bf16"
+    flat = m.use_flat_buffers()
+    opt = pkg.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, flat=flat)
+    x, _ = synthetic_volume(8, 1, 32, 2, seed=77)        # joint batch [r0.f1, r1.f1, r0.f2, r1.f2]: this rank's views 2r, 2r+1 of each half
+    xs = torch.cat([x[2 * rank:2 * rank + 2], x[4 + 2 * rank:4 + 2 * rank + 2]]).to(dev)
+    feat = pkg.TrainStep(m, None, opt, xs, None, use_graph=mode == "graph", data_parallel=True, warmup=1, comm_dtype=torch.float32,
+                         loss_fn=lambda e, l: pkg.ranking_loss(e, 2, 0, 0.1, kind="ranking"))
+    recon = pkg.TrainStep(m, None, opt, xs, None, use_graph=mode == "graph", data_parallel=True, warmup=1, comm_dtype=torch.float32,
+                          loss_fn=lambda e, l: pkg.ranking_loss(l, 4, 3, 0.1, kind="ranking"), freeze_encoder=True)
+    for _ in range(2):
+        feat.run()
+        recon.run()
+    torch.cuda.synchronize()
+    torch.save({"param": flat["param"].cpu(), "loss": (float(feat.loss), float(recon.loss)), "steps": (feat.eager_steps, recon.eager_steps),
+                "pieces": (feat.pieces, recon.pieces)}, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 torch.manual_seed(11)                                   # same initial weights on both ranks
 m = pkg.UNETRLogits(**cfg).to(dev)
 m.precision = "bf16"

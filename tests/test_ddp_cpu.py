@@ -1,6 +1,8 @@
 """world_size-2 gloo test of the bucketed gradient all-reducer (the N>1 path of bench.py): averaged
 gradients, unused parameters (cls_token / frozen encoder) and bucket ordering."""
 import os
+
+import pytest
 import socket
 import sys
 
@@ -200,14 +202,15 @@ def test_reduced_plan_gloo_world2():
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
-def test_bench_launcher_starts_n_ranks_gloo_stub():
+@pytest.mark.parametrize("config", ["c2", "c5"])
+def test_bench_launcher_starts_n_ranks_gloo_stub(config):
     """`python bench.py --gpus 2` without a rendezvous environment must start 2 ranks itself (a child torchrun job) and
     print ONE JSON line from rank 0 -- exercised here on the CPU stub step over gloo (the schedule of the data-parallel
     step: ranges all-reduced as they fill, update in completion order)."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1", "--config", config],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
@@ -217,6 +220,7 @@ def test_bench_launcher_starts_n_ranks_gloo_stub():
     assert out["ranks_agree"] is True and out["scaling"] == "weak" and out["value"] > 0
     for k in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert k in out
+    assert ("c5" in out["config"]["workload"]) == (config == "c5")      # config 5: six passes per step, the frozen ones on one piece
 
 
 def test_stage_ranges_and_piece_plan():

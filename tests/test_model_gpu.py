@@ -756,6 +756,60 @@ def test_two_rank_data_parallel_step(pkg, dev, tmp_path, mode, size):
     flat["state"].clear()
 
 
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_rank_ranking_pretraining_step(pkg, dev, tmp_path, mode):
+    """BASELINE configs[4] in its data-parallel form with a REAL 2-rank all-reduce (two processes on one GPU, gloo): per rank a
+    "feat" TrainStep (loss on enc4: staged backward, per-pass all-reduce under the passes that follow) and a "recon" TrainStep
+    (encoder frozen: one backward pass, its gradient runs are the pieces), two rounds.  Both ranks end bit-identical, the frozen
+    step's pieces lie in the decoder's arena range, and the update is the update of ONE process that averages the gradients of
+    the two ranks' batches itself (per-tensor gradients accumulated over the two [4, ...] batches, each loss halved)."""
+    import socket
+    import subprocess
+    import sys
+    from oracle.unetr_oracle import synthetic_volume
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), str(tmp_path), mode, "c5"], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert torch.equal(r0["param"], r1["param"])
+    # one process, joint batch, the same number of feat / recon updates
+    x, _ = synthetic_volume(8, 1, 32, 2, seed=77)
+    torch.manual_seed(11)
+    m = pkg.UNETR(**C1).to(dev)
+    m.precision = "bf16"
+    flat = m.use_flat_buffers()                                       # (only for the arena geometry and the flat parameter vector)
+    names = [n for n, _ in m.named_parameters()]
+    dec_lo = min(o for n, o in zip(names, flat["offsets"]) if n.startswith("decoder") or n.startswith("out."))
+    for lo, hi in r0["pieces"][1][0]:
+        assert dec_lo <= lo < hi <= flat["total"]                    # the frozen pass communicates decoder / out gradients only
+    assert len(r0["pieces"][0]) == 5                                  # feat: the five staged passes
+    p0 = flat["param"].clone()
+    flat["state"].clear()                                             # per-tensor gradients from here on: they accumulate over two batches
+    opt = pkg.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    xr = [torch.cat([x[2 * r:2 * r + 2], x[4 + 2 * r:4 + 2 * r + 2]]).to(dev) for r in range(2)]      # the two ranks' batches
+    nf, nr = r0["steps"][0] + (2 if mode == "graph" else 0), r0["steps"][1] + (2 if mode == "graph" else 0)
+    assert nf == nr
+    for _ in range(nf):
+        for xb in xr:
+            enc4, _ = m(xb)
+            (0.5 * pkg.ranking_loss(enc4, 2, 0, 0.1, kind="ranking")).backward()
+        opt.step(); opt.zero_grad(set_to_none=True)
+        for xb in xr:
+            _, logits = m(xb, freeze_encoder=True)
+            (0.5 * pkg.ranking_loss(logits, 4, 3, 0.1, kind="ranking")).backward()
+        opt.step(); opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    upd_dp, upd_1 = r0["param"].to(dev) - p0, flat["param"] - p0
+    cos = torch.nn.functional.cosine_similarity(upd_dp.double(), upd_1.double(), dim=0)
+    assert cos > 0.95, float(cos)
+    assert relerr(r0["param"].to(dev), flat["param"]) < 1e-2
+
+
 def test_next_block_layernorm_ride_is_exact(pkg, dev, monkeypatch):
     """UNETR_AMD_LN_RIDE=1 (norm1 of block i+1 formed by block i's last split-K reduction): logits, loss and every gradient
     bit-identical to the default launch form."""
