@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
-ABI_VERSION = 10       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 11       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -66,6 +66,10 @@ class PackProblem(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("Cin", c_int), ("Cout", c_int), ("kind", c_int)]
 
 
+class ReduceProblem(ctypes.Structure):
+    _fields_ = [("part", c_void_p), ("dst", c_void_p), ("n", c_long), ("rows", c_int)]
+
+
 class ColsumProblem(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("ld", c_long), ("M", c_int), ("N", c_int), ("x_bf16", c_int)]
 
@@ -114,6 +118,9 @@ _SIGNATURES = {
     "unetr_conv3_dgrad_stats": [P, c_long, P, P, c_long, P, c_long, P, P, ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_instnorm_apply_fin": [P, c_long, P, c_int, P, c_long, P, c_int, P, P, c_float, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
     "unetr_instnorm_bwd_apply_fin": [P, c_long, P, c_long, P, P, c_long, P, P, c_int, c_int, P, c_long, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
+    "unetr_conv3_wgrad_parts": [P, c_long, P, c_long, P, c_long, P, c_size_t, ctypes.POINTER(c_long), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_tconv2_wgrad_parts": [P, c_long, P, c_long, P, c_size_t, ctypes.POINTER(c_long), c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "unetr_reduce_rows_grouped": [ctypes.POINTER(ReduceProblem), c_int, P],
     "unetr_conv3_dgrad_fused": [P, c_long, P, P, c_long, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P],
     "unetr_conv3_pack_grouped": [ctypes.POINTER(PackProblem), c_int, c_int, P],
     "unetr_conv3_pack_1x1": [P, P, c_int, c_int, c_int, P],
@@ -142,7 +149,8 @@ _SIGNATURES = {
     "unetr_adamw_reduced": [P, P, c_int, c_float, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],
 }
 
-EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_conv3_packed_1x1_bytes", "unetr_ranking_workspace_floats")
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_conv3_packed_1x1_bytes", "unetr_ranking_workspace_floats",
+                                            "unetr_conv3_wgrad_rows", "unetr_tconv2_wgrad_rows")
 
 _lib = None
 
@@ -170,6 +178,10 @@ def load():
     lib.unetr_conv3_packed_bytes.restype = c_size_t
     lib.unetr_conv3_packed_1x1_bytes.argtypes = [c_int, c_int, c_int]
     lib.unetr_conv3_packed_1x1_bytes.restype = c_size_t
+    lib.unetr_conv3_wgrad_rows.argtypes = [c_int] * 9
+    lib.unetr_conv3_wgrad_rows.restype = c_long
+    lib.unetr_tconv2_wgrad_rows.argtypes = [c_int] * 6
+    lib.unetr_tconv2_wgrad_rows.restype = c_long
     lib.unetr_ranking_workspace_floats.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.unetr_ranking_workspace_floats.restype = c_size_t
     _lib = lib

@@ -2001,9 +2001,13 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
     return unetr_check_launch();
 }
 
+// rows_only != nullptr: just report the number of partial rows (workgroups along the voxel walk) a launch of this shape uses with an
+// unlimited partial buffer; parts_only: the partial rows stay in ws ([G][n] then [G][n3]) and NO reduce is launched -- the caller
+// reduces them later (unetr_reduce_rows_grouped: every weight-gradient reduction of a backward pass in one launch)
 template <class P>
 int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, const void* dy3v, long lddy3, float* dw3,
-            int B, int D, int H, int W, int Cin, int Cout, float* ws, size_t ws_bytes, hipStream_t st, int x_f32 = 0) {
+            int B, int D, int H, int W, int Cin, int Cout, float* ws, size_t ws_bytes, hipStream_t st, int x_f32 = 0,
+            bool parts_only = false, long* rows_only = nullptr, long* rows_used = nullptr) {
     typedef typename ActOf<P>::type GT;
     const GT* dy = (const GT*)dyv;
     const GT* dy3 = (const GT*)dy3v;
@@ -2022,13 +2026,16 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
             (!dy3 || (((uintptr_t)dy3 & 15) == 0 && (lddy3 & 7) == 0)) && (long)D * H * W < (1L << 31) && !getenv("UNETR_CONV_C1_OFF")) {
             long G = std::min<long>(1024, ntiles);
             if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) G = std::min<long>(G, atoi(e)); }
+            if (rows_only) { *rows_only = G; return UNETR_OK; }
             const long n1 = 27L * 16, n31 = dy3 ? 16 : 0, rows = G;
             if (!ws || (size_t)rows * (n1 + n31) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+            if (rows_used) *rows_used = rows;
             float* wsb = ws + (size_t)rows * n1;
             hipLaunchKernelGGL(conv3_c1_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, st, (const float*)x, (const uint16_t*)dy, lddy, (const uint16_t*)dy3, lddy3,
                                ws, wsb, D, H, W, ntx, nty, ntz, (int)ntiles);
             const int blocks = (int)cdiv(n1, 32), blocks3 = dy3 ? 1 : 0;
-            hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)rows, n1, dw, blocks, (const float*)wsb, n31, dw3);
+            if (!parts_only)
+                hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)rows, n1, dw, blocks, (const float*)wsb, n31, dw3);
             return unetr_check_launch();
         }
     }
@@ -2045,8 +2052,10 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     G = std::min(G, ntiles);
     if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) G = std::min<long>(G, atoi(e)); }   // test hook: long tile walks
     const long n3 = dy3 ? (long)Cin * Cout : 0;
+    if (rows_only) { *rows_only = G; return UNETR_OK; }
     while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;
     if (!ws || (size_t)G * (n + n3) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    if (rows_used) *rows_used = G;
     float* ws3 = ws + (size_t)G * n;
     const int vecy3 = (dy3 && ((uintptr_t)dy3 & 15) == 0 && (lddy3 & 3) == 0 && (Cout & 3) == 0) ? 1 : 0;
     if (nci > 65535 || nco > 65535) return UNETR_ERR_ARG;
@@ -2085,8 +2094,9 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
     }
     const int blocks = (int)std::min<long>((n + 31) / 32, 16384);
     const int blocks3 = dy3 ? (int)std::min<long>((n3 + 31) / 32, 16384) : 0;
-    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)G, n, dw, blocks,
-                       (const float*)ws3, n3, dw3);
+    if (!parts_only)
+        hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)G, n, dw, blocks,
+                           (const float*)ws3, n3, dw3);
     return unetr_check_launch();
 }
 
@@ -2282,6 +2292,32 @@ extern "C" int unetr_conv3_wgrad(const void* x, long ldx, const void* dy, long l
     if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, x_f32);
     if (prec == UNETR_PREC_F32) return wgrad_t<PrecF32>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     if (prec == UNETR_PREC_BF16X3) return wgrad_t<PrecBF16x3>(x, ldx, dy, ldy, dw, dy3, ldy3, dw3, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    return UNETR_ERR_ARG;
+}
+
+// number of partial rows unetr_conv3_wgrad_parts writes for this shape (< 0: the shape is not supported)
+extern "C" long unetr_conv3_wgrad_rows(int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32, int has3) {
+    long rows = -1;
+    const void* dummy = (const void*)(uintptr_t)256;           // (aligned, never dereferenced: rows_only returns before any launch)
+    int rc = UNETR_ERR_ARG;
+    const long ldx = x_f32 && Cin == 1 ? 1 : (Cin + 7) / 8 * 8;
+    if (prec == UNETR_PREC_BF16) rc = wgrad_t<PrecBF16>(dummy, ldx, dummy, Cout, nullptr, has3 ? dummy : nullptr, Cout, nullptr, B, D, H, W, Cin, Cout, nullptr, 0, nullptr, x_f32, true, &rows);
+    else if (prec == UNETR_PREC_F32) rc = wgrad_t<PrecF32>(dummy, ldx, dummy, Cout, nullptr, has3 ? dummy : nullptr, Cout, nullptr, B, D, H, W, Cin, Cout, nullptr, 0, nullptr, 0, true, &rows);
+    else if (prec == UNETR_PREC_BF16X3) rc = wgrad_t<PrecBF16x3>(dummy, ldx, dummy, Cout, nullptr, has3 ? dummy : nullptr, Cout, nullptr, B, D, H, W, Cin, Cout, nullptr, 0, nullptr, 0, true, &rows);
+    return rc == UNETR_OK ? rows : -1;
+}
+
+// unetr_conv3_wgrad without its reduce launch: the per-workgroup partial sums stay in `part` -- [rows][27 Cin Cout] followed, when dy3
+// is given, by [rows][Cin Cout] (rows = unetr_conv3_wgrad_rows) -- for unetr_reduce_rows_grouped
+extern "C" int unetr_conv3_wgrad_parts(const void* x, long ldx, const void* dy, long ldy, const void* dy3, long ldy3,
+                                       float* part, size_t part_bytes, long* rows_out, int B, int D, int H, int W, int Cin, int Cout, int prec,
+                                       int x_f32, void* stream) {
+    if (!x || !dy || !part || !rows_out || B <= 0) return UNETR_ERR_ARG;
+    float* dummy3 = dy3 ? part : nullptr;                        // (dw / dw3 are not written in this form)
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == UNETR_PREC_BF16) return wgrad_t<PrecBF16>(x, ldx, dy, ldy, part, dy3, ldy3, dummy3, B, D, H, W, Cin, Cout, part, part_bytes, st, x_f32, true, nullptr, rows_out);
+    if (prec == UNETR_PREC_F32) return wgrad_t<PrecF32>(x, ldx, dy, ldy, part, dy3, ldy3, dummy3, B, D, H, W, Cin, Cout, part, part_bytes, st, 0, true, nullptr, rows_out);
+    if (prec == UNETR_PREC_BF16X3) return wgrad_t<PrecBF16x3>(x, ldx, dy, ldy, part, dy3, ldy3, dummy3, B, D, H, W, Cin, Cout, part, part_bytes, st, 0, true, nullptr, rows_out);
     return UNETR_ERR_ARG;
 }
 

@@ -328,6 +328,51 @@ colsum_grouped_kernel(ColsumArgs a) {
     if (ty == 0 && n < pr.N) pr.out[n] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
 
+// ---- every weight-gradient reduction of a backward pass in ONE launch: dst_p[i] = sum_g part_p[g][i] for each problem p (the
+// per-workgroup partial sums of the 3x3x3 / 2x2x2 conv weight-gradient kernels).  Same body and summation order as
+// conv3_wgrad_reduce_kernel (32 outputs x 8 row phases per workgroup, eight loads of a phase in flight, phases added in order);
+// a workgroup finds its problem by binary search over the kernel-argument table.  Fourteen ~6 us launches per step before.
+constexpr int RR_MAX = 48;
+struct RrProblem { const float* part; float* dst; long n; int G; int blk0; int nblk; };
+struct RrArgs { int n; RrProblem p[RR_MAX]; };
+__global__ void __launch_bounds__(256) reduce_rows_grouped_kernel(RrArgs a) {
+    int pi = 0, hi_ = a.n - 1;
+    while (pi < hi_) {
+        const int mid = (pi + hi_ + 1) >> 1;
+        if ((int)blockIdx.x >= a.p[mid].blk0) pi = mid; else hi_ = mid - 1;
+    }
+    const RrProblem& pr = a.p[pi];
+    const float* __restrict__ part = pr.part;
+    float* __restrict__ dw = pr.dst;
+    const long n = pr.n;
+    const int G = pr.G, bx = (int)blockIdx.x - pr.blk0, nbx = pr.nblk;
+    __shared__ float sm[8][33];
+    const int o = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    for (long i0 = (long)bx * 32; i0 < n; i0 += (long)nbx * 32) {
+        const long i = i0 + o;
+        float s = 0.f;
+        if (i < n) {
+            int gI = ph;
+            for (; gI + 56 < G; gI += 64) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = part[(long)(gI + 8 * u) * n + i];
+                s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
+            for (; gI < G; gI += 8) s += part[(long)gI * n + i];
+        }
+        sm[ph][o] = s;
+        __syncthreads();
+        if (ph == 0 && i < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) t += sm[p][o];
+            dw[i] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------ InstanceNorm
 // x: [B, V, C] pitch ld.  thread -> (channel vec cv, voxel phase); block covers VPB voxels of one batch item.
 constexpr int IN_VPB = 1024;
@@ -1378,6 +1423,25 @@ static int in_check(int C, long ld, int act16 = 0) {
     const int W = act16 ? 8 : 4;            // one 16-byte access per thread
     if ((C % W) || C > 1024 || (ld % W) || (256 % (C / W)) != 0) return UNETR_ERR_UNSUPPORTED;
     return UNETR_OK;
+}
+
+extern "C" int unetr_reduce_rows_grouped(const unetr_reduce_problem* probs, int n, void* stream) {
+    if (!probs || n <= 0) return UNETR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += RR_MAX) {
+        RrArgs a;
+        a.n = std::min(RR_MAX, n - base);
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const unetr_reduce_problem& q = probs[base + i];
+            if (!q.part || !q.dst || q.rows <= 0 || q.n <= 0) return UNETR_ERR_ARG;
+            const int nb = (int)std::min<long>((q.n + 31) / 32, 8192);
+            a.p[i] = RrProblem{q.part, q.dst, q.n, q.rows, blocks, nb};
+            blocks += nb;
+        }
+        hipLaunchKernelGGL(reduce_rows_grouped_kernel, dim3(blocks), dim3(256), 0, st, a);
+    }
+    return unetr_check_launch();
 }
 
 extern "C" int unetr_instnorm_stats(const void* x, long ld, int B, long V, int C, float eps, float* stats,

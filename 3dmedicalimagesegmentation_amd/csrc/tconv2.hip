@@ -389,20 +389,22 @@ void launch_wgrad(int G, int NG, const typename Elem<P>::type* x, long ldx, cons
 
 template <class P>
 int wgrad2(const typename Elem<P>::type* x, long ldx, const typename Elem<P>::type* dy, long lddy, float* dw, int B, int D, int H, int W, int Cin, int Cout,
-           float* ws, size_t ws_bytes, hipStream_t st) {
+           float* ws, size_t ws_bytes, hipStream_t st, bool parts_only = false, long* rows_only = nullptr, long* rows_used = nullptr) {
     const long Ml = (long)B * D * H * W;
     const int M = (int)Ml, ntiles = cdiv(M, TV), N = 8 * Cout, RT = Cin / 16;
     // column tiles per wave: the whole result in one workgroup column when it fits 256 columns, else several column groups
     const int CTW = N >= 256 ? 4 : (N >= 128 ? 2 : 1), NG = cdiv(N, 64 * CTW);
     int G = std::max(1, std::min(ntiles, 768 / NG));
     const long n = (long)Cin * Cout * 8;
+    if (rows_only) { *rows_only = G; return UNETR_OK; }
     while (G > 1 && (size_t)G * n * sizeof(float) > ws_bytes) G >>= 1;
     if (!ws || (size_t)G * n * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    if (rows_used) *rows_used = G;
 #define TC_WG(RT_, CTW_) launch_wgrad<P, RT_, CTW_>(G, NG, x, ldx, dy, lddy, ws, M, D, H, W, Cin, Cout, ntiles, st)
 #define TC_WG_RT(CTW_) \
     switch (RT) { case 1: TC_WG(1, CTW_); break; case 2: TC_WG(2, CTW_); break; case 3: TC_WG(3, CTW_); break; default: TC_WG(4, CTW_); break; }
     if (CTW == 4) { TC_WG_RT(4) } else if (CTW == 2) { TC_WG_RT(2) } else { TC_WG_RT(1) }
-    hipLaunchKernelGGL(tconv2_reduce_kernel, dim3((int)std::min<long>((n + 31) / 32, 4096)), dim3(256), 0, st, ws, G, n, dw);
+    if (!parts_only) hipLaunchKernelGGL(tconv2_reduce_kernel, dim3((int)std::min<long>((n + 31) / 32, 4096)), dim3(256), 0, st, ws, G, n, dw);
     return unetr_check_launch();
 }
 
@@ -472,6 +474,31 @@ extern "C" int unetr_tconv2_wgrad(const void* x, long ldx, const void* dy, long 
     }
     if (prec == UNETR_PREC_F32) return wgrad2<PrecF32>((const float*)x, ldx, (const float*)dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
     if (prec == UNETR_PREC_BF16X3) return wgrad2<PrecBF16x3>((const float*)x, ldx, (const float*)dy, lddy, dw, B, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+    return UNETR_ERR_ARG;
+}
+
+// partial rows of unetr_tconv2_wgrad_parts for this shape (< 0: unsupported)
+extern "C" long unetr_tconv2_wgrad_rows(int B, int D, int H, int W, int Cin, int Cout) {
+    long rows = -1;
+    if (!unetr_tconv2_wgrad_supported((long)B * D * H * W, Cin, Cout, Cin, Cout)) return -1;
+    const int rc = wgrad2<PrecF32>(nullptr, Cin, nullptr, Cout, nullptr, B, D, H, W, Cin, Cout, nullptr, 0, nullptr, true, &rows);
+    return rc == UNETR_OK ? rows : -1;
+}
+
+// unetr_tconv2_wgrad without its reduce launch: the per-workgroup partial sums stay in `part` [rows][Cin Cout 8] for
+// unetr_reduce_rows_grouped
+extern "C" int unetr_tconv2_wgrad_parts(const void* x, long ldx, const void* dy, long lddy, float* part, size_t part_bytes, long* rows_out,
+                                        int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream) {
+    if (!x || !dy || !part || !rows_out) return UNETR_ERR_ARG;
+    if (!unetr_tconv2_wgrad_supported((long)B * D * H * W, Cin, Cout, ldx, lddy) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15))
+        return UNETR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == UNETR_PREC_BF16) {
+        if ((ldx & 7) || (lddy & 7)) return UNETR_ERR_UNSUPPORTED;
+        return wgrad2<PrecBF16>((const uint16_t*)x, ldx, (const uint16_t*)dy, lddy, part, B, D, H, W, Cin, Cout, part, part_bytes, st, true, nullptr, rows_out);
+    }
+    if (prec == UNETR_PREC_F32) return wgrad2<PrecF32>((const float*)x, ldx, (const float*)dy, lddy, part, B, D, H, W, Cin, Cout, part, part_bytes, st, true, nullptr, rows_out);
+    if (prec == UNETR_PREC_BF16X3) return wgrad2<PrecBF16x3>((const float*)x, ldx, (const float*)dy, lddy, part, B, D, H, W, Cin, Cout, part, part_bytes, st, true, nullptr, rows_out);
     return UNETR_ERR_ARG;
 }
 

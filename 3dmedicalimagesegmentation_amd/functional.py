@@ -37,6 +37,36 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- an auxiliary stream per device for conv-side work that nothing on the ViT's dependency chain waits for (the encoder1 residual
+# block: its forward is only needed by decoder2, its backward feeds no other gradient).  Autograd runs a node's backward on the stream
+# its forward ran on, so work placed here in the forward also leaves the backward's critical path; under graph capture the stream
+# becomes a branch of the captured graph.  UNETR_AMD_AUX_STREAM=1 enables it (A/B hook).
+_AUX = {}
+_AUX_USED = set()
+
+
+def aux_stream_enabled():
+    return os.environ.get("UNETR_AMD_AUX_STREAM", "0") == "1"
+
+
+def aux_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _AUX.get(idx)
+    if st is None:
+        st = _AUX[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+def join_aux_streams():
+    """the current stream waits for everything queued on the auxiliary streams used since the last join (end of a backward pass:
+    parameter gradients written there bypass autograd's own leaf-stream synchronisation)"""
+    cur = torch.cuda.current_stream()
+    for idx in list(_AUX_USED):
+        if idx == cur.device.index:
+            cur.wait_stream(_AUX[idx])
+            _AUX_USED.discard(idx)
+
+
 # ---- gradient sinks: parameters registered here get their gradients written straight into a slice of one flat
 # arena (UNETR.use_flat_buffers), so AdamW is one launch and the data-parallel all-reduce needs no flatten copies.
 # Everything mutable about that fast path -- the sink table, the deferred weight-gradient queues, the readiness
@@ -47,7 +77,7 @@ class ArenaState:
     def __init__(self):
         self.sinks = {}            # data_ptr -> (weakref(param), arena view)
         self.ready_cb = []         # data-parallel reducers: called with a parameter once its arena gradient is final
-        self.defer = {"wgrad": [], "wgrad_b": [], "colsum": [], "params": [], "armed": False, "prec": 0}
+        self.defer = {"wgrad": [], "wgrad_b": [], "colsum": [], "reduce": [], "params": [], "armed": False, "prec": 0}
         self.unmaintained = 0      # arena shadows of THIS model re-derived since its flat optimizer last vouched for them
         self.fuse = None           # optim.AdamW.begin_fused_step: the deferred weight-gradient launch applies AdamW itself
 
@@ -55,7 +85,7 @@ class ArenaState:
         """Drop whatever a backward pass that raised left queued (its end-of-pass callback never ran): without this the
         queue stays armed, no later pass re-arms the flush, and AdamW steps on stale arena gradients."""
         d = self.defer
-        d["wgrad"], d["wgrad_b"], d["colsum"], d["params"], d["armed"] = [], [], [], [], False
+        d["wgrad"], d["wgrad_b"], d["colsum"], d["reduce"], d["params"], d["armed"] = [], [], [], [], [], False
 
     def clear(self):
         self.fuse = None
@@ -175,6 +205,19 @@ def colsum_or_defer(x, M, N, ld, b, view_shape=None):
     return _ret(b, out, deferred=True)
 
 
+def reduce_defer_enabled():
+    """UNETR_AMD_REDUCE_DEFER=0 (A/B hook): every conv weight-gradient kernel launches its own partial-sum reduction again"""
+    return os.environ.get("UNETR_AMD_REDUCE_DEFER", "1") != "0"
+
+
+def _launch_reduces(rq):
+    """every queued weight-gradient reduction (dst[i] = sum over rows of part[row][i]) in ONE launch"""
+    arr = (_capi.ReduceProblem * len(rq))()
+    for i, (part, dst, n, rows) in enumerate(rq):
+        arr[i].part, arr[i].dst, arr[i].n, arr[i].rows = part.data_ptr(), dst.data_ptr(), n, rows
+    call("unetr_reduce_rows_grouped", arr, len(rq), _stream())
+
+
 def _launch_deferred(wq, cq, wbq=(), prec=0, fuse=None):
     if wbq and fuse is not None:
         # the optimizer rides on the launch: problems whose destination is a registered arena slice get AdamW in the epilogue
@@ -236,8 +279,11 @@ def flush_deferred(st=None):
     """Runs at the end of the backward pass (autograd engine callback) on the backward stream."""
     st = st if st is not None else _DEFAULT_STATE
     d = st.defer
-    wq, cq, wbq, params, prec = d["wgrad"], d["colsum"], d["wgrad_b"], d["params"], d["prec"]
+    wq, cq, wbq, params, prec, rq = d["wgrad"], d["colsum"], d["wgrad_b"], d["params"], d["prec"], d["reduce"]
     st.reset_deferred()
+    join_aux_streams()
+    if rq:
+        _launch_reduces(rq)
     _launch_deferred(wq, cq, wbq, prec, st.fuse)
     for p in params:
         for cb in st.ready_cb:
@@ -920,22 +966,43 @@ def conv3_dgrad_fused(dc1, dc3, w1, w3, dx, dims, prec):
     return rc == 0
 
 
-def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None):
-    """dw of the 3x3x3 conv; with dy3/out3 also the weight gradient of the 1x1x1 conv sharing the input x."""
+def conv3_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=None, dy3=None, out3=None, defer=None):
+    """dw of the 3x3x3 conv; with dy3/out3 also the weight gradient of the 1x1x1 conv sharing the input x.
+    defer = the ArenaState owning `out` (and `out3`): returns (dw, True) when the reduction of the partial sums was queued for the
+    end-of-backward grouped launch; plain calls return dw."""
+    want = defer is not None                 # such callers get (dw, queued)
     if _use_gemm_conv():
         if dy3 is not None:
             x32 = x if x.dtype == torch.float32 else x.float().contiguous()
             gemm(dy3.float() if dy3.dtype != torch.float32 else dy3, x32, out3, cout, cin, dims[0] * dims[1] * dims[2] * dims[3], lda=cout,
                  ldb=x32.stride(-2), ldc=cin, prec=_capi.PREC_F32, a_trans=True, b_trans=True)
-        return conv_wgrad(x, ldx, dy, lddy, dims, cin, cout, 3, prec, out=out)
+        r = conv_wgrad(x, ldx, dy, lddy, dims, cin, cout, 3, prec, out=out)
+        return (r, False) if want else r
     B, D, H, W = dims
     dw = out if out is not None else torch.empty(cout, cin, 3, 3, 3, dtype=torch.float32, device=x.device)
-    ws = workspace(x.device)
     x_f32 = int(prec == _capi.PREC_BF16 and x.dtype == torch.float32)
+    if defer is not None and reduce_defer_enabled():
+        # arena mode: the kernel leaves its per-workgroup partial sums in a buffer of its own and the reduction joins the ONE grouped
+        # reduce launch at the end of the backward pass (functional.flush_deferred)
+        rows = _capi.load().unetr_conv3_wgrad_rows(B, D, H, W, cin, cout, prec, x_f32, int(dy3 is not None))
+        n, n3 = 27 * cin * cout, (cin * cout if dy3 is not None else 0)
+        if rows > 0 and rows * (n + n3) * 4 <= (256 << 20):
+            part = torch.empty(rows * (n + n3), dtype=torch.float32, device=x.device)
+            got = ctypes.c_long(0)
+            rc = call_rc("unetr_conv3_wgrad_parts", x.data_ptr(), ldx, dy.data_ptr(), lddy, _p(dy3), cout, part.data_ptr(), part.numel() * 4,
+                         ctypes.byref(got), B, D, H, W, cin, cout, prec, x_f32, _stream())
+            if rc == 0:
+                g = got.value
+                defer.defer["reduce"].append((part, dw, n, g))
+                if dy3 is not None:
+                    defer.defer["reduce"].append((part[g * n:], out3, n3, g))
+                _arm_flush(defer)
+                return dw, True
+    ws = workspace(x.device)
     call("unetr_conv3_wgrad", x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(),
          dy3.data_ptr() if dy3 is not None else None, cout, out3.data_ptr() if out3 is not None else None,
          B, D, H, W, cin, cout, prec, x_f32, ws.data_ptr(), ws.numel() * 4, _stream())
-    return dw
+    return (dw, False) if want else dw
 
 
 def conv_pack(w, mode):
@@ -1083,7 +1150,22 @@ def tconv_bwd(x, ldx, xb, dy, lddy, w, dims, cin, cout, prec, need_dx):
     if prec == _capi.PREC_BF16 and dy.dtype != torch.bfloat16:
         dy = dy.to(torch.bfloat16).contiguous(); lddy = cout
     dx = tconv_dgrad(dy, lddy, w, dims, cin, cout, prec) if need_dx else None
-    dw = tconv_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=_gout(w))
+    gw = _gout(w)
+    st = _GRAD_SINK.get(w.data_ptr()) if gw is not None else None
+    if st is not None and reduce_defer_enabled():
+        # arena mode: the partial sums of the weight gradient stay in a buffer of their own; their reduction joins the grouped launch
+        # at the end of the backward pass
+        rows = _capi.load().unetr_tconv2_wgrad_rows(B, D, H, W, cin, cout)
+        n = cin * cout * 8
+        if rows > 0:
+            part = torch.empty(rows * n, dtype=torch.float32, device=x.device)
+            got = ctypes.c_long(0)
+            if call_rc("unetr_tconv2_wgrad_parts", x.data_ptr(), ldx, dy.data_ptr(), lddy, part.data_ptr(), part.numel() * 4, ctypes.byref(got),
+                       B, D, H, W, cin, cout, prec, _stream()) == 0:
+                st.defer["reduce"].append((part, gw, n, got.value))
+                _arm_flush(st)
+                return dx, _ret(w, gw, deferred=True)
+    dw = tconv_wgrad(x, ldx, dy, lddy, dims, cin, cout, prec, out=gw)
     return dx, _ret(w, dw)
 
 
@@ -1442,8 +1524,17 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     # conv3 (1x1x1)
     g3 = _gout(w3)
     dw3 = g3 if g3 is not None else torch.empty(cout, cin, 1, 1, 1, dtype=torch.float32, device=x.device)
+    # arena mode: the three weight gradients' partial-sum reductions join the grouped launch at the end of the backward pass
+    g1, g2 = _gout(w1), _gout(w2)
+    st = _GRAD_SINK.get(w1.data_ptr()) if (g1 is not None and g2 is not None and g3 is not None) else None
+    if st is not None and (_GRAD_SINK.get(w2.data_ptr()) is not st or _GRAD_SINK.get(w3.data_ptr()) is not st):
+        st = None
+    q1 = q2 = False
     # conv2
-    dw2 = conv3_wgrad(a1, cout, dc2, cout, dims, cout, cout, prec, out=_gout(w2))
+    if st is not None:
+        dw2, q2 = conv3_wgrad(a1, cout, dc2, cout, dims, cout, cout, prec, out=g2, defer=st)
+    else:
+        dw2 = conv3_wgrad(a1, cout, dc2, cout, dims, cout, cout, prec, out=g2)
     dc1 = None
     if in_fuse_level() & 2:
         # the backward sums of the first norm come out of the data-gradient conv's epilogue: no reduction pass over (da1, c1)
@@ -1454,7 +1545,10 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     if dc1 is None:
         da1 = conv3(dc2, cout, w2, dims, prec, mode=1)
         dc1, _ = instnorm_bwd(da1, cout, c1, s1, B, V, cout, True)
-    dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=_gout(w1), dy3=dc3, out3=dw3)
+    if st is not None:
+        dw1, q1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=g1, dy3=dc3, out3=dw3, defer=st)
+    else:
+        dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=g1, dy3=dc3, out3=dw3)
     dx = None
     if need_dx:
         dx = torch.empty(B, D, H, W, cin, dtype=act_dtype(prec), device=x.device)
@@ -1463,7 +1557,7 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
             gemm(dc3.float() if dc3.dtype != torch.float32 else dc3, w3, d32, B * V, cin, cout, lda=cout, ldb=cin, ldc=cin, prec=prec, b_trans=True)
             dx.copy_(d32)
             conv3(dc1, cout, w1, dims, prec, mode=1, out=dx, ldo=cin, accumulate=True)
-    return dx, dw1, dw2, dw3
+    return dx, dw1, dw2, dw3, (q1, q2)
 
 
 class ResBlockFn(torch.autograd.Function):
@@ -1485,8 +1579,8 @@ class ResBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, w1, w2, w3, *saved = ctx.saved_tensors
         ldx, dims, cin, cout, prec = ctx.meta
-        dx, dw1, dw2, dw3 = _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, ctx.needs_input_grad[0])
-        return dx, _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None, None
+        dx, dw1, dw2, dw3, (q1, q2) = _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, ctx.needs_input_grad[0])
+        return dx, _ret(w1, dw1, deferred=q1), _ret(w2, dw2, deferred=q2), _ret(w3, dw3, deferred=q1), None, None
 
 
 class TconvFn(torch.autograd.Function):
@@ -1551,10 +1645,10 @@ class UpBlockFn(torch.autograd.Function):
         ldi, dims, cin, C, prec = ctx.meta
         B, D, H, W = dims
         dims2 = (B, 2 * D, 2 * H, 2 * W)
-        dcat, dw1, dw2, dw3 = _resblock_bwd(dout, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True)
+        dcat, dw1, dw2, dw3, (q1, q2) = _resblock_bwd(dout, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True)
         dinp, dwt = tconv_bwd(inp, ldi, ctx.xb, dcat, 2 * C, wt, dims, cin, C, prec, ctx.needs_input_grad[0])
         dskip = dcat[..., C:] if ctx.needs_input_grad[1] else None
-        return dinp, dskip, dwt, _ret(w1, dw1), _ret(w2, dw2), _ret(w3, dw3), None, None
+        return dinp, dskip, dwt, _ret(w1, dw1, deferred=q1), _ret(w2, dw2, deferred=q2), _ret(w3, dw3, deferred=q1), None, None
 
 
 class OutConvFn(torch.autograd.Function):

@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 10
+#define UNETR_ABI_VERSION 11
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -139,6 +139,10 @@ int unetr_tconv2_wgrad(const void* x, long ldx, const void* dy, long ldy, float*
 int unetr_tconv2_dgrad(const void* dy, long ldy, const float* w, void* dx, long ldx, int accumulate,
                        int B, int D, int H, int W, int Cin, int Cout, int prec,
                        float* ws, size_t ws_bytes, void* stream);
+/* unetr_tconv2_wgrad without its reduce launch (see unetr_conv3_wgrad_parts): part [rows][Cin Cout 8] */
+long unetr_tconv2_wgrad_rows(int B, int D, int H, int W, int Cin, int Cout);
+int unetr_tconv2_wgrad_parts(const void* x, long ldx, const void* dy, long ldy, float* part, size_t part_bytes, long* rows_out,
+                             int B, int D, int H, int W, int Cin, int Cout, int prec, void* stream);
 int unetr_tconv2_fwd_supported(long M, int Cin, int Cout, long ldx, long ldy);
 int unetr_tconv2_wgrad_supported(long M, int Cin, int Cout, long ldx, long lddy);
 
@@ -284,6 +288,17 @@ int unetr_conv3_wgrad(const void* x, long ldx, const void* dy, long ldy, float* 
                       const void* dy3, long ldy3, float* dw3,
                       int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32 /* as in unetr_conv3_fwd_fused */,
                       float* ws, size_t ws_bytes, void* stream);
+/* The same weight gradients WITHOUT their reduce launch: the per-workgroup partial sums stay in `part` -- [rows][27 Cin Cout] followed,
+ * when dy3 is given, by [rows][Cin Cout]; *rows_out = rows written (= unetr_conv3_wgrad_rows for an unlimited buffer; fewer when
+ * part_bytes forces it) -- and are summed later by unetr_reduce_rows_grouped together with every other weight-gradient reduction
+ * of the backward pass. */
+long unetr_conv3_wgrad_rows(int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32, int has3);
+int unetr_conv3_wgrad_parts(const void* x, long ldx, const void* dy, long ldy, const void* dy3, long ldy3,
+                            float* part, size_t part_bytes, long* rows_out, int B, int D, int H, int W, int Cin, int Cout, int prec,
+                            int x_f32, void* stream);
+/* dst[i] = sum over rows g of part[g][i], i < n, for every problem, in one launch (fixed summation order) */
+typedef struct { const float* part; float* dst; long n; int rows; } unetr_reduce_problem;
+int unetr_reduce_rows_grouped(const unetr_reduce_problem* probs, int n, void* stream);
 /* probe of the ds_read_b64_tr_b16 lane map used by the bf16 weight-gradient kernel (test hook) */
 int unetr_debug_tr16(const void* in_u16_64x64, void* out_u16_64x4, void* stream);
 
