@@ -19,18 +19,38 @@ LN_EPS = 1e-5
 IN_EPS = 1e-5
 
 _WS = {}
-_WS_BYTES = 256 << 20
+_WS_BYTES = int(os.environ.get("UNETR_AMD_WS_MB", "256")) << 20     # largest users: split-K slabs (M x N x splits fp32), InstanceNorm
+                                                                     # partial rows, weight-gradient partials outside arena mode
+_WS_SHARED = {}                                                      # device index -> stream ids that use the device's shared buffer
+
+
+def share_workspace(stream):
+    """Declare that work on `stream` never runs concurrently with work on the device's default stream or on another stream declared
+    here -- the caller orders them with wait_stream / graph-replay order (train_step.side_stream: eager warm-up and graph capture
+    run there while the launching stream waits; replays are launched on the launching stream).  Such streams use ONE scratch buffer
+    per device instead of one each (256 MB per (device, stream) before: main + warm-up + capture = 768 MB)."""
+    _WS_SHARED.setdefault(stream.device.index, set()).add(stream.cuda_stream)
 
 
 def workspace(device):
     """Scratch for split-K slabs and reduction partials: one buffer per (device, stream) -- reuse inside a stream is
-    stream-ordered and therefore safe; two streams (e.g. two models stepping concurrently) never share one."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    stream-ordered and therefore safe; two streams (e.g. two models stepping concurrently) never share one -- except the streams
+    declared by share_workspace, which together with the default stream share the device's buffer."""
+    sid = torch.cuda.current_stream(device).cuda_stream
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if sid == 0 or sid in _WS_SHARED.get(idx, ()):
+        sid = 0
+    key = (device.type, idx, sid)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
+
+
+def release_workspaces():
+    """drop every scratch buffer (they are re-created on demand; captured graphs that baked a pointer must be dropped first)"""
+    _WS.clear()
 
 
 def _stream():

@@ -29,13 +29,14 @@ _SIDE = {}
 
 
 def side_stream(device=None):
-    """ONE side stream per device for every TrainStep of the process: eager warm-up and graph capture both run on it, so the
-    scratch workspace of that stream (functional.workspace: 256 MB per (device, stream)) is allocated once, during the eager
-    warm-up -- i.e. OUTSIDE any graph's private memory pool -- and shared by all steps and graphs."""
+    """ONE side stream per device for every TrainStep of the process: eager warm-up and graph capture both run on it; it shares the
+    device's scratch workspace with the default stream (functional.share_workspace), which is allocated during the eager warm-up
+    -- i.e. OUTSIDE any graph's private memory pool -- and used by all steps and graphs."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     st = _SIDE.get(idx)
     if st is None:
         st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+        Fn.share_workspace(st)          # ordered against the launching stream by construction: one scratch buffer for both
     return st
 
 
