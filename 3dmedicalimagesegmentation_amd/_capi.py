@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
-ABI_VERSION = 11       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 12       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -70,6 +70,10 @@ class ReduceProblem(ctypes.Structure):
     _fields_ = [("part", c_void_p), ("dst", c_void_p), ("n", c_long), ("rows", c_int)]
 
 
+class SplitProblem(ctypes.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_long), ("cols", c_long), ("second", c_int)]
+
+
 class ColsumProblem(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("ld", c_long), ("M", c_int), ("N", c_int), ("x_bf16", c_int)]
 
@@ -83,6 +87,7 @@ _SIGNATURES = {
     "unetr_gemm_bf16_ln_fwd": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_float, P, P, P, P, P, c_size_t, P],
     "unetr_cast_bf16": [P, P, c_long, P],
     "unetr_split_stack_bf16": [P, P, c_long, c_long, c_int, P],
+    "unetr_split_stack_bf16_grouped": [ctypes.POINTER(SplitProblem), c_int, P],
     "unetr_ln_gemm_bf16": [ctypes.POINTER(LnGemmDesc), P],
     "unetr_attention_bf16_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "unetr_attention_bf16_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],

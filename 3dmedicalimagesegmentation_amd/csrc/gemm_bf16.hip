@@ -818,6 +818,37 @@ __global__ void __launch_bounds__(256) split_stack_kernel(const float* __restric
     }
 }
 
+// every stack of a backward pass in one launch (98 launches of ~5 us each before: one per operand)
+constexpr int SS_MAX = 64;
+struct SsProblem { const float* src; uint16_t* dst; long n8; int second; int blk0; int nblk; };
+struct SsArgs { int n; SsProblem p[SS_MAX]; };
+__global__ void __launch_bounds__(256) split_stack_grouped_kernel(SsArgs a) {
+    int pi = 0, hi_ = a.n - 1;
+    while (pi < hi_) {
+        const int mid = (pi + hi_ + 1) >> 1;
+        if ((int)blockIdx.x >= a.p[mid].blk0) pi = mid; else hi_ = mid - 1;
+    }
+    const SsProblem& pr = a.p[pi];
+    const float* __restrict__ src = pr.src;
+    uint16_t* __restrict__ dst = pr.dst;
+    const long n8 = pr.n8, plane = n8 * 8;
+    const int second = pr.second;
+    for (long i = ((long)blockIdx.x - pr.blk0) * 256L + threadIdx.x; i < n8; i += (long)pr.nblk * 256) {
+        const f32x4 x = ((const f32x4*)src)[2 * i], y = ((const f32x4*)src)[2 * i + 1];
+        float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]}, r[8];
+        const u32x4 hi = PrecBF16::pack(v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[2 * e] = v[2 * e] - __builtin_bit_cast(float, hi[e] << 16);
+            r[2 * e + 1] = v[2 * e + 1] - __builtin_bit_cast(float, hi[e] & 0xffff0000u);
+        }
+        const u32x4 lo = PrecBF16::pack(r);
+        ((u32x4*)dst)[i] = hi;
+        ((u32x4*)(dst + plane))[i] = second ? lo : hi;
+        ((u32x4*)(dst + 2 * plane))[i] = second ? hi : lo;
+    }
+}
+
 __global__ void __launch_bounds__(256) cast_bf16_tail_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long beg, long n) {
     const long i = beg + blockIdx.x * 256L + threadIdx.x;
     if (i < n) { __bf16 h = (__bf16)src[i]; dst[i] = __builtin_bit_cast(uint16_t, h); }
@@ -947,6 +978,26 @@ extern "C" int unetr_split_stack_bf16(const float* src, void* dst, long rows, lo
     if ((n & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return UNETR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(split_stack_kernel, dim3((unsigned)std::min<long>(cdiv(n / 8, 256), 4096)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst,
                        n / 8, n, second);
+    return unetr_check_launch();
+}
+
+extern "C" int unetr_split_stack_bf16_grouped(const unetr_split_problem* probs, int n, void* stream) {
+    if (!probs || n <= 0) return UNETR_ERR_ARG;
+    for (int base = 0; base < n; base += SS_MAX) {
+        SsArgs a;
+        a.n = std::min(SS_MAX, n - base);
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const unetr_split_problem& q = probs[base + i];
+            const long ne = q.rows * q.cols;
+            if (!q.src || !q.dst || q.rows <= 0 || q.cols <= 0) return UNETR_ERR_ARG;
+            if ((ne & 7) || (((uintptr_t)q.src | (uintptr_t)q.dst) & 15)) return UNETR_ERR_UNSUPPORTED;
+            const int nb = (int)std::min<long>(cdiv(ne / 8, 256), 1024);
+            a.p[i] = SsProblem{q.src, (uint16_t*)q.dst, ne / 8, q.second, blocks, nb};
+            blocks += nb;
+        }
+        hipLaunchKernelGGL(split_stack_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return unetr_check_launch();
 }
 

@@ -267,7 +267,7 @@ def _launch_deferred(wq, cq, wbq=(), prec=0, fuse=None):
         # bf16x3: dW = dY^T X over (hi, lo) halves is the bf16 kernel's contraction over three times the rows of the stacks
         # [dYh; dYh; dYl] / [Xh; Xl; Xh] (two streaming split launches per problem) -- the generic fp32-storage grouped kernel spends
         # 2.2 ms per step on these 76 GF, the bf16 kernel 0.2 ms per 432 rows; with an optimizer epilogue armed it rides here too
-        rest, stacked = [], []
+        rest, stacked, splits = [], [], []
         for dy, x, out in wq:
             M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
             if (M * N) % 8 or (M * K) % 8 or (3 * M) % 8 or N % 8 or K % 8 or not dy.is_contiguous() or not x.is_contiguous():
@@ -275,11 +275,14 @@ def _launch_deferred(wq, cq, wbq=(), prec=0, fuse=None):
                 continue
             dys = torch.empty(3 * M, N, dtype=torch.bfloat16, device=dy.device)
             xs = torch.empty(3 * M, K, dtype=torch.bfloat16, device=dy.device)
-            call("unetr_split_stack_bf16", dy.data_ptr(), dys.data_ptr(), M, N, 0, _stream())
-            call("unetr_split_stack_bf16", x.data_ptr(), xs.data_ptr(), M, K, 1, _stream())
+            splits += [(dy, dys, M, N, 0), (x, xs, M, K, 1)]
             stacked.append((dys, xs, out))
         wq = rest
         if stacked:
+            arr = (_capi.SplitProblem * len(splits))()
+            for i, (src, dst, rows, cols, second) in enumerate(splits):
+                arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols, arr[i].second = src.data_ptr(), dst.data_ptr(), rows, cols, second
+            call("unetr_split_stack_bf16_grouped", arr, len(splits), _stream())          # every stack of the pass in one launch
             _launch_deferred((), (), stacked, prec, fuse)
     if wq:
         arr = (_capi.GroupedProblem * len(wq))()

@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 11
+#define UNETR_ABI_VERSION 12
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -97,6 +97,9 @@ int unetr_cast_bf16(const float* src, void* dst, long n, void* stream);
  * (the dY side), second == 1: [hi; lo; hi] (the X side) -- so that dY^T X over the stacked rows = hi*hi + hi*lo + lo*hi on the
  * bf16 grouped weight-gradient kernel (unetr_gemm_bf16_grouped_wgrad[_adamw]).  rows * cols % 8 == 0, 16-byte aligned. */
 int unetr_split_stack_bf16(const float* src, void* dst, long rows, long cols, int second, void* stream);
+/* every stack of a backward pass in one launch */
+typedef struct { const float* src; void* dst; long rows, cols; int second; } unetr_split_problem;
+int unetr_split_stack_bf16_grouped(const unetr_split_problem* probs, int n, void* stream);
 /* out = a + b (fp32, n % 4 == 0, 16-byte aligned) and out_bf16 = bf16(out) (may be NULL): the sum autograd forms for a hidden
  * state with two consumers (unetr.py:197-201: hidden states 3, 6, 9 feed the next block AND encoder2-4) */
 int unetr_add_cast_bf16(const float* a, const float* b, float* out, void* out_bf16, long n, void* stream);
