@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
-ABI_VERSION = 12       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 13       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -122,6 +122,8 @@ _SIGNATURES = {
     "unetr_conv3_fwd_parts": [P, c_long, P, P, c_long, P, P, P, c_long, P, ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_conv3_dgrad_stats": [P, c_long, P, P, c_long, P, c_long, P, P, ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_instnorm_apply_fin": [P, c_long, P, c_int, P, c_long, P, c_int, P, P, c_float, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
+    "unetr_instnorm_apply_fin_img": [P, c_long, P, c_int, P, c_int, P, P, c_int, P, P, c_float, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
+    "unetr_instnorm_bwd_img": [P, c_long, P, c_long, P, P, c_int, P, P, P, c_long, P, ctypes.POINTER(c_int), c_int, c_long, c_int, c_int, P, c_size_t, c_int, P],
     "unetr_instnorm_bwd_apply_fin": [P, c_long, P, c_long, P, P, c_long, P, P, c_int, c_int, P, c_long, P, c_long, c_int, c_long, c_int, c_int, c_int, P],
     "unetr_conv3_wgrad_parts": [P, c_long, P, c_long, P, c_long, P, c_size_t, ctypes.POINTER(c_long), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "unetr_tconv2_wgrad_parts": [P, c_long, P, c_long, P, c_size_t, ctypes.POINTER(c_long), c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

@@ -1012,12 +1012,14 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                     }
             }
             if constexpr (has3) {
+                if (y3) {                                 // (y3 == nullptr: the caller only wants the branch's statistics)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    YT* q = y3 + (yrow[i] - y);          // same pitch as y (checked by the host)
+                    for (int i = 0; i < 4; ++i) {
+                        YT* q = y3 + (yrow[i] - y);          // same pitch as y (checked by the host)
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j)
-                        if (okv[i]) Io<YT>::st4(q + j * 16, acc3[i][j]);
+                        for (int j = 0; j < NTB; ++j)
+                            if (okv[i]) Io<YT>::st4(q + j * 16, acc3[i][j]);
+                    }
                 }
                 stats_add<NTB>(acc3, okv, rt1, rt2);
             }
@@ -1034,12 +1036,14 @@ conv3_fwd_pipe_kernel(const void* __restrict__ x, long ldx, const char* __restri
                         P::mma(a3[i][j], w3res[j], a);
                     }
                 }
+                if (y3) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    YT* q = y3 + (yrow[i] - y);
+                    for (int i = 0; i < 4; ++i) {
+                        YT* q = y3 + (yrow[i] - y);
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j)
-                        if (okv[i]) Io<YT>::st4(q + j * 16, a3[i][j]);
+                        for (int j = 0; j < NTB; ++j)
+                            if (okv[i]) Io<YT>::st4(q + j * 16, a3[i][j]);
+                    }
                 }
                 stats_add<NTB>(a3, okv, rt1, rt2);
             }
@@ -1172,7 +1176,7 @@ conv3_c1_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wp
         for (int i = 0; i < 4; ++i) {
             if (okv[i]) {
                 Io<uint16_t>::st4(y + (tb + (long)i * W) * ldy + 4 * g, acc[i][0]);
-                if (has3) Io<uint16_t>::st4(y3 + (tb + (long)i * W) * ldy + 4 * g, acc3[i][0]);
+                if (has3 && y3) Io<uint16_t>::st4(y3 + (tb + (long)i * W) * ldy + 4 * g, acc3[i][0]);      // (y3 == nullptr: statistics only)
             }
         }
         stats_add<1>(acc, okv, rs1, rs2);
@@ -2158,8 +2162,11 @@ extern "C" int unetr_conv3_fwd_parts(const void* x, long ldx, const void* wpack,
                                      const void* w3pack, void* y3, long ldy3, float* part3, int* rows_out,
                                      int B, int D, int H, int W, int Cin, int Cout, int prec, int x_f32, void* stream) {
     if (!x || !wpack || !y || !part || !rows_out || B <= 0) return UNETR_ERR_ARG;
-    if ((w3pack != nullptr) != (y3 != nullptr) || (w3pack != nullptr) != (part3 != nullptr)) return UNETR_ERR_ARG;
-    if (Cout % 16 || (w3pack && ldy3 != ldy)) return UNETR_ERR_UNSUPPORTED;
+    // y3 may be NULL with w3pack given: only the statistics of the 1x1x1 branch are wanted (the block on the image: its consumers
+    // form the branch from the image, unetr_instnorm_apply_fin_img)
+    if ((y3 != nullptr && w3pack == nullptr) || (w3pack != nullptr) != (part3 != nullptr)) return UNETR_ERR_ARG;
+    if (Cout % 16 || (y3 && ldy3 != ldy)) return UNETR_ERR_UNSUPPORTED;
+    if (!y3) ldy3 = ldy;
     hipStream_t st = (hipStream_t)stream;
     FuseArgs fz{part, w3pack, y3, ldy3, part3, 0, 0};
     int rc;

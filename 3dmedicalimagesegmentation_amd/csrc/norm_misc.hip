@@ -935,6 +935,277 @@ in_bwd_apply_fin_kernel(const T* __restrict__ dy, long lddy, const T* __restrict
     }
 }
 
+// ---- the residual block on the IMAGE (encoder1: UnetrBasicBlock(in_channels, feature_size), unetr.py:90-98): its 1x1x1 branch
+// c3[v][c] = sum_ci w3[c][ci] * img[v][ci] has <= 4 input channels, so every pass that reads c3 (32 B per voxel in bf16 storage, 64
+// in fp32) can form it from the image (4 - 16 B per voxel) instead, and c3 / its gradient are never stored: per step that is six
+// full-resolution tensors (c3 written by the conv, read by the block-end apply, the backward reduction and the backward apply;
+// dc3 written by the backward apply and read by the weight gradient) that do not move.  The value is formed exactly as the conv
+// kernel forms it before its store: operands rounded to the mode's operand type, fp32 products, result rounded to the storage type
+// (bit-identical to the stored tensor for one input channel).  dw3 = sum_v dc3[v][c] * img[v][ci] comes out of the backward apply
+// as per-block partial rows.
+template <class T, int W, int CIN>
+struct ImgBranch {
+    float w[W][CIN];
+    const float* img;
+    int cin;
+    static __device__ __forceinline__ float rnd(float v) {
+        if constexpr (Io<T>::B16) { const __bf16 h = (__bf16)v; return (float)h; }
+        return v;
+    }
+    // (CIN = 1 or 4 at compile time; a 2- or 3-channel image runs the 4-channel instance with zero weights for the missing ones)
+    __device__ __forceinline__ void init(const float* __restrict__ w3, int cin_, int c0, const float* __restrict__ img_b) {
+        img = img_b; cin = cin_;
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) w[e][ci] = ci < cin_ ? rnd(w3[(long)(c0 + e) * cin_ + ci]) : 0.f;
+    }
+    // the voxel's image values, already rounded to the operand type
+    __device__ __forceinline__ void load(long v, float (&xi)[CIN]) const {
+        if constexpr (CIN == 1) xi[0] = img[v];
+        else {
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) xi[ci] = ci < cin ? img[v * cin + ci] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void value(float (&xi)[CIN], float (&t2)[W]) const {
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) xi[ci] = rnd(xi[ci]);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float a = w[e][0] * xi[0];
+#pragma unroll
+            for (int ci = 1; ci < CIN; ++ci) a = fmaf(w[e][ci], xi[ci], a);
+            t2[e] = rnd(a);
+        }
+    }
+};
+
+template <class T, int U, int CIN>
+__global__ void __launch_bounds__(IN_FIN_NT)
+in_apply_fin_img_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ pa, int rows_a, const float* __restrict__ img, int cin,
+                        const float* __restrict__ w3, const float* __restrict__ pb, int rows_b, float* __restrict__ stats_a,
+                        float* __restrict__ stats_b, float eps, T* __restrict__ y, long ldy, long V, long vpb, int C, int lrelu) {
+    constexpr int W = Io<T>::W;
+    __shared__ double red[IN_FIN_NT];
+    __shared__ double sums[4 * 128];
+    __shared__ float sta[2 * 128], stb[2 * 128];
+    const int cvn = C / W, nphase = IN_FIN_NT / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    T* py = y + ((long)b * V) * ldy + W * cv;
+    ImgBranch<T, W, CIN> br;
+    br.init(w3, cin, W * cv, img + (long)b * V * cin);
+    in_fin_sums(pa + (long)b * rows_a * 2 * C, rows_a, pb + (long)b * rows_b * 2 * C, rows_b, 2 * C, red, sums);
+    in_fin_stats(sums, C, V, eps, sta, stats_a + (long)b * C * 2);
+    in_fin_stats(sums + 2 * C, C, V, eps, stb, stats_b + (long)b * C * 2);
+    __syncthreads();
+    float a1[W], o1[W], a2[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        a1[e] = sta[2 * (W * cv + e) + 1]; o1[e] = -sta[2 * (W * cv + e)] * a1[e];
+        a2[e] = stb[2 * (W * cv + e) + 1]; o1[e] -= stb[2 * (W * cv + e)] * a2[e];
+    }
+    const float slope = lrelu ? 0.01f : 1.f;
+    for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+        u32x4 rt[U];
+        float xi[U][CIN];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long vv = v + (long)u * nphase;
+            live[u] = vv < v1;
+            const long vc = live[u] ? vv : v;
+            rt[u] = *(const u32x4*)(px + vc * ldx);
+            br.load(vc, xi[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float t[W], t2[W], o[W];
+            Io<T>::unpack(rt[u], t);
+            br.value(xi[u], t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float n = fmaf(t[e], a1[e], o1[e]);
+                n = fmaf(t2[e], a2[e], n);
+                o[e] = n > 0.f ? n : slope * n;
+            }
+            if (live[u]) Io<T>::stw(py + (v + (long)u * nphase) * ldy, o);
+        }
+    }
+}
+
+// backward stage 1 of the same block end (in_bwd_reduce_kernel<T, true, U> with the second branch formed from the image)
+template <class T, int U, int CIN>
+__global__ void __launch_bounds__(256)
+in_bwd_reduce_img_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
+                         const float* __restrict__ img, int cin, const float* __restrict__ w3, const float* __restrict__ sb, long V, long vpb,
+                         int C, int lrelu, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int W = Io<T>::W;
+    const int cvn = C / W, nphase = 256 / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    float acc[3][W];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[s][e] = 0.f;
+    if (ph < nphase) {
+        const float* s1 = sa + ((long)b * C + W * cv) * 2;
+        const float* s2 = sb + ((long)b * C + W * cv) * 2;
+        float a1[W], o1[W], a2[W], o2[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            a1[e] = s1[2 * e + 1]; o1[e] = -s1[2 * e] * a1[e];
+            a2[e] = s2[2 * e + 1]; o2[e] = -s2[2 * e] * a2[e];
+        }
+        ImgBranch<T, W, CIN> br;
+        br.init(w3, cin, W * cv, img + (long)b * V * cin);
+        const float slope = lrelu ? 0.01f : 1.f;
+        const T* pg = dy + ((long)b * V) * lddy + W * cv;
+        const T* px = x + ((long)b * V) * ldx + W * cv;
+        for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+            u32x4 rg[U], rt[U];
+            float xi[U][CIN];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long vv = v + (long)u * nphase;
+                live[u] = vv < v1;
+                const long vc = live[u] ? vv : v;
+                rg[u] = *(const u32x4*)(pg + vc * lddy);
+                rt[u] = *(const u32x4*)(px + vc * ldx);
+                br.load(vc, xi[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float g[W], t[W], t2[W];
+                Io<T>::unpack(rg[u], g);
+                Io<T>::unpack(rt[u], t);
+                br.value(xi[u], t2);
+                if (live[u]) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                        const float n1 = fmaf(t[e], a1[e], o1[e]);
+                        const float n2 = fmaf(t2[e], a2[e], o2[e]);
+                        const float ge = (n1 + n2) > 0.f ? g[e] : slope * g[e];
+                        acc[0][e] += ge;
+                        acc[1][e] = fmaf(ge, n1, acc[1][e]);
+                        acc[2][e] = fmaf(ge, n2, acc[2][e]);
+                    }
+                }
+            }
+        }
+    }
+    in_block_reduce<3, W>(acc, cvn, nphase, lds, part + ((long)b * gridDim.x + blockIdx.x) * 3 * C, C);
+}
+
+// backward stage 2: dx of the 3x3x3 branch; the 1x1x1 branch's gradient dc3 is formed per voxel, multiplied with the image and
+// summed: dw3_part[(b * gridDim.x + blockIdx.x)][C][cin] (rows for unetr_reduce_rows_grouped); dc3 itself is never stored
+template <class T, int U, int CIN>
+__global__ void __launch_bounds__(IN_FIN_NT)
+in_bwd_apply_fin_img_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
+                            const float* __restrict__ img, int cin, const float* __restrict__ w3, const float* __restrict__ sb,
+                            const float* __restrict__ part, int nrows, T* __restrict__ dx, long lddx, float* __restrict__ dw3_part,
+                            long V, long vpb, int C, int lrelu) {
+    constexpr int W = Io<T>::W;
+    __shared__ double red[IN_FIN_NT];
+    __shared__ double sums[IN_FIN_MAXCOL];
+    __shared__ float wsum[(IN_FIN_NT / 64) * 128 * CIN];        // [wave][C][CIN]
+    const int cvn = C / W, nphase = IN_FIN_NT / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    in_fin_sums(part + (long)b * nrows * 3 * C, nrows, nullptr, 0, 3 * C, red, sums);
+    const float* s1 = sa + ((long)b * C + W * cv) * 2;
+    const float* s2 = sb + ((long)b * C + W * cv) * 2;
+    float a1[W], o1[W], k0[W], k1[W], a2[W], o2[W], q0[W], q2[W];
+    const double iv = 1.0 / (double)V;
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const int c = W * cv + e;
+        const float m0 = (float)(sums[c] * iv), m1 = (float)(sums[C + c] * iv), m2 = (float)(sums[2 * C + c] * iv);
+        a1[e] = s1[2 * e + 1]; o1[e] = -s1[2 * e] * a1[e];
+        k0[e] = a1[e] * m0; k1[e] = a1[e] * m1;
+        a2[e] = s2[2 * e + 1]; o2[e] = -s2[2 * e] * a2[e];
+        q0[e] = a2[e] * m0; q2[e] = a2[e] * m2;
+    }
+    ImgBranch<T, W, CIN> br;
+    br.init(w3, cin, W * cv, img + (long)b * V * cin);
+    float dwa[W][CIN];
+#pragma unroll
+    for (int e = 0; e < W; ++e)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) dwa[e][ci] = 0.f;
+    const float slope = lrelu ? 0.01f : 1.f;
+    const T* pg = dy + ((long)b * V) * lddy + W * cv;
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    T* pd = dx + ((long)b * V) * lddx + W * cv;
+    for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+        u32x4 rg[U], rt[U];
+        float xi[U][CIN];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long vv = v + (long)u * nphase;
+            live[u] = vv < v1;
+            const long vc = live[u] ? vv : v;
+            rg[u] = *(const u32x4*)(pg + vc * lddy);
+            rt[u] = *(const u32x4*)(px + vc * ldx);
+            br.load(vc, xi[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float g[W], t[W], t2[W], o[W];
+            Io<T>::unpack(rg[u], g);
+            Io<T>::unpack(rt[u], t);
+            br.value(xi[u], t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float n1 = fmaf(t[e], a1[e], o1[e]);
+                const float n2 = fmaf(t2[e], a2[e], o2[e]);
+                const float ge = (n1 + n2) > 0.f ? g[e] : slope * g[e];
+                o[e] = fmaf(a1[e], ge, -k0[e]) - k1[e] * n1;
+                // the gradient of the 1x1x1 branch as the weight-gradient kernel would have read it back: rounded to the storage type
+                float p = ImgBranch<T, W, CIN>::rnd(fmaf(a2[e], ge, -q0[e]) - q2[e] * n2);
+                p = live[u] ? p : 0.f;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) dwa[e][ci] = fmaf(p, xi[u][ci], dwa[e][ci]);      // (xi was rounded by value())
+            }
+            if (live[u]) Io<T>::stw(pd + (v + (long)u * nphase) * lddx, o);
+        }
+    }
+    // block sum of dwa over the voxel phases: lanes of a wave that share cv (cvn <= 64 divides 64: lane % cvn), then the waves in
+    // order through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < W; ++e)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            float t = dwa[e][ci];
+            for (int o_ = cvn; o_ < 64; o_ <<= 1) t += __shfl_xor(t, o_, 64);
+            dwa[e][ci] = t;
+        }
+    if (lane < cvn) {
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) wsum[(wave * 128 + W * lane + e) * CIN + ci] = dwa[e][ci];
+    }
+    __syncthreads();
+    float* prow = dw3_part + ((long)b * gridDim.x + blockIdx.x) * C * cin;
+    for (int i = threadIdx.x; i < C * cin; i += IN_FIN_NT) {
+        const int c = i / cin, ci = i - c * cin;
+        float t = 0.f;
+        for (int wv_ = 0; wv_ < IN_FIN_NT / 64; ++wv_) t += wsum[(wv_ * 128 + c) * CIN + ci];
+        prow[i] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------ layout moves
 // per batch: src [R, Ccols] (pitch lds_) -> dst [Ccols, R] (pitch ldd)
 template <class TS, class TD>
@@ -1557,9 +1828,13 @@ extern "C" int unetr_instnorm_apply_fin(const void* x, long ldx, const float* pa
     long vpb; int nchunk;
     hipStream_t st = (hipStream_t)stream;
     if (x2) {
-        in_chunks(V, B, 2 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
-        ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_fin_kernel<AT, true, 2>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, st, (const AT*)x, ldx, part_a, rows_a,
-                                               (const AT*)x2, ldx2, part_b, rows_b, stats_a, stats_b, eps, (AT*)y, ldy, V, vpb, C, lrelu));
+        int u = 2;                           // voxels in flight per thread (2 / 3 / 4 measured inside the step: 63.7 / 66.4 / 63.4 us per step)
+        if (const char* e = getenv("UNETR_IN_U_FWD2")) { const int v = atoi(e); if (v >= 2 && v <= 4) u = v; }
+        in_chunks(V, B, u * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
+#define FWD2(U_) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_fin_kernel<AT, true, U_>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, st, (const AT*)x, ldx, part_a, rows_a, \
+                                                       (const AT*)x2, ldx2, part_b, rows_b, stats_a, stats_b, eps, (AT*)y, ldy, V, vpb, C, lrelu))
+        if (u == 2) FWD2(2); else if (u == 3) FWD2(3); else FWD2(4);
+#undef FWD2
     } else {
         in_chunks(V, B, 4 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
         ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_fin_kernel<AT, false, 4>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, st, (const AT*)x, ldx, part_a, rows_a,
@@ -1593,6 +1868,57 @@ extern "C" int unetr_instnorm_bwd_apply_fin(const void* dy, long lddy, const voi
     return unetr_check_launch();
 }
 
+/* The block end of the residual block on the image (<= 4 input channels): y = lrelu(norm(x) + norm(c3)) with c3 = conv1x1x1(img; w3)
+ * formed per voxel from the image instead of read from memory (see ImgBranch).  part_b = the partial rows of c3's statistics. */
+extern "C" int unetr_instnorm_apply_fin_img(const void* x, long ldx, const float* part_a, int rows_a, const float* img, int Cin, const float* w3,
+                                            const float* part_b, int rows_b, float* stats_a, float* stats_b, float eps,
+                                            void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream) {
+    if (!x || !part_a || !stats_a || !y || !img || !w3 || !part_b || !stats_b || rows_a <= 0 || rows_b <= 0 || B <= 0 || V <= 0) return UNETR_ERR_ARG;
+    const int W = act16 ? 8 : 4;
+    if (Cin < 1 || Cin > 4 || !in_fin_ok(C, W, 2) || (ldx % W) || (ldy % W) || B > 65535 || 64 % (C / W)) return UNETR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return UNETR_ERR_UNSUPPORTED;
+    const int cvn = C / W;
+    long vpb; int nchunk;
+    in_chunks(V, B, 2 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
+#define IMG_APPLY(CIN_) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_apply_fin_img_kernel<AT, 2, CIN_>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, (hipStream_t)stream, \
+                                                              (const AT*)x, ldx, part_a, rows_a, img, Cin, w3, part_b, rows_b, stats_a, stats_b, eps, (AT*)y, ldy, V, vpb, C, lrelu))
+    if (Cin == 1) IMG_APPLY(1); else IMG_APPLY(4);
+#undef IMG_APPLY
+    return unetr_check_launch();
+}
+
+/* backward of the same block end: dx of the 3x3x3 branch, and the weight gradient of the 1x1x1 branch as partial rows
+ * dw3_part [*rows_out][C][Cin] (caller-allocated for UNETR_IN_IMG_MAX_ROWS rows) for unetr_reduce_rows_grouped; the branch's
+ * feature-map gradient is never stored.  ws: >= B * 1024 * 3 * C floats. */
+extern "C" int unetr_instnorm_bwd_img(const void* dy, long lddy, const void* x, long ldx, const float* sa, const float* img, int Cin,
+                                      const float* w3, const float* sb, void* dx, long lddx, float* dw3_part, int* rows_out,
+                                      int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, int act16, void* stream) {
+    if (!dy || !x || !sa || !img || !w3 || !sb || !dx || !dw3_part || !rows_out || B <= 0 || V <= 0) return UNETR_ERR_ARG;
+    if (int e = in_check(C, ldx, act16)) return e;
+    const int W = act16 ? 8 : 4;
+    if (Cin < 1 || Cin > 4 || !in_fin_ok(C, W, 3) || (lddy % W) || (lddx % W) || B > 65535 || 64 % (C / W)) return UNETR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) != 0) return UNETR_ERR_UNSUPPORTED;
+    const int cvn = C / W, nphase = 256 / cvn;
+    const long step = 2L * nphase;
+    long vpb = std::max<long>(2 * step, cdiv(cdiv((long)V * B, 768L), step) * step);
+    const int nchunk = (int)cdiv(V, vpb);
+    if (!ws || (size_t)B * nchunk * 3 * C * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+#define IMG_RED(CIN_) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_reduce_img_kernel<AT, 2, CIN_>), dim3(nchunk, B), dim3(256), (size_t)3 * nphase * C * 4, st, \
+                                                            (const AT*)dy, lddy, (const AT*)x, ldx, sa, img, Cin, w3, sb, V, vpb, C, lrelu, ws))
+    if (Cin == 1) IMG_RED(1); else IMG_RED(4);
+#undef IMG_RED
+    long vpa; int nca;
+    in_chunks(V, B, 1 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpa, nca);
+    if ((long)nca * B > UNETR_IN_IMG_MAX_ROWS) return UNETR_ERR_UNSUPPORTED;
+#define IMG_BAPPLY(CIN_) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_apply_fin_img_kernel<AT, 1, CIN_>), dim3(nca, B), dim3(IN_FIN_NT), 0, st, (const AT*)dy, lddy, \
+                                                               (const AT*)x, ldx, sa, img, Cin, w3, sb, ws, nchunk, (AT*)dx, lddx, dw3_part, V, vpa, C, lrelu))
+    if (Cin == 1) IMG_BAPPLY(1); else IMG_BAPPLY(4);
+#undef IMG_BAPPLY
+    *rows_out = nca * B;
+    return unetr_check_launch();
+}
+
 extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const float* sa,
                                   const void* x2, long ldx2, const float* sb, void* dx, long lddx, void* dx2, long lddx2,
                                   int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, int act16, void* stream) {
@@ -1603,7 +1929,9 @@ extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long
     // about three blocks per CU, each at least two full iterations of its threads (a fixed 1024-voxel block left the 12^3 x
     // 128-channel layer on TWO blocks: 51 us for 0.9 MB); offsets inside a block are 32-bit
     const int cvn = C / W, nphase = 256 / cvn;
-    const int UD = 2, US = 4;                    // voxels in flight per thread: dual / single form
+    int UD = 2;                                  // voxels in flight per thread: dual / single form
+    const int US = 4;
+    if (const char* e = getenv("UNETR_IN_U_RED2")) { const int v = atoi(e); if (v >= 2 && v <= 4) UD = v; }
     const long step = (long)(x2 ? UD : US) * nphase;
     long vpb = std::max<long>(2 * step, cdiv(cdiv((long)V * B, 768L), step) * step);
     const long ldmax = std::max(std::max(lddy, ldx), x2 ? ldx2 : 0L);
@@ -1617,7 +1945,7 @@ extern "C" int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long
     const size_t lds_bytes = (size_t)3 * nphase * C * 4;
 #define IN_RED(DUAL_, U_) ACT_DISPATCH(act16, hipLaunchKernelGGL((in_bwd_reduce_kernel<AT, DUAL_, U_>), dim3(nchunk, B), dim3(256), lds_bytes, st, (const AT*)dy, lddy, \
                                                                  (const AT*)x, ldx, sa, (const AT*)x2, ldx2, sb, V, vpb, C, lrelu, ws))
-    if (x2) IN_RED(true, UD); else IN_RED(false, US);
+    if (x2) { if (UD == 2) IN_RED(true, 2); else if (UD == 3) IN_RED(true, 3); else IN_RED(true, 4); } else IN_RED(false, 4);
 #undef IN_RED
     // the finalize of the partial sums rides in the prologue of the apply kernel where that form exists (UNETR_IN_FIN=0: the
     // separate finalize launch, kept for A/B measurements and as the route for shapes the folded form declines)

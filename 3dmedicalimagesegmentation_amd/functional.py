@@ -904,9 +904,15 @@ def in_fuse_level():
     return int(os.environ.get("UNETR_AMD_IN_FUSE", "3"))
 
 
-def conv3_parts(x, ldx, w, w3, dims, prec):
+def img_branch_enabled():
+    """UNETR_AMD_IMG_BRANCH=0 (A/B hook): the residual block on the image stores and re-reads its 1x1x1 branch like every other block"""
+    return os.environ.get("UNETR_AMD_IMG_BRANCH", "1") != "0"
+
+
+def conv3_parts(x, ldx, w, w3, dims, prec, store3=True):
     """conv3_fused without the statistics finalize: returns (c, part, c3, part3, rows) -- part* = InstanceNorm partial rows
-    [B, rows, 2, Cout] that instnorm_apply_fin reduces in its prologue -- or None when the shape takes another route."""
+    [B, rows, 2, Cout] that instnorm_apply_fin reduces in its prologue -- or None when the shape takes another route.
+    store3=False: the 1x1x1 branch is not stored (c3 is None), only its statistics rows are formed."""
     B, D, H, W = dims
     cout, cin = w.shape[0], w.shape[1]
     if _use_gemm_conv() or cout % 16 != 0 or cout > 128 or int(os.environ.get("UNETR_AMD_CONV_FUSE", "2")) < 2:
@@ -920,7 +926,7 @@ def conv3_parts(x, ldx, w, w3, dims, prec):
     wp3 = c3 = part3 = None
     if w3 is not None:
         wp3 = conv_pack_get(w3, 2, prec)
-        c3 = torch.empty(B, D, H, W, cout, dtype=adt, device=dev)
+        c3 = torch.empty(B, D, H, W, cout, dtype=adt, device=dev) if store3 else None
         part3 = torch.empty(B, CONV3_MAX_ROWS, 2, cout, dtype=torch.float32, device=dev)
     rows = ctypes.c_int(0)
     rc = call_rc("unetr_conv3_fwd_parts", x.data_ptr(), ldx, wp.data_ptr(), c.data_ptr(), cout, part.data_ptr(), _p(wp3), _p(c3), cout,
@@ -940,6 +946,33 @@ def instnorm_apply_fin(x, part, rows, B, V, C, lrelu, x2=None, part_b=None, rows
     if rc != 0:
         return None
     return y, sa, sb
+
+
+IN_IMG_MAX_ROWS = 512       # = UNETR_IN_IMG_MAX_ROWS
+
+
+def instnorm_apply_fin_img(x, part, rows, img, cin, w3, part_b, rows_b, B, V, C, out=None, ldo=None):
+    """block end of the residual block on the image: lrelu(norm(x) + norm(conv1x1x1(img; w3))) with the 1x1x1 branch formed from the
+    image in the kernel; returns (y, stats, stats_b) or None"""
+    y = torch.empty_like(x) if out is None else out
+    sa = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    sb = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    rc = call_rc("unetr_instnorm_apply_fin_img", x.data_ptr(), C, part.data_ptr(), rows, img.data_ptr(), cin, w3.data_ptr(), part_b.data_ptr(), rows_b,
+                 sa.data_ptr(), sb.data_ptr(), IN_EPS, y.data_ptr(), C if out is None else ldo, B, V, C, 1, _a16(x), _stream())
+    return (y, sa, sb) if rc == 0 else None
+
+
+def instnorm_bwd_img(dy, lddy, x, sa, img, cin, w3, sb, B, V, C):
+    """backward of the same block end: (dx of the 3x3x3 branch, dw3 partial rows [rows, C * cin], rows) or None"""
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype).contiguous(); lddy = dy.stride(-2)
+    dx = torch.empty_like(x)
+    part = torch.empty(IN_IMG_MAX_ROWS, C * cin, dtype=torch.float32, device=x.device)
+    rows = ctypes.c_int(0)
+    ws = workspace(x.device)
+    rc = call_rc("unetr_instnorm_bwd_img", dy.data_ptr(), lddy, x.data_ptr(), C, sa.data_ptr(), img.data_ptr(), cin, w3.data_ptr(), sb.data_ptr(),
+                 dx.data_ptr(), C, part.data_ptr(), ctypes.byref(rows), B, V, C, 1, ws.data_ptr(), ws.numel() * 4, _a16(x), _stream())
+    return (dx, part, rows.value) if rc == 0 else None
 
 
 def stats_from_parts(part, rows, B, V, C):
@@ -1513,12 +1546,29 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec, to_cat=False):
     return out, (c1, s1, a1, c2, s2, c3, s3)
 
 
+def _materialize_c3(x, w3, dims, cin, cout, prec):
+    """the 1x1x1 branch of the block on the image as a stored tensor (fallback of the image form: generic GEMM family)"""
+    B, D, H, W = dims
+    V = D * H * W
+    c3f = torch.empty(B * V, cout, dtype=torch.float32, device=x.device)
+    gemm(x.reshape(B * V, cin), w3, c3f, B * V, cout, cin, lda=cin, ldb=cin, ldc=cout, prec=prec)
+    return _as_act(c3f.view(B, D, H, W, cout), prec)
+
+
 def _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat):
     """the same block in FOUR launches: both convs leave their InstanceNorm sums as partial rows and the two apply kernels form
     the statistics in their prologues (no finalize launches); None when a shape declines (the caller takes the route above)"""
     B, D, H, W = dims
     V = D * H * W
-    f1 = conv3_parts(x, ldx, w1, w3, dims, prec)
+    cin = w1.shape[1]
+    # the block on the image (<= 4 fp32 input channels, no input gradient): its 1x1x1 branch is never stored -- the block-end
+    # kernels form it from the image (csrc/norm_misc.hip: ImgBranch)
+    img = (img_branch_enabled() and x.dtype == torch.float32 and cin <= 4 and ldx == cin and not x.requires_grad and w3.is_contiguous()
+           and cout % 8 == 0 and 64 % max(1, cout // 8) == 0)
+    f1 = conv3_parts(x, ldx, w1, w3, dims, prec, store3=not img)
+    if f1 is None and img:
+        img = False
+        f1 = conv3_parts(x, ldx, w1, w3, dims, prec)
     if f1 is None:
         return None
     c1, p1, c3, p3, rows1 = f1
@@ -1531,7 +1581,13 @@ def _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat):
         return None
     c2, p2, _, _, rows2 = f2
     half = skip_half(dims, cout, prec, x.device)[1] if to_cat else None
-    r2 = instnorm_apply_fin(c2, p2, rows2, B, V, cout, True, x2=c3, part_b=p3, rows_b=rows1, out=half, ldo=2 * cout if to_cat else None)
+    if img:
+        r2 = instnorm_apply_fin_img(c2, p2, rows2, x, cin, w3, p3, rows1, B, V, cout, out=half, ldo=2 * cout if to_cat else None)
+        if r2 is None:                         # (a shape the image form declines: materialise the branch after all)
+            c3 = _materialize_c3(x, w3, dims, cin, cout, prec)
+            r2 = instnorm_apply_fin(c2, p2, rows2, B, V, cout, True, x2=c3, part_b=p3, rows_b=rows1, out=half, ldo=2 * cout if to_cat else None)
+    else:
+        r2 = instnorm_apply_fin(c2, p2, rows2, B, V, cout, True, x2=c3, part_b=p3, rows_b=rows1, out=half, ldo=2 * cout if to_cat else None)
     if r2 is None:
         return None
     out, s2, s3 = r2
@@ -1543,7 +1599,17 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     V = D * H * W
     c1, s1, a1, c2, s2, c3, s3 = saved
     dout, lddo = _rows(dout)
-    dc2, dc3 = instnorm_bwd(dout, lddo, c2, s2, B, V, cout, True, x2=c3, sb=s3)
+    img3 = None
+    if c3 is None:
+        # the block on the image: the 1x1x1 branch was never stored -- its gradient is formed per voxel inside the backward apply and
+        # leaves only as partial rows of dw3
+        img3 = instnorm_bwd_img(dout, lddo, c2, s2, x, cin, w3, s3, B, V, cout)
+        if img3 is None:
+            c3 = _materialize_c3(x, w3, dims, cin, cout, prec)
+    if img3 is not None:
+        dc2, dc3 = img3[0], None
+    else:
+        dc2, dc3 = instnorm_bwd(dout, lddo, c2, s2, B, V, cout, True, x2=c3, sb=s3)
     # conv3 (1x1x1)
     g3 = _gout(w3)
     dw3 = g3 if g3 is not None else torch.empty(cout, cin, 1, 1, 1, dtype=torch.float32, device=x.device)
@@ -1568,10 +1634,17 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
     if dc1 is None:
         da1 = conv3(dc2, cout, w2, dims, prec, mode=1)
         dc1, _ = instnorm_bwd(da1, cout, c1, s1, B, V, cout, True)
+    o3 = dw3 if dc3 is not None else None
     if st is not None:
-        dw1, q1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=g1, dy3=dc3, out3=dw3, defer=st)
+        dw1, q1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=g1, dy3=dc3, out3=o3, defer=st)
     else:
-        dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=g1, dy3=dc3, out3=dw3)
+        dw1 = conv3_wgrad(x, ldx, dc1, cout, dims, cin, cout, prec, out=g1, dy3=dc3, out3=o3)
+    if img3 is not None:
+        rq = [(img3[1], dw3, cout * cin, img3[2])]
+        if st is not None and q1 and reduce_defer_enabled():
+            st.defer["reduce"].append(rq[0])           # joins the grouped reduce at the end of the backward pass (armed by conv3_wgrad)
+        else:
+            _launch_reduces(rq)
     dx = None
     if need_dx:
         dx = torch.empty(B, D, H, W, cin, dtype=act_dtype(prec), device=x.device)

@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 12
+#define UNETR_ABI_VERSION 13
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -323,6 +323,18 @@ int unetr_instnorm_apply_fin(const void* x, long ldx, const float* part_a, int r
 int unetr_instnorm_bwd_apply_fin(const void* dy, long lddy, const void* x, long ldx, const float* sa,
                                  const void* x2, long ldx2, const float* sb, const float* part, int nrows, int nsp,
                                  void* dx, long lddx, void* dx2, long lddx2, int B, long V, int C, int lrelu, int act16, void* stream);
+/* The block end of the residual block that reads the IMAGE (encoder1, unetr.py:90-98; <= 4 input channels): its 1x1x1 branch
+ * c3 = conv1x1x1(img; w3 [C][Cin]) is formed per voxel from the fp32 image [B][V][Cin] instead of being stored and re-read, forward
+ * (y = lrelu(norm(x) + norm(c3)); part_b = the partial rows of c3's statistics from unetr_conv3_fwd_parts, which then takes
+ * y3 = NULL) and backward (dx of the 3x3x3 branch; the branch's weight gradient as partial rows dw3_part [*rows_out][C][Cin],
+ * caller-allocated for UNETR_IN_IMG_MAX_ROWS rows, summed by unetr_reduce_rows_grouped; ws >= B * 1024 * 3 * C floats). */
+#define UNETR_IN_IMG_MAX_ROWS 512
+int unetr_instnorm_apply_fin_img(const void* x, long ldx, const float* part_a, int rows_a, const float* img, int Cin, const float* w3,
+                                 const float* part_b, int rows_b, float* stats_a, float* stats_b, float eps,
+                                 void* y, long ldy, int B, long V, int C, int lrelu, int act16, void* stream);
+int unetr_instnorm_bwd_img(const void* dy, long lddy, const void* x, long ldx, const float* sa, const float* img, int Cin,
+                           const float* w3, const float* sb, void* dx, long lddx, float* dw3_part, int* rows_out,
+                           int B, long V, int C, int lrelu, float* ws, size_t ws_bytes, int act16, void* stream);
 /* backward of y = lrelu?(norm(x) [+ norm(x2)]): writes dx (and dx2). */
 int unetr_instnorm_bwd(const void* dy, long lddy, const void* x, long ldx, const float* sa,
                        const void* x2, long ldx2, const float* sb, void* dx, long lddx, void* dx2, long lddx2,
