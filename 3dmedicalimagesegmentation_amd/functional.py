@@ -80,6 +80,8 @@ def aux_stream(device):
 def join_aux_streams():
     """the current stream waits for everything queued on the auxiliary streams used since the last join (end of a backward pass:
     parameter gradients written there bypass autograd's own leaf-stream synchronisation)"""
+    if not _AUX_USED:
+        return
     cur = torch.cuda.current_stream()
     for idx in list(_AUX_USED):
         if idx == cur.device.index:
