@@ -139,7 +139,8 @@ def _short(name):
 def _pmc_traffic(kernel_rx):
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     d, rel = None, None
-    for cand in ("r03_pmc_step_kernels.json", "r02_pmc_step_kernels.json"):      # newest committed summary first
+    import glob
+    for cand in sorted((os.path.basename(f) for f in glob.glob(os.path.join(root, "r[0-9][0-9]_pmc_step_kernels.json"))), reverse=True):   # newest round first
         try:
             d, rel = json.load(open(os.path.join(root, cand))), "profiles/" + cand
             break
