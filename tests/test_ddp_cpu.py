@@ -1,11 +1,10 @@
 """world_size-2 gloo test of the bucketed gradient all-reducer (the N>1 path of bench.py): averaged
 gradients, unused parameters (cls_token / frozen encoder) and bucket ordering."""
 import os
-
-import pytest
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
