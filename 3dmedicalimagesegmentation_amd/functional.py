@@ -57,38 +57,6 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# ---- an auxiliary stream per device for conv-side work that nothing on the ViT's dependency chain waits for (the encoder1 residual
-# block: its forward is only needed by decoder2, its backward feeds no other gradient).  Autograd runs a node's backward on the stream
-# its forward ran on, so work placed here in the forward also leaves the backward's critical path; under graph capture the stream
-# becomes a branch of the captured graph.  UNETR_AMD_AUX_STREAM=1 enables it (A/B hook).
-_AUX = {}
-_AUX_USED = set()
-
-
-def aux_stream_enabled():
-    return os.environ.get("UNETR_AMD_AUX_STREAM", "0") == "1"
-
-
-def aux_stream(device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _AUX.get(idx)
-    if st is None:
-        st = _AUX[idx] = torch.cuda.Stream(device=idx)
-    return st
-
-
-def join_aux_streams():
-    """the current stream waits for everything queued on the auxiliary streams used since the last join (end of a backward pass:
-    parameter gradients written there bypass autograd's own leaf-stream synchronisation)"""
-    if not _AUX_USED:
-        return
-    cur = torch.cuda.current_stream()
-    for idx in list(_AUX_USED):
-        if idx == cur.device.index:
-            cur.wait_stream(_AUX[idx])
-            _AUX_USED.discard(idx)
-
-
 # ---- gradient sinks: parameters registered here get their gradients written straight into a slice of one flat
 # arena (UNETR.use_flat_buffers), so AdamW is one launch and the data-parallel all-reduce needs no flatten copies.
 # Everything mutable about that fast path -- the sink table, the deferred weight-gradient queues, the readiness
@@ -306,7 +274,6 @@ def flush_deferred(st=None):
     d = st.defer
     wq, cq, wbq, params, prec, rq = d["wgrad"], d["colsum"], d["wgrad_b"], d["params"], d["prec"], d["reduce"]
     st.reset_deferred()
-    join_aux_streams()
     if rq:
         _launch_reduces(rq)
     _launch_deferred(wq, cq, wbq, prec, st.fuse)

@@ -364,19 +364,7 @@ class UNETR(nn.Module):
                                  Fn._bf16_path(prec, self.hidden_size, self.vit.blocks[0].mlp.linear1.weight.shape[0]))
         x = cut(x, 0)
         # every skip tensor is produced straight into the second half of the decoder's concatenation buffer (to_cat)
-        if Fn.aux_stream_enabled() and stages is None:
-            # encoder1 on the auxiliary stream: its forward runs beside the skip-path transposed convs and decoder5..3, its backward
-            # (two weight gradients, a data gradient, the InstanceNorm passes: ~0.3 ms that nothing else waits for) beside the ViT's
-            cur = torch.cuda.current_stream()
-            aux = Fn.aux_stream(x_in.device)
-            aux.wait_stream(cur)
-            with torch.cuda.stream(aux):
-                enc1 = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec, True)
-            Fn._AUX_USED.add(aux.device.index)
-            self._aux_pending = (aux, enc1)
-        else:
-            enc1 = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec, True)
-            self._aux_pending = None
+        enc1 = Fn.ResBlockFn.apply(Fn.to_channels_last(x_in), *self._res_w(self.encoder1.layer), prec, True)
         enc = []
         for tap, blk in ((3, self.encoder2), (6, self.encoder3), (9, self.encoder4)):
             t = Fn.TconvFn.apply(self._tokens_cl(hidden_states_out[tap], B), blk.transp_conv_init.conv.weight, prec, len(blk.blocks) == 0)
@@ -395,12 +383,6 @@ class UNETR(nn.Module):
         d = self.decoder3
         dec1 = Fn.UpBlockFn.apply(dec2, enc2, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
         d = self.decoder2
-        pend = getattr(self, "_aux_pending", None)
-        if pend is not None:                    # decoder2 is the first consumer of encoder1's output
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(pend[0])
-            Fn.cat_of_skip(pend[1], pend[1].shape[-1]).record_stream(cur)
-            self._aux_pending = None
         out = Fn.UpBlockFn.apply(dec1, enc1, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
         logits = Fn.OutConvFn.apply(out, self.out.conv.conv.weight, self.out.conv.conv.bias)
         return Fn.ToNCDHWFn.apply(enc4), logits
