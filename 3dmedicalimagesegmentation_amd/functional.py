@@ -944,12 +944,6 @@ def instnorm_bwd_img(dy, lddy, x, sa, img, cin, w3, sb, B, V, C):
     return (dx, part, rows.value) if rc == 0 else None
 
 
-def stats_from_parts(part, rows, B, V, C):
-    stats = torch.empty(B, C, 2, dtype=torch.float32, device=part.device)
-    call("unetr_instnorm_stats_finalize", part.data_ptr(), rows, B, V, C, IN_EPS, stats.data_ptr(), _stream())
-    return stats
-
-
 def conv3_dgrad_stats(dy, w, xn, stats, dims, prec):
     """da = conv3x3x3^T(dy; w) together with the partial sums of the InstanceNorm backward of xn's norm (the norm whose
     lrelu'd output the conv read): returns (da, part, rows) or None when the shape takes the unfused route"""
