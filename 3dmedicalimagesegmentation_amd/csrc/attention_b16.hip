@@ -13,6 +13,7 @@
 //   * workgroup = 32 queries (2 waves): 2 x 12 heads x 7 query tiles = 168 workgroups at batch 2, one round on 256 CUs.
 //
 // Layout: qkv bf16 [B*L, 3*Hd], feature = which*Hd + head*64 + j; out [B*L, Hd]; lse / delta [B, heads, L].
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/unetr_hip.h"
 
@@ -457,8 +458,15 @@ void launch_dyn(K kern, dim3 grid, int nt, size_t lds, hipStream_t st, A... args
     hipLaunchKernelGGL(kern, grid, dim3(nt), lds, st, args...);
 }
 
-// queries per workgroup: 32 (2 waves) while that still gives at most ~2 rounds of workgroups, else 64
+// queries per workgroup: 32 (2 waves) while that still gives at most ~2 rounds of workgroups, else 64; the FORWARD kernel takes 128
+// (8 waves) once even the 64-query grid is several rounds deep (batch >= 16 at 216 tokens): every workgroup stages all of K and V
+// for its (batch item, head), so twice the queries per workgroup halve that traffic (UNETR_ATTN_NW forces 2 / 4 / 8)
 inline int pick_nw(int B, int L, int heads) { return ((long)cdiv(L, 32) * heads * B <= 512) ? 2 : 4; }
+inline int pick_nw_fwd(int B, int L, int heads) {
+    if (const char* e = getenv("UNETR_ATTN_NW")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) return v; }
+    const int nw = pick_nw(B, L, heads);
+    return (nw == 4 && (long)cdiv(L, 64) * heads * B > 1024) ? 8 : nw;
+}
 
 }  // namespace
 
@@ -468,10 +476,13 @@ extern "C" int unetr_attention_bf16_fwd(const void* qkv, float* out, void* out_b
     if (dh != DH || ((uintptr_t)qkv & 15) || (out && ((uintptr_t)out & 15)) || (out_bf16 && ((uintptr_t)out_bf16 & 7))) return UNETR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = 2 * IMG;
-    if (pick_nw(B, L, heads) == 2)
+    const int nw = pick_nw_fwd(B, L, heads);
+    if (nw == 2)
         launch_dyn(attn16_fwd_kernel<2>, dim3(cdiv(L, 32), heads, B), 128, lds, st, (const uint16_t*)qkv, out, (uint16_t*)out_bf16, lse, L, heads, scale);
-    else
+    else if (nw == 4)
         launch_dyn(attn16_fwd_kernel<4>, dim3(cdiv(L, 64), heads, B), 256, lds, st, (const uint16_t*)qkv, out, (uint16_t*)out_bf16, lse, L, heads, scale);
+    else
+        launch_dyn(attn16_fwd_kernel<8>, dim3(cdiv(L, 128), heads, B), 512, lds, st, (const uint16_t*)qkv, out, (uint16_t*)out_bf16, lse, L, heads, scale);
     return unetr_check_launch();
 }
 

@@ -780,6 +780,26 @@ def test_gemm_bf16_small_m_tiles(pkg, dev, cfg, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nw", [2, 4, 8])
+@pytest.mark.parametrize("B,L,heads", [(2, 216, 12), (1, 1000, 3), (3, 230, 1), (1, 40, 2)])
+def test_attention_bf16_forward_wave_counts(pkg, dev, monkeypatch, nw, B, L, heads):
+    """the forward attention kernel with 32 / 64 / 128 queries per workgroup (UNETR_ATTN_NW; 128 = the form deep grids -- batch
+    >= 16 at 216 tokens -- take by themselves): same output, same log-sum-exp"""
+    monkeypatch.setenv("UNETR_ATTN_NW", str(nw))
+    Fn = pkg.functional
+    dh, Hd = 64, heads * 64
+    qkv = (g(B * L, 3 * Hd, seed=1) * 0.8).bfloat16()
+    t = qkv.float().view(B, L, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    sc = t[0] @ t[1].transpose(-1, -2) * dh ** -0.5
+    out_ref = (torch.softmax(sc, dim=-1) @ t[2]).permute(0, 2, 1, 3).reshape(B * L, Hd)
+    outb = torch.empty(B * L, Hd, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(B * L, Hd, device=dev)
+    lse = Fn.attention_bf16_fwd(qkv.to(dev), B, L, heads, dh, outb, out=out)
+    assert relerr(out, out_ref) < 1e-2 and torch.equal(outb.cpu(), out.cpu().bfloat16())
+    assert relerr(lse, torch.logsumexp(sc, dim=-1)) < 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,heads", [(2, 216, 12), (1, 8, 2), (1, 1000, 3), (3, 230, 1), (1, 512, 2)])
 def test_attention_bf16_storage(pkg, dev, B, L, heads):
     """attention on bf16-stored q/k/v (csrc/attention_b16.hip: LDS-DMA staged images, one image for row and transposed
