@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
-ABI_VERSION = 13       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 14       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -145,6 +145,8 @@ _SIGNATURES = {
     "unetr_copy_rows": [P, c_long, P, c_long, c_long, c_int, c_int, c_int, P],
     "unetr_outconv_fwd": [P, c_long, P, P, P, c_int, c_long, c_int, c_int, c_int, P],
     "unetr_outconv_bwd": [P, P, c_long, P, P, c_long, P, P, c_int, c_long, c_int, c_int, P, c_size_t, c_int, P],
+    "unetr_outconv_in_fwd": [P, c_long, P, c_int, P, c_long, P, c_int, P, P, c_float, P, P, P, c_int, c_long, c_int, c_int, c_int, P],
+    "unetr_outconv_in_bwd": [P, P, c_long, P, P, c_long, P, P, P, c_long, P, P, P, c_int, c_long, c_int, c_int, P, c_size_t, c_int, P],
     "unetr_dicece_fwd": [P, P, c_int, c_int, c_long, c_int, c_float, c_float, P, P, P, c_size_t, P],
     "unetr_dicece_bwd": [P, P, P, P, P, c_int, c_int, c_long, c_int, P],
     "unetr_sw_accumulate": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
@@ -157,7 +159,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_conv3_packed_1x1_bytes", "unetr_ranking_workspace_floats",
-                                            "unetr_conv3_wgrad_rows", "unetr_tconv2_wgrad_rows")
+                                            "unetr_conv3_wgrad_rows", "unetr_tconv2_wgrad_rows", "unetr_outconv_in_bwd_rows")
 
 _lib = None
 
@@ -189,6 +191,8 @@ def load():
     lib.unetr_conv3_wgrad_rows.restype = c_long
     lib.unetr_tconv2_wgrad_rows.argtypes = [c_int] * 6
     lib.unetr_tconv2_wgrad_rows.restype = c_long
+    lib.unetr_outconv_in_bwd_rows.argtypes = [c_int, c_long, c_int, c_int]
+    lib.unetr_outconv_in_bwd_rows.restype = c_long
     lib.unetr_ranking_workspace_floats.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.unetr_ranking_workspace_floats.restype = c_size_t
     _lib = lib

@@ -1518,6 +1518,166 @@ outconv_wgrad_generic_kernel(const float* __restrict__ dl, const T* __restrict__
         if ((int)threadIdx.x + k * 256 < np) part[(long)blockIdx.x * np + threadIdx.x + k * 256] = acc[k];
 }
 
+// ---- the LAST residual block's end folded into the out conv (decoder2 -> UnetOutBlock, unetr.py:165-175,206-207) ------------------
+// out = lrelu(norm(c2) + norm(c3)) is consumed by the 1x1x1 out conv only, so it is never stored: the forward kernel forms it per
+// voxel from c2 / c3 (statistics finalized in its prologue from the convs' partial rows, as in_apply_fin_kernel) and writes the
+// logits; the backward kernel forms it again (for the out conv's weight gradient and the lrelu mask), computes dout = W^T dl,
+// stores it, and accumulates the InstanceNorm backward sums (g, g n2, g n3 with g = dout lrelu'(.)) on the way -- the separate
+// reduction pass over (dout, c2, c3) disappears.  `out` and `dout` are rounded to the storage type T where the unfused sequence
+// stored them, so both sequences see the same values.  Small heads only (Cout <= 4, C = 1 / 2 / 4 pieces of W channels).
+template <class T> __device__ __forceinline__ float store_round(float v);
+template <> __device__ __forceinline__ float store_round<float>(float v) { return v; }
+template <> __device__ __forceinline__ float store_round<uint16_t>(float v) { const __bf16 h = (__bf16)v; return (float)h; }
+
+template <class T, int U>
+__global__ void __launch_bounds__(IN_FIN_NT)
+outconv_in_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ pa, int rows_a, const T* __restrict__ x2, long ldx2,
+                      const float* __restrict__ pb, int rows_b, float* __restrict__ stats_a, float* __restrict__ stats_b, float eps,
+                      const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ logits,
+                      long V, long vpb, int C, int Cout) {
+    constexpr int W = Io<T>::W;
+    __shared__ double red[IN_FIN_NT];
+    __shared__ double sums[4 * 128];
+    __shared__ float sta[2 * 128], stb[2 * 128];
+    const int cvn = C / W, nphase = IN_FIN_NT / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    const T* px2 = x2 + ((long)b * V) * ldx2 + W * cv;
+    in_fin_sums(pa + (long)b * rows_a * 2 * C, rows_a, pb + (long)b * rows_b * 2 * C, rows_b, 2 * C, red, sums);
+    in_fin_stats(sums, C, V, eps, sta, stats_a + (long)b * C * 2);
+    in_fin_stats(sums + 2 * C, C, V, eps, stb, stats_b + (long)b * C * 2);
+    __syncthreads();
+    float a1[W], o1[W], a2[W], wr[4][W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        a1[e] = sta[2 * (W * cv + e) + 1]; o1[e] = -sta[2 * (W * cv + e)] * a1[e];
+        a2[e] = stb[2 * (W * cv + e) + 1]; o1[e] -= stb[2 * (W * cv + e)] * a2[e];
+#pragma unroll
+        for (int co = 0; co < 4; ++co) wr[co][e] = co < Cout ? w[co * C + W * cv + e] : 0.f;
+    }
+    float bz[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) bz[co] = (bias && co < Cout) ? bias[co] : 0.f;
+    float* pl = logits + (long)b * Cout * V;
+    for (long v = v0 + ph; v < v1; v += (long)U * nphase) {
+        u32x4 rt[U], rt2[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long vv = v + (long)u * nphase;
+            live[u] = vv < v1;
+            const long vc = live[u] ? vv : v;
+            rt[u] = *(const u32x4*)(px + vc * ldx);
+            rt2[u] = *(const u32x4*)(px2 + vc * ldx2);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float t[W], t2[W], d[4] = {0.f, 0.f, 0.f, 0.f};
+            Io<T>::unpack(rt[u], t);
+            Io<T>::unpack(rt2[u], t2);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float n = fmaf(t[e], a1[e], o1[e]);
+                n = fmaf(t2[e], a2[e], n);
+                const float o = store_round<T>(n > 0.f ? n : 0.01f * n);
+#pragma unroll
+                for (int co = 0; co < 4; ++co) d[co] = fmaf(o, wr[co][e], d[co]);
+            }
+            // the cvn pieces of a voxel sit in adjacent lanes
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+                for (int o = 1; o < cvn; o <<= 1) d[co] += __shfl_xor(d[co], o, 64);
+            if (live[u] && cv == 0) {
+                const long vv = v + (long)u * nphase;
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+                    if (co < Cout) pl[(long)co * V + vv] = d[co] + bz[co];
+            }
+        }
+    }
+}
+
+// part_in: this block's row [3][C] of the InstanceNorm backward sums (rows [B][gridDim.x]); part_oc: its row of the out conv's
+// bias / weight gradient partials [Cout + Cout * C] (rows [B * gridDim.x])
+template <class T>
+__global__ void __launch_bounds__(256)
+outconv_in_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ w, const T* __restrict__ x, long ldx, const float* __restrict__ sa,
+                      const T* __restrict__ x2, long ldx2, const float* __restrict__ sb, T* __restrict__ dx, long lddx,
+                      float* __restrict__ part_in, float* __restrict__ part_oc, long V, long vpb, int C, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int W = Io<T>::W;
+    __shared__ float red[4][4 + 64];
+    const int cvn = C / W, nphase = 256 / cvn;
+    const int cv = threadIdx.x % cvn, ph = threadIdx.x / cvn;
+    const int b = blockIdx.y;
+    const long v0 = (long)blockIdx.x * vpb, v1 = std::min<long>(V, v0 + vpb);
+    const float* s1 = sa + ((long)b * C + W * cv) * 2;
+    const float* s2 = sb + ((long)b * C + W * cv) * 2;
+    float a1[W], o1[W], a2[W], o2[W], wr[4][W], wsum[4][W], acc[3][W];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        a1[e] = s1[2 * e + 1]; o1[e] = -s1[2 * e] * a1[e];
+        a2[e] = s2[2 * e + 1]; o2[e] = -s2[2 * e] * a2[e];
+        acc[0][e] = acc[1][e] = acc[2][e] = 0.f;
+#pragma unroll
+        for (int co = 0; co < 4; ++co) { wr[co][e] = co < Cout ? w[co * C + W * cv + e] : 0.f; wsum[co][e] = 0.f; }
+    }
+    const T* px = x + ((long)b * V) * ldx + W * cv;
+    const T* px2 = x2 + ((long)b * V) * ldx2 + W * cv;
+    T* pd = dx + ((long)b * V) * lddx + W * cv;
+    const float* pg = dl + (long)b * Cout * V;
+#pragma unroll 1
+    for (long v = v0 + ph; v < v1; v += nphase) {
+        const u32x4 rt = *(const u32x4*)(px + v * ldx), rt2 = *(const u32x4*)(px2 + v * ldx2);
+        float g[4];
+#pragma unroll
+        for (int co = 0; co < 4; ++co) g[co] = co < Cout ? pg[(long)co * V + v] : 0.f;
+        float t[W], t2[W], dq[W];
+        Io<T>::unpack(rt, t);
+        Io<T>::unpack(rt2, t2);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const float n1 = fmaf(t[e], a1[e], o1[e]), n2 = fmaf(t2[e], a2[e], o2[e]);
+            const float sn = n1 + n2;
+            const float o = store_round<T>(sn > 0.f ? sn : 0.01f * sn);
+            dq[e] = store_round<T>(g[0] * wr[0][e] + g[1] * wr[1][e] + g[2] * wr[2][e] + g[3] * wr[3][e]);
+            const float ge = sn > 0.f ? dq[e] : 0.01f * dq[e];
+            acc[0][e] += ge;
+            acc[1][e] = fmaf(ge, n1, acc[1][e]);
+            acc[2][e] = fmaf(ge, n2, acc[2][e]);
+#pragma unroll
+            for (int co = 0; co < 4; ++co) wsum[co][e] = fmaf(g[co], o, wsum[co][e]);
+        }
+        Io<T>::stw(pd + v * lddx, dq);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) bsum[co] += cv == 0 ? g[co] : 0.f;
+    }
+    in_block_reduce<3, W>(acc, cvn, nphase, lds, part_in + ((long)b * gridDim.x + blockIdx.x) * 3 * C, C);
+    // out conv partials: lanes with the same cv (lane % cvn: cvn divides 64 and the block size) hold the same channels
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        float sbz = wave_sum(bsum[co]);
+        if (lane == 0) red[wave][co] = sbz;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float tt = wsum[co][e];
+            for (int o = 32; o >= cvn; o >>= 1) tt += __shfl_xor(tt, o, 64);
+            if (lane < cvn) red[wave][4 + co * 16 + W * lane + e] = tt;
+        }
+    }
+    __syncthreads();
+    const int np = Cout + Cout * C;
+    if ((int)threadIdx.x < np) {
+        int src = threadIdx.x;
+        if ((int)threadIdx.x >= Cout) { const int k = threadIdx.x - Cout, co = k / C, ci = k - co * C; src = 4 + co * 16 + ci; }
+        part_oc[((long)b * gridDim.x + blockIdx.x) * np + threadIdx.x] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    }
+}
+
 // out0[n] = sum_r part[r][n] for n < n0, out1[n - n0] for the rest (bias gradient, then weight gradient)
 __global__ void outconv_final_kernel(const float* __restrict__ part, int R, int N, int n0, float* __restrict__ out0, float* __restrict__ out1) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2063,6 +2223,61 @@ extern "C" int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, 
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(npw, 64), RB), dim3(256), 0, st, ws, (long)npw, nb2, npw, wsb, RB);
         hipLaunchKernelGGL(outconv_final_kernel, dim3(cdiv(npw, 256)), dim3(256), 0, st, wsb, RB, npw, 0, dbias, dw);
     }
+    return unetr_check_launch();
+}
+
+/* The last residual block's end + the out conv in one pass each way (see outconv_in_fwd_kernel).  Forward: logits [B][Cout][V] from
+ * c2 / c3 (the block's second 3x3x3 conv and its 1x1x1 branch, channels-last, C channels) and their InstanceNorm partial rows
+ * part_a / part_b [B][rows][2][C]; stats_a / stats_b [B][C][2] are written for backward.  UNSUPPORTED = take the unfused sequence. */
+extern "C" int unetr_outconv_in_fwd(const void* c2, long ld2, const float* part_a, int rows_a, const void* c3, long ld3, const float* part_b,
+                                    int rows_b, float* stats_a, float* stats_b, float eps, const float* w, const float* bias, float* logits,
+                                    int B, long V, int C, int Cout, int act16, void* stream) {
+    if (!c2 || !c3 || !part_a || !part_b || !stats_a || !stats_b || !w || !logits || rows_a <= 0 || rows_b <= 0 || B <= 0 || V <= 0) return UNETR_ERR_ARG;
+    const int W = act16 ? 8 : 4;
+    if (Cout < 1 || Cout > 4 || !in_fin_ok(C, W, 2) || C > 16 || 64 % (C / W) || (ld2 % W) || (ld3 % W) || B > 65535) return UNETR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)c2 | (uintptr_t)c3) & 15) != 0) return UNETR_ERR_UNSUPPORTED;
+    const int cvn = C / W;
+    long vpb; int nchunk;
+    in_chunks(V, B, 2 * (IN_FIN_NT / cvn), IN_FIN_BLOCKS, vpb, nchunk);
+    ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_in_fwd_kernel<AT, 2>), dim3(nchunk, B), dim3(IN_FIN_NT), 0, (hipStream_t)stream, (const AT*)c2, ld2, part_a, rows_a,
+                                           (const AT*)c3, ld3, part_b, rows_b, stats_a, stats_b, eps, w, bias, logits, V, vpb, C, Cout));
+    return unetr_check_launch();
+}
+
+/* rows of in_part (per batch item) that unetr_outconv_in_bwd writes for this shape; 0 = unsupported */
+extern "C" long unetr_outconv_in_bwd_rows(int B, long V, int C, int act16) {
+    const int W = act16 ? 8 : 4;
+    if (B <= 0 || V <= 0 || C % W || C > 16 || 64 % (C / W)) return 0;
+    const int nphase = 256 / (C / W);
+    const long step = 2L * nphase;
+    const long vpb = std::max<long>(2 * step, cdiv(cdiv((long)V * B, 768L), step) * step);
+    return cdiv(V, vpb);
+}
+
+/* Backward of the pair: dout [B][V][C] (pitch lddo, storage type of c2) = W^T dlogits; in_part [B][rows][3][C] = partial sums of the
+ * block end's InstanceNorm backward (rows = unetr_outconv_in_bwd_rows; consumed by unetr_instnorm_bwd_apply_fin with nsp = 3 and
+ * dy = dout); dw [Cout][C], dbias [Cout].  ws: the out conv's partial rows + their column sums. */
+extern "C" int unetr_outconv_in_bwd(const float* dlogits, const void* c2, long ld2, const float* sa, const void* c3, long ld3, const float* sb,
+                                    const float* w, void* dout, long lddo, float* in_part, float* dw, float* dbias,
+                                    int B, long V, int C, int Cout, float* ws, size_t ws_bytes, int act16, void* stream) {
+    if (!dlogits || !c2 || !c3 || !sa || !sb || !w || !dout || !in_part || !dw || !dbias || B <= 0 || V <= 0) return UNETR_ERR_ARG;
+    const int W = act16 ? 8 : 4;
+    const long rows = unetr_outconv_in_bwd_rows(B, V, C, act16);
+    if (Cout < 1 || Cout > 4 || rows <= 0 || rows > 65535 || (ld2 % W) || (ld3 % W) || (lddo % W) || B > 65535) return UNETR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)c2 | (uintptr_t)c3 | (uintptr_t)dout) & 15) != 0) return UNETR_ERR_UNSUPPORTED;
+    const int cvn = C / W, nphase = 256 / cvn;
+    const long step = 2L * nphase;
+    const long vpb = std::max<long>(2 * step, cdiv(cdiv((long)V * B, 768L), step) * step);
+    const int nblk = (int)rows * B, np = Cout + Cout * C;
+    const size_t part_al = ((size_t)nblk * np * sizeof(float) + 255) & ~(size_t)255;
+    const int RB = std::max(1, std::min(cdiv(nblk, 64), 256));
+    if (!ws || part_al + (size_t)RB * np * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    ACT_DISPATCH(act16, hipLaunchKernelGGL((outconv_in_bwd_kernel<AT>), dim3((unsigned)rows, B), dim3(256), (size_t)3 * nphase * C * 4, st, dlogits, w, (const AT*)c2, ld2, sa,
+                                           (const AT*)c3, ld3, sb, (AT*)dout, lddo, in_part, ws, V, vpb, C, Cout));
+    float* ws2 = (float*)((char*)ws + part_al);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(np, 64), RB), dim3(256), 0, st, ws, (long)np, nblk, np, ws2, RB);
+    hipLaunchKernelGGL(outconv_final_kernel, dim3(cdiv(np, 256)), dim3(256), 0, st, ws2, RB, np, Cout, dbias, dw);
     return unetr_check_launch();
 }
 

@@ -970,6 +970,52 @@ def instnorm_bwd_apply_fin(dy, lddy, x, sa, part, rows, nsp, B, V, C, lrelu):
     return dx if rc == 0 else None
 
 
+def out_fuse_enabled():
+    """UNETR_AMD_OUT_FUSE=0 (A/B hook): decoder2's block end is stored and the out conv reads it, as every other block end"""
+    return os.environ.get("UNETR_AMD_OUT_FUSE", "1") != "0"
+
+
+def outconv_in_fwd(c2, p2, rows2, c3, p3, rows3, wo, bo, B, V, C):
+    """logits of the out conv on lrelu(norm(c2) + norm(c3)) without storing that tensor (csrc/norm_misc.hip: outconv_in_fwd_kernel);
+    returns (logits [B, Cout, V] fp32, stats of c2, stats of c3) or None when the shape takes the unfused sequence"""
+    cout = wo.shape[0]
+    if wo.shape[1] != C or not wo.is_contiguous():
+        return None
+    logits = torch.empty(B, cout, V, dtype=torch.float32, device=c2.device)
+    sa = torch.empty(B, C, 2, dtype=torch.float32, device=c2.device)
+    sb = torch.empty(B, C, 2, dtype=torch.float32, device=c2.device)
+    rc = call_rc("unetr_outconv_in_fwd", c2.data_ptr(), C, p2.data_ptr(), rows2, c3.data_ptr(), C, p3.data_ptr(), rows3, sa.data_ptr(), sb.data_ptr(),
+                 IN_EPS, wo.data_ptr(), _p(bo), logits.data_ptr(), B, V, C, cout, _a16(c2), _stream())
+    return (logits, sa, sb) if rc == 0 else None
+
+
+def outconv_in_bwd(dl, c2, s2, c3, s3, wo, bo, B, V, C):
+    """backward of outconv_in_fwd up to the block end's normalisation: (dout in the storage type of c2, InstanceNorm backward partial
+    rows [B, rows, 3, C], rows, dwo, dbo)"""
+    cout = wo.shape[0]
+    rows = _capi.load().unetr_outconv_in_bwd_rows(B, V, C, _a16(c2))
+    if rows <= 0:
+        raise RuntimeError("unetr_outconv_in_bwd: shape accepted by the forward kernel is declined by backward")
+    dl = dl.contiguous()
+    dout = torch.empty_like(c2)
+    part = torch.empty(B, rows, 3, C, dtype=torch.float32, device=c2.device)
+    gw, gb = _gout(wo), _gout(bo)
+    dw = gw if gw is not None else torch.empty_like(wo)
+    db = gb if gb is not None else torch.empty(cout, dtype=torch.float32, device=c2.device)
+    ws = workspace(c2.device)
+    call("unetr_outconv_in_bwd", dl.data_ptr(), c2.data_ptr(), C, s2.data_ptr(), c3.data_ptr(), C, s3.data_ptr(), wo.data_ptr(), dout.data_ptr(), C,
+         part.data_ptr(), dw.data_ptr(), db.data_ptr(), B, V, C, cout, ws.data_ptr(), ws.numel() * 4, _a16(c2), _stream())
+    return dout, part, rows, dw, db
+
+
+def instnorm_bwd_apply_fin_dual(dy, lddy, x, sa, x2, sb, part, rows, B, V, C):
+    """(dx, dx2) of y = lrelu(norm(x) + norm(x2)) from dy and the partial sums `part` [B, rows, 3, C]; None when unsupported"""
+    dx, dx2 = torch.empty_like(x), torch.empty_like(x2)
+    rc = call_rc("unetr_instnorm_bwd_apply_fin", dy.data_ptr(), lddy, x.data_ptr(), C, sa.data_ptr(), x2.data_ptr(), C, sb.data_ptr(), part.data_ptr(), rows, 3,
+                 dx.data_ptr(), C, dx2.data_ptr(), C, B, V, C, 1, _a16(x), _stream())
+    return (dx, dx2) if rc == 0 else None
+
+
 def conv3_dgrad_fused(dc1, dc3, w1, w3, dx, dims, prec):
     """dx = conv3x3x3^T(dc1; w1) + conv1x1x1^T(dc3; w3) in one launch (the input gradient of a residual block);
     returns False when the shape has to take the two-kernel route."""
@@ -1470,14 +1516,16 @@ def cat_of_skip(skip, C):
     return skip.as_strided((B, D, H, W, 2 * C), want, 0)
 
 
-def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec, to_cat=False):
-    """MONAI UnetResBlock (instance norm, in != out): lrelu(IN(conv2(lrelu(IN(conv1 x)))) + IN(conv3 x))."""
+def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec, to_cat=False, head=None):
+    """MONAI UnetResBlock (instance norm, in != out): lrelu(IN(conv2(lrelu(IN(conv1 x)))) + IN(conv3 x)).
+    head = (wo, bo) of the out conv that is the block's only consumer: returns (logits [B, Cout, V] or out, saved, fused) -- fused:
+    the block end was folded into the out conv and never stored (the caller applies the out conv itself otherwise)."""
     B, D, H, W = dims
     V = D * H * W
     if in_fuse_level() & 1:
-        r = _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat)
+        r = _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat, head if out_fuse_enabled() else None)
         if r is not None:
-            return r
+            return r if head is not None else r[:2]
     f1 = conv3_fused(x, ldx, w1, w3, dims, prec)
     if f1 is not None:
         c1, s1, c3, s3 = f1
@@ -1506,6 +1554,8 @@ def _resblock_fwd(x, ldx, dims, cin, cout, w1, w2, w3, prec, to_cat=False):
         out = instnorm_apply(c2, s2, B, V, cout, True, x2=c3, sb=s3, out=half, ldo=2 * cout)
     else:
         out = instnorm_apply(c2, s2, B, V, cout, True, x2=c3, sb=s3)
+    if head is not None:
+        return out, (c1, s1, a1, c2, s2, c3, s3), False
     return out, (c1, s1, a1, c2, s2, c3, s3)
 
 
@@ -1518,9 +1568,10 @@ def _materialize_c3(x, w3, dims, cin, cout, prec):
     return _as_act(c3f.view(B, D, H, W, cout), prec)
 
 
-def _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat):
+def _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat, head=None):
     """the same block in FOUR launches: both convs leave their InstanceNorm sums as partial rows and the two apply kernels form
-    the statistics in their prologues (no finalize launches); None when a shape declines (the caller takes the route above)"""
+    the statistics in their prologues (no finalize launches); None when a shape declines (the caller takes the route above).
+    Returns (out, saved, fused); head = (wo, bo): the block end goes into the out conv's kernel when that accepts the shape."""
     B, D, H, W = dims
     V = D * H * W
     cin = w1.shape[1]
@@ -1543,6 +1594,10 @@ def _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat):
     if f2 is None:
         return None
     c2, p2, _, _, rows2 = f2
+    if head is not None and not img and c3 is not None and not to_cat:
+        r = outconv_in_fwd(c2, p2, rows2, c3, p3, rows1, head[0], head[1], B, V, cout)
+        if r is not None:
+            return r[0].view(B, head[0].shape[0], D, H, W), (c1, s1, a1, c2, r[1], c3, r[2]), True
     half = skip_half(dims, cout, prec, x.device)[1] if to_cat else None
     if img:
         r2 = instnorm_apply_fin_img(c2, p2, rows2, x, cin, w3, p3, rows1, B, V, cout, out=half, ldo=2 * cout if to_cat else None)
@@ -1554,22 +1609,34 @@ def _resblock_fwd_fin(x, ldx, dims, cout, w1, w2, w3, prec, to_cat):
     if r2 is None:
         return None
     out, s2, s3 = r2
-    return out, (c1, s1, a1, c2, s2, c3, s3)
+    return out, (c1, s1, a1, c2, s2, c3, s3), False
 
 
-def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_dx):
+def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_dx, head=None):
+    """head = (wo, bo): the block end was folded into the out conv (``_resblock_fwd(..., head=)`` returned fused): ``dout`` is the
+    gradient of the LOGITS; the result then ends with (dwo, dbo)"""
     B, D, H, W = dims
     V = D * H * W
     c1, s1, a1, c2, s2, c3, s3 = saved
+    head_grads = ()
+    dc23 = None
+    if head is not None:
+        dout, hpart, hrows, dwo, dbo = outconv_in_bwd(dout, c2, s2, c3, s3, head[0], head[1], B, V, cout)
+        head_grads = (dwo, dbo)
+        dc23 = instnorm_bwd_apply_fin_dual(dout, cout, c2, s2, c3, s3, hpart, hrows, B, V, cout)
     dout, lddo = _rows(dout)
     img3 = None
-    if c3 is None:
+    if dc23 is not None:
+        pass
+    elif c3 is None:
         # the block on the image: the 1x1x1 branch was never stored -- its gradient is formed per voxel inside the backward apply and
         # leaves only as partial rows of dw3
         img3 = instnorm_bwd_img(dout, lddo, c2, s2, x, cin, w3, s3, B, V, cout)
         if img3 is None:
             c3 = _materialize_c3(x, w3, dims, cin, cout, prec)
-    if img3 is not None:
+    if dc23 is not None:
+        dc2, dc3 = dc23
+    elif img3 is not None:
         dc2, dc3 = img3[0], None
     else:
         dc2, dc3 = instnorm_bwd(dout, lddo, c2, s2, B, V, cout, True, x2=c3, sb=s3)
@@ -1616,6 +1683,8 @@ def _resblock_bwd(dout, x, ldx, dims, cin, cout, w1, w2, w3, saved, prec, need_d
             gemm(dc3.float() if dc3.dtype != torch.float32 else dc3, w3, d32, B * V, cin, cout, lda=cout, ldb=cin, ldc=cin, prec=prec, b_trans=True)
             dx.copy_(d32)
             conv3(dc1, cout, w1, dims, prec, mode=1, out=dx, ldo=cin, accumulate=True)
+    if head is not None:
+        return dx, dw1, dw2, dw3, (q1, q2), head_grads
     return dx, dw1, dw2, dw3, (q1, q2)
 
 
@@ -1671,12 +1740,37 @@ class TconvFn(torch.autograd.Function):
         return dx, dw, None, None
 
 
+def _outconv_fwd(x, ldx, w, b):
+    B, D, H, W, cin = x.shape
+    cout = w.shape[0]
+    logits = torch.empty(B, cout, D, H, W, dtype=torch.float32, device=x.device)
+    call("unetr_outconv_fwd", x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), logits.data_ptr(), B, D * H * W, cin, cout, _a16(x), _stream())
+    return logits
+
+
+def _outconv_bwd(dl, x, ldx, w, b):
+    B, D, H, W, cin = x.shape
+    cout = w.shape[0]
+    dl = dl.contiguous()
+    dx = torch.empty(B, D, H, W, cin, dtype=x.dtype, device=x.device)
+    gw, gb = _gout(w), _gout(b)
+    dw = gw if gw is not None else torch.empty_like(w)
+    db = gb if gb is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
+    ws = workspace(x.device)
+    call("unetr_outconv_bwd", dl.data_ptr(), x.data_ptr(), ldx, w.data_ptr(), dx.data_ptr(), cin, dw.data_ptr(), db.data_ptr(),
+         B, D * H * W, cin, cout, ws.data_ptr(), ws.numel() * 4, _a16(x), _stream())
+    return dx, dw, db
+
+
 class UpBlockFn(torch.autograd.Function):
     """MONAI UnetrUpBlock(res_block=True): tconv(inp) -> cat(up, skip) -> UnetResBlock (unetr.py:135-174).
-    The transposed conv writes straight into the first half of the concatenation buffer."""
+    The transposed conv writes straight into the first half of the concatenation buffer.
+    With (wo, bo) -- the weights of the UnetOutBlock that is this block's only consumer (decoder2 -> out, unetr.py:165-175,206-207)
+    -- the Function returns the LOGITS: the block end lrelu(IN(c2) + IN(c3)) is formed inside the out conv's kernels and never
+    stored (forward: one tensor write + one read fewer; backward: the InstanceNorm backward reduction pass disappears)."""
 
     @staticmethod
-    def forward(ctx, inp, skip, wt, w1, w2, w3, prec, skip_in_cat=False):
+    def forward(ctx, inp, skip, wt, w1, w2, w3, prec, skip_in_cat=False, wo=None, bo=None):
         """skip_in_cat: ``skip`` already is the second half of a concatenation buffer made by functional.skip_half (its
         producer ran with to_cat=True): no copy"""
         _require_gpu(inp, act=True)
@@ -1693,21 +1787,41 @@ class UpBlockFn(torch.autograd.Function):
             skip, lds = _rows(_as_act(skip, prec))
             _, ctx.xb = tconv_fwd(inp, ldi, wt, (B, D, H, W), cin, C, prec, out=cat, ldo=2 * C)
             call("unetr_copy_rows", cat.data_ptr() + cat.element_size() * C, 2 * C, skip.data_ptr(), lds, rows2, C, 0, _a16(cat), _stream())
-        out, saved = _resblock_fwd(cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, prec)
-        ctx.save_for_backward(inp, wt, w1, w2, w3, cat, *saved)
         ctx.meta = (ldi, (B, D, H, W), cin, C, prec)
-        return out
+        if wo is None:
+            out, saved = _resblock_fwd(cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, prec)
+            ctx.head = None
+            ctx.save_for_backward(inp, wt, w1, w2, w3, cat, *saved)
+            return out
+        res, saved, fused = _resblock_fwd(cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, prec, head=(wo, bo))
+        ctx.head = fused
+        if fused:
+            ctx.save_for_backward(inp, wt, w1, w2, w3, cat, wo, bo, *saved)
+            return res
+        ctx.save_for_backward(inp, wt, w1, w2, w3, cat, wo, bo, res, *saved)
+        return _outconv_fwd(res, C, wo, bo)
 
     @staticmethod
     def backward(ctx, dout):
-        inp, wt, w1, w2, w3, cat, *saved = ctx.saved_tensors
         ldi, dims, cin, C, prec = ctx.meta
         B, D, H, W = dims
         dims2 = (B, 2 * D, 2 * H, 2 * W)
-        dcat, dw1, dw2, dw3, (q1, q2) = _resblock_bwd(dout, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True)
+        head_ret = (None, None)
+        if ctx.head is None:
+            inp, wt, w1, w2, w3, cat, *saved = ctx.saved_tensors
+            dcat, dw1, dw2, dw3, (q1, q2) = _resblock_bwd(dout, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True)
+        elif ctx.head:
+            inp, wt, w1, w2, w3, cat, wo, bo, *saved = ctx.saved_tensors
+            dcat, dw1, dw2, dw3, (q1, q2), (dwo, dbo) = _resblock_bwd(dout, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True, head=(wo, bo))
+            head_ret = (_ret(wo, dwo), _ret(bo, dbo))
+        else:
+            inp, wt, w1, w2, w3, cat, wo, bo, out, *saved = ctx.saved_tensors
+            dblk, dwo, dbo = _outconv_bwd(dout, out, C, wo, bo)
+            dcat, dw1, dw2, dw3, (q1, q2) = _resblock_bwd(dblk, cat, 2 * C, dims2, 2 * C, C, w1, w2, w3, saved, prec, True)
+            head_ret = (_ret(wo, dwo), _ret(bo, dbo))
         dinp, dwt = tconv_bwd(inp, ldi, ctx.xb, dcat, 2 * C, wt, dims, cin, C, prec, ctx.needs_input_grad[0])
         dskip = dcat[..., C:] if ctx.needs_input_grad[1] else None
-        return dinp, dskip, dwt, _ret(w1, dw1, deferred=q1), _ret(w2, dw2, deferred=q2), _ret(w3, dw3, deferred=q1), None, None
+        return (dinp, dskip, dwt, _ret(w1, dw1, deferred=q1), _ret(w2, dw2, deferred=q2), _ret(w3, dw3, deferred=q1), None, None) + head_ret
 
 
 class OutConvFn(torch.autograd.Function):
@@ -1717,26 +1831,14 @@ class OutConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         _require_gpu(x, act=True)
         x, ldx = _rows(x)
-        B, D, H, W, cin = x.shape
-        cout = w.shape[0]
-        logits = torch.empty(B, cout, D, H, W, dtype=torch.float32, device=x.device)
-        call("unetr_outconv_fwd", x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), logits.data_ptr(), B, D * H * W, cin, cout, _a16(x), _stream())
         ctx.save_for_backward(x, w, b)
-        ctx.meta = (ldx, (B, D, H, W), cin, cout)
-        return logits
+        ctx.ldx = ldx
+        return _outconv_fwd(x, ldx, w, b)
 
     @staticmethod
     def backward(ctx, dl):
         x, w, b = ctx.saved_tensors
-        ldx, (B, D, H, W), cin, cout = ctx.meta
-        dl = dl.contiguous()
-        dx = torch.empty(B, D, H, W, cin, dtype=x.dtype, device=x.device)
-        gw, gb = _gout(w), _gout(b)
-        dw = gw if gw is not None else torch.empty_like(w)
-        db = gb if gb is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
-        ws = workspace(x.device)
-        call("unetr_outconv_bwd", dl.data_ptr(), x.data_ptr(), ldx, w.data_ptr(), dx.data_ptr(), cin, dw.data_ptr(), db.data_ptr(),
-             B, D * H * W, cin, cout, ws.data_ptr(), ws.numel() * 4, _a16(x), _stream())
+        dx, dw, db = _outconv_bwd(dl, x, ctx.ldx, w, b)
         return dx, _ret(w, dw), _ret(b, db)
 
 

@@ -383,8 +383,9 @@ class UNETR(nn.Module):
         d = self.decoder3
         dec1 = Fn.UpBlockFn.apply(dec2, enc2, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
         d = self.decoder2
-        out = Fn.UpBlockFn.apply(dec1, enc1, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True)
-        logits = Fn.OutConvFn.apply(out, self.out.conv.conv.weight, self.out.conv.conv.bias)
+        # (the out conv is decoder2's only consumer: its kernels form the block end themselves -- UpBlockFn with the head's weights)
+        logits = Fn.UpBlockFn.apply(dec1, enc1, d.transp_conv.conv.weight, *self._res_w(d.conv_block), prec, True,
+                                    self.out.conv.conv.weight, self.out.conv.conv.bias)
         return Fn.ToNCDHWFn.apply(enc4), logits
 
     def forward(self, x_in, freeze_encoder=False):

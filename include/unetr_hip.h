@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 13
+#define UNETR_ABI_VERSION 14
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -358,6 +358,20 @@ int unetr_outconv_fwd(const void* x, long ldx, const float* w, const float* bias
 int unetr_outconv_bwd(const float* dlogits, const void* x, long ldx, const float* w, void* dx, long lddx,
                       float* dw, float* dbias, int B, long V, int Cin, int Cout,
                       float* ws, size_t ws_bytes, int act16, void* stream);
+
+/* decoder2's block end folded into the out conv (reference: UnetrUpBlock's UnetResBlock followed by UnetOutBlock,
+ * /root/reference/unetr.py:165-175,206-207): out = lrelu(IN(c2) + IN(c3)) is formed per voxel and never stored.
+ * unetr_outconv_in_fwd: logits [B][Cout][V] from c2 / c3 [B][V][C] and their InstanceNorm partial rows; writes stats_a / stats_b.
+ * unetr_outconv_in_bwd: dout = W^T dlogits (stored, pitch lddo), the InstanceNorm backward partial rows in_part [B][rows][3][C]
+ * (rows = unetr_outconv_in_bwd_rows; feed unetr_instnorm_bwd_apply_fin with nsp = 3), dw [Cout][C], dbias [Cout].
+ * UNETR_ERR_UNSUPPORTED (Cout > 4, C > 16, ...) = run the unfused sequence. */
+int unetr_outconv_in_fwd(const void* c2, long ld2, const float* part_a, int rows_a, const void* c3, long ld3, const float* part_b,
+                         int rows_b, float* stats_a, float* stats_b, float eps, const float* w, const float* bias, float* logits,
+                         int B, long V, int C, int Cout, int act16, void* stream);
+long unetr_outconv_in_bwd_rows(int B, long V, int C, int act16);
+int unetr_outconv_in_bwd(const float* dlogits, const void* c2, long ld2, const float* sa, const void* c3, long ld3, const float* sb,
+                         const float* w, void* dout, long lddo, float* in_part, float* dw, float* dbias,
+                         int B, long V, int C, int Cout, float* ws, size_t ws_bytes, int act16, void* stream);
 
 /* ---- DiceCELoss (unetr_segmentation_3d.py:404 and :477-482) -------------------------------------------
  * sigmoid_multilabel = 0: DiceCELoss(to_onehot_y=True, softmax=True); label [B,V] float-valued class ids.

@@ -62,7 +62,12 @@ def test_gemm_bf16_storage(pkg, dev, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,force", [(6912, 2304, 768, 0), (6912, 3072, 768, 0), (6912, 768, 3072, 0), (1030, 520, 192, 4), (1024, 512, 64, 4),
                                          (2100, 772, 128, 4), (1500, 1026, 320, 4), (300, 256, 3072, 4), (1030, 520, 192, 3), (2100, 772, 128, 3),
-                                         (1500, 1026, 320, 2), (1024, 384, 64, 3), (1300, 130, 256, 2)])
+                                         (1500, 1026, 320, 2), (1024, 384, 64, 3), (1300, 130, 256, 2),
+                                         # the three-buffer ring kernel (tile widths 128 / 64): 1, 2, 3, 4, 7 and 48 K tiles
+                                         (1024, 512, 64, 2), (2100, 772, 128, 2), (1030, 520, 192, 2), (300, 256, 3072, 2), (1030, 200, 448, 1),
+                                         (1024, 64, 64, 1), (1300, 130, 256, 1), (700, 1026, 128, 1),
+                                         # negative: the two-phase kernel at width 128 (UNETR_GEMM_RING=0)
+                                         (1500, 1026, 320, -2), (6912, 768, 3072, -2)])
 def test_gemm_bf16_big_tile(pkg, dev, monkeypatch, M, N, K, force):
     """The 256 x {256, 192, 128} ping-pong kernel (8 waves, two groups one barrier interval apart, LDS-DMA into half-tile regions):
     picked by itself at encoder shapes of batch 32 (N = 2304 / 3072 / 768 -> tile widths 256 / 192 / 128), forced (UNETR_GEMM_CFG=256,
@@ -70,9 +75,11 @@ def test_gemm_bf16_big_tile(pkg, dev, monkeypatch, M, N, K, force):
     5 / 48 K tiles (odd and even counts walk both LDS buffers), N % 4 != 0 (scalar epilogue) -- with every epilogue kind,
     against fp64 products of the same bf16 inputs."""
     Fn = pkg.functional
-    if force:                       # force = columns / 64 of the tile (256 x 256 / 192 / 128); 0 = the dispatcher's own choice
+    if force:                       # force = columns / 64 of the tile (256 x 256 / 192 / 128 / 64); 0 = the dispatcher's own choice
         monkeypatch.setenv("UNETR_GEMM_CFG", "256")
-        monkeypatch.setenv("UNETR_GEMM_BIG_WN", str(force))
+        monkeypatch.setenv("UNETR_GEMM_BIG_WN", str(abs(force)))
+        if force < 0:
+            monkeypatch.setenv("UNETR_GEMM_RING", "0")
     L = 206 if M == 1030 else M
     x, w = g(M, K, seed=1).bfloat16(), g(N, K, seed=2, scale=0.1).bfloat16()
     b, res, aux = g(N, seed=3), g(L, N, seed=4), g(M, N, seed=6)
@@ -865,6 +872,51 @@ def test_skip_written_into_concat_buffer(pkg, dev, prec, producer):
     # a tensor that is not the second half of such a buffer is refused rather than overwritten
     with pytest.raises(RuntimeError):
         Fn.UpBlockFn.apply(inp, torch.zeros(B, 2 * S, 2 * S, 2 * S, C, device=dev, dtype=adt), wt, w1, w2, w3, prec, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("B,S,C,ncls", [(2, 8, 16, 4), (1, 6, 16, 2), (2, 5, 16, 3), (1, 8, 8, 4), (2, 6, 16, 14)])
+def test_upblock_with_out_conv_head(pkg, dev, monkeypatch, prec, B, S, C, ncls):
+    """decoder2 + UnetOutBlock (unetr.py:165-175,206-207) as ONE Function: the block end lrelu(IN(c2) + IN(c3)) is formed inside the
+    out conv's kernels and never stored (csrc/norm_misc.hip: outconv_in_fwd_kernel / outconv_in_bwd_kernel).  Fused against the
+    stored sequence (UNETR_AMD_OUT_FUSE=0) to rounding -- logits and all eight gradients -- and both against torch autograd;
+    14 classes and 8 channels (bf16: one piece per voxel) also run: the first declines the fused kernels (Cout > 4) and must take
+    the stored sequence by itself."""
+    Fn = pkg.functional
+    adt = Fn.act_dtype(prec)
+    inp0 = rq(g(B, 2 * C, S, S, S, seed=1), prec)
+    skip0 = rq(g(B, C, 2 * S, 2 * S, 2 * S, seed=2), prec)
+    ws0 = [g(2 * C, C, 2, 2, 2, seed=3) * 0.2, g(C, 2 * C, 3, 3, 3, seed=4) * 0.1, g(C, C, 3, 3, 3, seed=5) * 0.1, g(C, 2 * C, 1, 1, 1, seed=6) * 0.2,
+           g(ncls, C, 1, 1, 1, seed=7) * 0.3, g(ncls, seed=8)]
+    dl = g(B, ncls, 2 * S, 2 * S, 2 * S, seed=9)
+    # torch autograd on the same (storage-rounded) inputs
+    ir, sr = inp0.clone().requires_grad_(True), skip0.clone().requires_grad_(True)
+    wr = [t.clone().requires_grad_(True) for t in ws0]
+    cat = torch.cat((F.conv_transpose3d(ir, wr[0], stride=2), sr), dim=1)
+    a1 = F.leaky_relu(F.instance_norm(F.conv3d(cat, wr[1], padding=1)), 0.01)
+    blk = F.leaky_relu(F.instance_norm(F.conv3d(a1, wr[2], padding=1)) + F.instance_norm(F.conv3d(cat, wr[3])), 0.01)
+    ref = F.conv3d(blk, wr[4], wr[5])
+    ref.backward(dl)
+    ref_all = [ref.detach(), cl(ir.grad), cl(sr.grad)] + [t.grad for t in wr]
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("UNETR_AMD_OUT_FUSE", fuse)
+        leaves = [cl(inp0).to(dev).requires_grad_(True), cl(skip0).to(dev).requires_grad_(True)] + [t.to(dev).requires_grad_(True) for t in ws0]
+        i_, s_, wt, w1, w2, w3, wo, bo = leaves
+        logits = Fn.UpBlockFn.apply(i_.to(adt), s_.to(adt), wt, w1, w2, w3, prec, False, wo, bo)
+        assert logits.shape == (B, ncls, 2 * S, 2 * S, 2 * S) and logits.dtype == torch.float32
+        logits.backward(dl.to(dev))
+        res[fuse] = [logits.detach().cpu()] + [t.grad.float().cpu() for t in leaves]
+    tol_pair = 2e-4 if prec != 1 else 2e-2
+    tol_ref = 2e-3 if prec != 1 else 6e-2
+    for k, (a, b) in enumerate(zip(res["0"], res["1"])):
+        assert relerr(a, b) < tol_pair, k
+    for k, (a, r) in enumerate(zip(res["1"], ref_all)):
+        if prec == 1 and k > 0:       # bf16-stored intermediates: gradients through two InstanceNorms are compared by direction
+            assert F.cosine_similarity(a.double().flatten(), r.double().flatten(), dim=0).item() > 0.995, k
+        else:
+            assert relerr(a, r) < tol_ref, k
 
 
 @pytest.mark.gpu
