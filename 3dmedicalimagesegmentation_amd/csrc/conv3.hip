@@ -1592,6 +1592,192 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
     }
 }
 
+// ---- bf16x3 weight gradient on (hi, lo) bf16 images ---------------------------------------------------------------------------
+// The 4-byte fragment path above (fp32 and bf16x3 modes) feeds every MFMA operand with four ds_read_b32 per lane: 8 LDS instructions
+// per 2 MFMAs saturate the LDS pipe (366 us for a 96^3 16-channel layer against 105 us for the bf16 kernel).  Voxel-contiguous b128
+// fragments are not available -- the 27 taps shift the window along every axis, and a misaligned ds_read_b128 is replayed at 64
+// cycles -- but the transposing 16-bit read is: this kernel splits the fp32-stored window and gradient tiles into TWO bf16 images
+// each while staging (hi = bf16(v), lo = bf16(v - hi)), both in the conflict-free layout of the bf16 kernel (LAY 2, 32-byte voxels),
+// and runs the bf16 kernel's software-pipelined (k-block, unit) line with three MFMAs per step,
+//     dw += dy_hi x_hi + dy_hi x_lo + dy_lo x_hi        (v_mfma_f32_16x16x32_bf16, fp32 accumulate; the lo-lo term is 2^-16 of the sum)
+// four ds_read_b64_tr_b16 per 3 MFMAs over 32 voxels instead of eight ds_read_b32 per 4 MFMAs.  16-channel input slab, 16-channel
+// output tile, one partial row per workgroup -- grid and partial layout of conv3_wgrad_kernel<P, ., ., HAS3, 1, .>.
+template <bool HAS3>
+__global__ void __launch_bounds__(256, 2)
+conv3_wgrad_x3_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
+                      const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
+                      int D, int H, int W, int Cin, int Cout, int ntx, int nty, int ntz, int ntiles) {
+    constexpr int PX = 32, PY = 32, XB = NHALO * PX, YB = NVOX * PY;
+    constexpr int NKB = NVOX / 32, NU = 27, NUX = NU + (HAS3 ? 1 : 0), UPW = (NUX + 3) / 4;
+    __shared__ __attribute__((aligned(16))) char lds[2 * XB + (HAS3 ? 4 : 2) * YB];
+    char* const xhi = lds;
+    char* const xlo = lds + XB;
+    char* const yhi = lds + 2 * XB;
+    char* const ylo = yhi + YB;
+    char* const y3hi = ylo + YB;
+    char* const y3lo = y3hi + YB;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, g = lane >> 4;
+    const int ci0 = blockIdx.y * 16, co0 = blockIdx.z * 16;
+    // per-unit window offsets (wave-uniform) and the per-lane parts of the transposing reads: as in conv3_wgrad_kernel's FLIP path
+    int uoff[UPW];
+#pragma unroll
+    for (int ui = 0; ui < UPW; ++ui) {
+        const int u = wv + 4 * ui;
+        const int tap = u >= NU ? 13 : u;
+        const int dz = tap / 9, rem = tap - dz * 9, dyy = rem / 3;
+        uoff[ui] = ((dz * HY + dyy) * HX) * PX;
+    }
+    int xs0[3], xs1[3], xc0, xc1, ylane0, ylane1;
+    {
+        const int q = c >> 2, p = c & 3;
+        const int xl = (8 * g + q) & 15;
+        const int lane_zy = (g >> 1) * HX * PX + 8 * p;
+        int t0[3], t1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { t0[d] = lay_flip(xl + d) * PX + lane_zy; t1[d] = lay_flip(xl + 4 + d) * PX + lane_zy; }
+        const int w3 = wv % 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int d = (w3 + j) % 3;
+            xs0[j] = d == 0 ? t0[0] : (d == 1 ? t0[1] : t0[2]);
+            xs1[j] = d == 0 ? t1[0] : (d == 1 ? t1[1] : t1[2]);
+        }
+        xc0 = t0[1]; xc1 = t1[1];
+        ylane0 = lay_flip(8 * g + q) * PY + 8 * p;
+        ylane1 = lay_flip(8 * g + q + 4) * PY + 8 * p;
+    }
+    f32x4 acc[UPW];
+#pragma unroll
+    for (int ui = 0; ui < UPW; ++ui) acc[ui] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // four fp32 channels -> 8 bytes of the hi image and 8 bytes of the lo image
+    auto put = [&](f32x4 v, char* hi, char* lo, int off) __attribute__((always_inline)) {
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+#ifdef UNETR_X3_DROP_LO
+        const bf16x4 l = __builtin_convertvector((f32x4){0.f, 0.f, 0.f, 0.f}, bf16x4);
+#else
+        const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+#endif
+        *(bf16x4*)(hi + off) = h;
+        *(bf16x4*)(lo + off) = l;
+    };
+    constexpr int XIT = (NHALO * 4 + 255) / 256, SB = 6;       // window: 648 voxels x 4 quads of channels; SB loads in flight
+    TileTable tt;
+    int kt = 0, tx = 0, ty = 0, tz = 0, b = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++kt) {
+        tt.get(kt, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+        __syncthreads();                                       // the previous tile's fragment reads are done
+        // dy (and dy3) tile: 256 voxels x 4 quads, one per thread and quarter
+        {
+            f32x4 yb[4], y3b[HAS3 ? 4 : 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int id = threadIdx.x + j * 256, v = id >> 2, qd = id & 3;
+                const int gz = z0 + (v >> 6), gy = y0 + ((v >> 4) & 3), gx = x0 + (v & 15), cc = co0 + 4 * qd;
+                const bool ok = gz < D && gy < H && gx < W && cc < Cout;
+                const long vox = (((long)b * D + gz) * H + gy) * W + gx;
+                const f32x4 t = *(const f32x4*)(ok ? dy + vox * lddy + cc : dy);
+                yb[j] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (HAS3) {
+                    const f32x4 t3 = *(const f32x4*)(ok ? dy3 + vox * lddy3 + cc : dy3);
+                    y3b[j] = ok ? t3 : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int id = threadIdx.x + j * 256, v = id >> 2, qd = id & 3;
+                const int off = lay_flip(v) * PY + qd * 8;
+                put(yb[j], yhi, ylo, off);
+                if constexpr (HAS3) put(y3b[j], y3hi, y3lo, off);
+            }
+        }
+        // window
+        for (int it0 = 0; it0 < XIT; it0 += SB) {
+            f32x4 xb[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int id = threadIdx.x + (it0 + j) * 256, hv = id >> 2, qd = id & 3;
+                const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1, cc = ci0 + 4 * qd;
+                const bool ok = (it0 + j < XIT) && hv < NHALO && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
+                                (unsigned)gx < (unsigned)W && cc < Cin;
+                const f32x4 t = *(const f32x4*)(ok ? x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + cc : x);
+                xb[j] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int id = threadIdx.x + (it0 + j) * 256, hv = id >> 2, qd = id & 3;
+                if (it0 + j < XIT && hv < NHALO) {
+                    const int hx = hv % HX;
+                    put(xb[j], xhi, xlo, (hv - hx + lay_flip(hx)) * PX + qd * 8);
+                }
+            }
+        }
+        __syncthreads();
+        // the NKB x UPW (k-block, unit) steps as one software-pipelined straight line (see conv3_wgrad_kernel's fast path)
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        constexpr int NST = NKB * UPW, DPT = 3;
+        auto tr2 = [&](const char* img, int o0, int o1) __attribute__((always_inline)) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + o0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + o1));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(u32x4, v);
+        };
+        auto bread = [&](int st, u32x4& bh, u32x4& bl) __attribute__((always_inline)) {
+            const int kb = st / UPW, ui = st % UPW;
+            const bool ext1 = HAS3 && ui == UPW - 1 && wv + 4 * ui >= NU;     // wave-uniform
+            const int uo = ((kb >> 1) * HY + (kb & 1) * 2) * HX * PX + uoff[ui];
+            const int o0 = uo + (ext1 ? xc0 : xs0[ui % 3]), o1 = uo + (ext1 ? xc1 : xs1[ui % 3]);
+            bh = tr2(xhi, o0, o1);
+            bl = tr2(xlo, o0, o1);
+        };
+        u32x4 rbh[DPT], rbl[DPT];
+        u32x4 ah[2], al[2], a3h = {0u, 0u, 0u, 0u}, a3l = {0u, 0u, 0u, 0u};
+        ah[0] = tr2(yhi, ylane0, ylane1);
+        al[0] = tr2(ylo, ylane0, ylane1);
+#pragma unroll
+        for (int st = 0; st < DPT; ++st) bread(st, rbh[st], rbl[st]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int kb = st / UPW, ui = st % UPW;
+            if (ui == 0 && kb + 1 < NKB) {
+                const int ykb = (kb + 1) * 32 * PY;
+                ah[(kb + 1) & 1] = tr2(yhi, ykb + ylane0, ykb + ylane1);
+                al[(kb + 1) & 1] = tr2(ylo, ykb + ylane0, ykb + ylane1);
+            }
+            if constexpr (HAS3) {
+                if (ui == UPW - 3) { const int ykb = kb * 32 * PY; a3h = tr2(y3hi, ykb + ylane0, ykb + ylane1); a3l = tr2(y3lo, ykb + ylane0, ykb + ylane1); }
+            }
+            const u32x4 bh = rbh[st % DPT], bl = rbl[st % DPT];
+            const bool ext1 = HAS3 && ui == UPW - 1 && wv + 4 * ui >= NU;
+            const u32x4 fh = ext1 ? a3h : ah[kb & 1], fl = ext1 ? a3l : al[kb & 1];
+            PrecBF16::mma(acc[ui], fh, bh);
+            PrecBF16::mma(acc[ui], fh, bl);
+            PrecBF16::mma(acc[ui], fl, bh);
+            if (st + DPT < NST) bread(st + DPT, rbh[st % DPT], rbl[st % DPT]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // partial sums: part[blockIdx.x][co][ci][tap]
+#pragma unroll
+    for (int ui = 0; ui < UPW; ++ui) {
+        const int u = wv + 4 * ui;
+        if (u < NUX) {
+            const int ci = ci0 + c;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int co = co0 + 4 * g + rr;
+                if (ci < Cin && co < Cout) {
+                    if (u < NU) part[(((long)blockIdx.x * Cout + co) * Cin + ci) * 27 + u] = acc[ui][rr];
+                    else part3[((long)blockIdx.x * Cout + co) * Cin + ci] = acc[ui][rr];
+                }
+            }
+        }
+    }
+}
+
 // Weight gradient of the same single-input-channel conv (+ its 1x1x1 branch): dw[co][tap] = sum_v dy[v, co] x[v + off(tap)],
 // dw3[co] = sum_v dy3[v, co] x[v].  The generic kernel contracts over voxels with the window zero-padded to 16 channels (70 us
 // at 96^3 for 114 MB of gradient maps); here the tap is the OUTPUT column: per 32-voxel k-block two MFMAs [16 co x 32 voxels] x
@@ -2040,6 +2226,34 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
             const int blocks = (int)cdiv(n1, 32), blocks3 = dy3 ? 1 : 0;
             if (!parts_only)
                 hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)rows, n1, dw, blocks, (const float*)wsb, n31, dw3);
+            return unetr_check_launch();
+        }
+    }
+    if constexpr (std::is_same<P, PrecBF16x3>::value) {
+        // bf16x3: the (hi, lo) bf16-image kernel (conv3_wgrad_x3_kernel) wherever rows of x / dy / dy3 are whole 16-byte quads of channels
+        // (UNETR_X3_WGRAD_TR16=0: the 4-byte fragment path below, kept for A/B runs and for the shapes this form declines)
+        const char* e = getenv("UNETR_X3_WGRAD_TR16");
+        const bool q16 = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy3) & 15) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (Cin & 3) == 0 &&
+                         (Cout & 3) == 0 && (!dy3 || (lddy3 & 3) == 0);
+        if (q16 && Cin >= 8 && !(e && atoi(e) == 0)) {
+            const int nci = cdiv(Cin, 16), nco = cdiv(Cout, 16);
+            const long n = 27L * Cin * Cout, n3 = dy3 ? (long)Cin * Cout : 0;
+            long G = std::min<long>(ntiles, std::max<long>(1, 512 / ((long)nci * nco)));
+            if (const char* t = getenv("UNETR_TEST_MAX_WG")) { if (atoi(t) > 0) G = std::min<long>(G, atoi(t)); }
+            if (rows_only) { *rows_only = G; return UNETR_OK; }
+            while (G > 1 && (size_t)G * (n + n3) * sizeof(float) > ws_bytes) G >>= 1;
+            if (!ws || (size_t)G * (n + n3) * sizeof(float) > ws_bytes) return UNETR_ERR_WORKSPACE;
+            if (nci > 65535 || nco > 65535) return UNETR_ERR_ARG;
+            if (rows_used) *rows_used = G;
+            float* ws3 = ws + (size_t)G * n;
+            if (dy3) hipLaunchKernelGGL((conv3_wgrad_x3_kernel<true>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, ws,
+                                        (const float*)dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);
+            else hipLaunchKernelGGL((conv3_wgrad_x3_kernel<false>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, ws,
+                                    (const float*)nullptr, 0L, (float*)nullptr, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);
+            const int blocks = (int)std::min<long>((n + 31) / 32, 16384);
+            const int blocks3 = dy3 ? (int)std::min<long>((n3 + 31) / 32, 16384) : 0;
+            if (!parts_only)
+                hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(blocks + blocks3), dim3(256), 0, st, ws, (int)G, n, dw, blocks, (const float*)ws3, n3, dw3);
             return unetr_check_launch();
         }
     }

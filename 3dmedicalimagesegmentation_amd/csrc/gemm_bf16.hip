@@ -567,150 +567,8 @@ gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
     big_epilogue<WN>(acc, ep, lds, M, N, m0, n0, wave, lane, wr, wc);
 }
 
-// ---- the large-tile kernel as a THREE-buffer ring with ONE phase per K tile (narrow tiles: WN <= 2) ---------------------------
-// Why: in the two-phase schedule above every barrier interval carries 8 WN MFMAs per wave next to a fixed ~500 cycles of fragment
-// reads, waits and barrier; at WN = 2 (256 x 128 tiles: the N = 768 shapes, 162 tiles) that is 16 MFMAs = 256 matrix-pipe cycles
-// per interval -- the K tile took 1.29 us for half the MFMAs of the 1.72 us 256 x 256 tile.  Here a wave reads ALL its fragments
-// of a K tile (16 A + 2 WN B reads) in one mem segment and issues all 16 WN MFMAs in one compute segment: two intervals per K
-// tile instead of four.  The two M-halves still alternate (group 0 = waves 0-3 computes while group 1 = waves 4-7 reads).
-//
-// Three K-tile buffers of 32 + 8 WN KB (WN = 2: 144 KB), tile T in buffer T % 3.  Each group DMAs its OWN regions of a K tile --
-// its 128 A rows and its half of the B rows (4 + WN pieces per thread) -- so a group's issue points follow its own schedule:
-//   group 0, tile T:  mem(T)     = { DMA(T+2) -> buffer (T+2) % 3;  reads of tile T;  lgkmcnt(0);  barrier }            interval 2T
-//                     compute(T) = { 16 WN MFMAs;  vmcnt: its DMA(T+1) has landed;  barrier }                             interval 2T+1
-//   group 1, tile T:  mem(T)     = { reads of tile T;  lgkmcnt(0);  vmcnt: its DMA(T+1) has landed;  barrier }           interval 2T+1
-//                     compute(T) = { DMA(T+3) -> buffer T % 3;  16 WN MFMAs;  barrier }                                   interval 2T+2
-// Write-after-read: buffer (T+2) % 3 held tile T-1, last read by group 1 in interval 2T-1 (retired by its lgkmcnt(0) before that
-// interval's barrier), group 0 overwrites it from interval 2T on; buffer T % 3 is last read in interval 2T+1 and group 1 overwrites
-// it from interval 2T+2 on.  Read-after-write: every wave's pieces of tile T+1 are waited for before the barrier that ends
-// interval 2T+1, and tile T+1 is first read in interval 2T+2.  A DMA has 3-4 intervals (1.5-2 K tiles) to land.
-template <int WN>
-__global__ void __launch_bounds__(512, 2)
-gemm_bf16_ring_kernel(int M, int N, int K, int mt, int nt, int n_fast,
-                      const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep) {
-    constexpr int HALF = 128 * 128, BN = 64 * WN, BUFB = 2 * HALF + BN * 128, NB = 3, G = 4 + WN;
-    constexpr int LDSB = NB * BUFB > 8 * 16384 ? NB * BUFB : 8 * 16384;
-    static_assert(LDSB <= 160 * 1024, "three K-tile buffers must fit the CU's LDS");
-    __shared__ __attribute__((aligned(1024))) char lds[LDSB];
-
-    int tm, tn;
-    {
-        const int T = mt * nt, per = (T + 7) >> 3, L = blockIdx.x;
-        const int t = (L & 7) * per + (L >> 3);
-        if ((L >> 3) >= per || t >= T) return;
-        if (n_fast) { tn = t % nt; tm = t / nt; } else { tm = t % mt; tn = t / mt; }
-    }
-    const int m0 = tm * 256, n0 = tn * BN;
-    const int nk = K / 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
-    const int tg = tid & 255;                    // thread within its group
-
-    // DMA sources of this thread's pieces of its group's regions (row r of a region, 16-byte slot id & 7 <- global chunk
-    // (id & 7) ^ ((r >> 1) & 7); the B half starts at a multiple of 16 rows, so the swizzle term is that of the local row)
-    const uint16_t* asrc[4];
-    const uint16_t* bsrc[WN];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tg + i * 256, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
-        asrc[i] = A + (long)min(m0 + wr * 128 + r, M - 1) * lda + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-        const int id = tg + i * 256, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
-        bsrc[i] = B + (long)min(n0 + wr * (32 * WN) + r, N - 1) * ldb + c * 8;
-    }
-    auto dma = [&](int T, char* buf) __attribute__((always_inline)) {
-        char* da = buf + wr * HALF + (wave & 3) * 1024;
-        char* db = buf + 2 * HALF + wr * (32 * WN * 128) + (wave & 3) * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + (long)T * 64), (lds_void_t*)(da + i * 4096), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WN; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[i] + (long)T * 64), (lds_void_t*)(db + i * 4096), 16, 0, 0);
-    };
-    int off[2];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) off[kh] = lds_tile_off(lane & 15, kh * 4 + (lane >> 4));
-
-    f32x4 acc[8][WN];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4 af[8][2], bf[WN][2];
-
-#define RING_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
-#define RING_BARRIER() do { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-    // prologue: tiles 0 and 1 (group 1 also tile 2: its steady-state issue point for tile T+3 is compute(T)); tile 0 has landed
-    // and is published before anybody reads
-    dma(0, lds);
-    if (nk > 1) dma(1, lds + BUFB);
-    if (wr == 1 && nk > 2) dma(2, lds + 2 * BUFB);
-    if (wr == 0) { if (nk > 1) RING_WAIT(G); else RING_WAIT(0); }
-    else { if (nk > 2) RING_WAIT(2 * G); else if (nk > 1) RING_WAIT(G); else RING_WAIT(0); }
-    RING_BARRIER();
-    if (wr == 1) RING_BARRIER();              // group 1 runs one interval behind group 0
-
-    auto reads = [&](const char* cur) __attribute__((always_inline)) {
-        const char* la = cur + wr * HALF;
-        const char* lb = cur + 2 * HALF + wc * (16 * WN) * 128;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j][kh] = *(const u32x4*)(lb + off[kh] + j * 2048);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) af[i][kh] = *(const u32x4*)(la + off[kh] + i * 2048);
-        }
-    };
-    auto mfmas = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], bf[j][kh], af[i][kh]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto ktile = [&](int T, auto bufc) __attribute__((always_inline)) {
-        constexpr int b = decltype(bufc)::value;
-        char* const cur = lds + b * BUFB;
-        const bool n1 = T + 1 < nk, n2 = T + 2 < nk;
-        if (wr == 0) {
-            if (n2) dma(T + 2, lds + ((b + 2) % NB) * BUFB);
-            reads(cur);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            RING_BARRIER();
-            mfmas();
-            __builtin_amdgcn_sched_barrier(0);
-            if (n2) RING_WAIT(G); else if (n1) RING_WAIT(0);
-            RING_BARRIER();
-        } else {
-            reads(cur);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (n2) RING_WAIT(G); else if (n1) RING_WAIT(0);
-            RING_BARRIER();
-            if (T + 3 < nk) dma(T + 3, cur);
-            mfmas();
-            __builtin_amdgcn_sched_barrier(0);
-            if (n1) RING_BARRIER();           // group 1 skips its very last barrier: both groups execute the same number
-        }
-    };
-    for (int T = 0; T < nk; T += 3) {
-        ktile(T, BufC<0>{});
-        if (T + 1 < nk) ktile(T + 1, BufC<1>{});
-        if (T + 2 < nk) ktile(T + 2, BufC<2>{});
-    }
-#undef RING_WAIT
-#undef RING_BARRIER
-    big_epilogue<WN>(acc, ep, lds, M, N, m0, n0, wave, lane, wr, wc);
-}
-
 static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep, hipStream_t st, int wn) {
     const int BN = 64 * wn;
-    const int ring = getenv("UNETR_GEMM_RING") ? atoi(getenv("UNETR_GEMM_RING")) : 1;     // 0: the two-phase kernel at WN = 2
     const int mt = cdiv(M, 256), nt = cdiv(N, BN);
     const long tiles = (long)mt * nt;
     // traffic of the two tile orders, in rows of K elements fetched per XCD pass: m fastest re-reads A for every weight column
@@ -719,10 +577,8 @@ static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, con
     const int n_fast = cost_n < cost_m;
     const int per = cdiv(tiles, 8);
 #define BIG_GO(W_) hipLaunchKernelGGL(gemm_bf16_big_kernel<W_>, dim3(per * 8), dim3(512), 0, st, M, N, K, mt, nt, n_fast, A, lda, B, ldb, ep)
-#define RING_GO(W_) hipLaunchKernelGGL(gemm_bf16_ring_kernel<W_>, dim3(per * 8), dim3(512), 0, st, M, N, K, mt, nt, n_fast, A, lda, B, ldb, ep)
-    if (wn == 2) { if (ring) RING_GO(2); else BIG_GO(2); } else if (wn == 1) RING_GO(1); else if (wn == 3) BIG_GO(3); else BIG_GO(4);
+    if (wn == 2) BIG_GO(2); else if (wn == 3) BIG_GO(3); else BIG_GO(4);
 #undef BIG_GO
-#undef RING_GO
     return unetr_check_launch();
 }
 
@@ -730,7 +586,7 @@ static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, con
 // tile (K-loop share ~ wn + 1: MFMAs scale with wn, the A half of the DMA and the fragment reads do not; + a fixed prologue /
 // epilogue share).  0 = the 128 x 128 family (too few large tiles to fill the chip).
 static int big_tile_width(int M, int N, int K) {
-    if (const char* e = getenv("UNETR_GEMM_BIG_WN")) { const int v = atoi(e); if (v >= 1 && v <= 4) return v; }
+    if (const char* e = getenv("UNETR_GEMM_BIG_WN")) { const int v = atoi(e); if (v >= 2 && v <= 4) return v; }
     int best = 0; double best_t = 1e30;
     for (int wn = 4; wn >= 2; --wn) {
         const long tiles = (long)cdiv(M, 256) * cdiv(N, 64 * wn);

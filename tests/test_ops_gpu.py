@@ -63,11 +63,7 @@ def test_gemm_bf16_storage(pkg, dev, M, N, K):
 @pytest.mark.parametrize("M,N,K,force", [(6912, 2304, 768, 0), (6912, 3072, 768, 0), (6912, 768, 3072, 0), (1030, 520, 192, 4), (1024, 512, 64, 4),
                                          (2100, 772, 128, 4), (1500, 1026, 320, 4), (300, 256, 3072, 4), (1030, 520, 192, 3), (2100, 772, 128, 3),
                                          (1500, 1026, 320, 2), (1024, 384, 64, 3), (1300, 130, 256, 2),
-                                         # the three-buffer ring kernel (tile widths 128 / 64): 1, 2, 3, 4, 7 and 48 K tiles
-                                         (1024, 512, 64, 2), (2100, 772, 128, 2), (1030, 520, 192, 2), (300, 256, 3072, 2), (1030, 200, 448, 1),
-                                         (1024, 64, 64, 1), (1300, 130, 256, 1), (700, 1026, 128, 1),
-                                         # negative: the two-phase kernel at width 128 (UNETR_GEMM_RING=0)
-                                         (1500, 1026, 320, -2), (6912, 768, 3072, -2)])
+                                         (1024, 512, 64, 2), (2100, 772, 128, 2), (1030, 520, 192, 2), (300, 256, 3072, 2)])
 def test_gemm_bf16_big_tile(pkg, dev, monkeypatch, M, N, K, force):
     """The 256 x {256, 192, 128} ping-pong kernel (8 waves, two groups one barrier interval apart, LDS-DMA into half-tile regions):
     picked by itself at encoder shapes of batch 32 (N = 2304 / 3072 / 768 -> tile widths 256 / 192 / 128), forced (UNETR_GEMM_CFG=256,
@@ -75,11 +71,9 @@ def test_gemm_bf16_big_tile(pkg, dev, monkeypatch, M, N, K, force):
     5 / 48 K tiles (odd and even counts walk both LDS buffers), N % 4 != 0 (scalar epilogue) -- with every epilogue kind,
     against fp64 products of the same bf16 inputs."""
     Fn = pkg.functional
-    if force:                       # force = columns / 64 of the tile (256 x 256 / 192 / 128 / 64); 0 = the dispatcher's own choice
+    if force:                       # force = columns / 64 of the tile (256 x 256 / 192 / 128); 0 = the dispatcher's own choice
         monkeypatch.setenv("UNETR_GEMM_CFG", "256")
-        monkeypatch.setenv("UNETR_GEMM_BIG_WN", str(abs(force)))
-        if force < 0:
-            monkeypatch.setenv("UNETR_GEMM_RING", "0")
+        monkeypatch.setenv("UNETR_GEMM_BIG_WN", str(force))
     L = 206 if M == 1030 else M
     x, w = g(M, K, seed=1).bfloat16(), g(N, K, seed=2, scale=0.1).bfloat16()
     b, res, aux = g(N, seed=3), g(L, N, seed=4), g(M, N, seed=6)
@@ -457,6 +451,42 @@ def test_conv3_halo(pkg, dev, monkeypatch, prec, B, dims3, cin, cout):
         assert relerr(ncdhw(buf[..., :cin].cpu()), xr.grad + 1) < TOL[prec]
         assert (buf[..., cin:] == 1).all()
     assert relerr(Fn.conv3_wgrad(xd, cin, dyd, cout, dims, cin, cout, prec), wr.grad) < TOL[prec]
+
+
+@pytest.mark.parametrize("B,dims3,cin,cout,with3,pitch2,max_wg", [(2, (8, 8, 16), 16, 16, True, False, 0), (1, (9, 7, 19), 32, 16, True, True, 0),
+                                                                   (1, (5, 6, 7), 8, 16, False, False, 0), (1, (12, 12, 12), 64, 32, True, False, 0),
+                                                                   (2, (4, 4, 16), 256, 128, False, False, 0), (1, (10, 9, 33), 48, 48, True, True, 0),
+                                                                   (3, (16, 16, 32), 16, 16, True, False, 4), (1, (6, 5, 20), 20, 12, True, False, 0)])
+def test_conv3_wgrad_bf16x3_split_images(pkg, dev, monkeypatch, B, dims3, cin, cout, with3, pitch2, max_wg):
+    """bf16x3 weight gradient on (hi, lo) bf16 images and transposing reads (csrc/conv3.hip: conv3_wgrad_x3_kernel): 3x3x3 and the
+    1x1x1 branch's gradient from the same pass, ragged volumes, 8 / 20 / 48 channels (masked slabs), x read through a wider pitch (the
+    concatenation buffer), a workgroup walking many tiles -- against torch fp32, and against the 4-byte fragment path it replaces
+    (UNETR_X3_WGRAD_TR16=0)."""
+    Fn = pkg.functional
+    D, H, W = dims3
+    if max_wg:
+        monkeypatch.setenv("UNETR_TEST_MAX_WG", str(max_wg))
+    x, dy, dy3 = g(B, cin, D, H, W, seed=1), g(B, cout, D, H, W, seed=2), g(B, cout, D, H, W, seed=3)
+    w, w3 = g(cout, cin, 3, 3, 3, seed=4, scale=0.2).requires_grad_(True), g(cout, cin, 1, 1, 1, seed=5).requires_grad_(True)
+    xr = x.clone()
+    F.conv3d(xr, w, padding=1).backward(dy)
+    if with3:
+        F.conv3d(xr, w3).backward(dy3)
+    ldx = 2 * cin if pitch2 else cin
+    xd = torch.zeros(B, D, H, W, ldx, device=dev)
+    xd[..., :cin] = cl(x).to(dev)
+    dyd, dy3d = cl(dy).to(dev), cl(dy3).to(dev)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UNETR_X3_WGRAD_TR16", mode)
+        out3 = torch.empty(cout, cin, 1, 1, 1, device=dev) if with3 else None
+        dw = Fn.conv3_wgrad(xd, ldx, dyd, cout, (B, D, H, W), cin, cout, 2, dy3=dy3d if with3 else None, out3=out3)
+        res[mode] = (dw.cpu(), out3.cpu() if with3 else None)
+    for mode in ("1", "0"):
+        assert relerr(res[mode][0], w.grad) < TOL[2]
+        if with3:
+            assert relerr(res[mode][1], w3.grad) < TOL[2]
+    assert relerr(res["1"][0], res["0"][0]) < TOL[2]
 
 
 @pytest.mark.parametrize("B,dims3,max_wg", [(2, (9, 7, 19), 0), (2, (20, 12, 40), 0), (3, (16, 16, 32), 8)])
@@ -913,8 +943,8 @@ def test_upblock_with_out_conv_head(pkg, dev, monkeypatch, prec, B, S, C, ncls):
     for k, (a, b) in enumerate(zip(res["0"], res["1"])):
         assert relerr(a, b) < tol_pair, k
     for k, (a, r) in enumerate(zip(res["1"], ref_all)):
-        if prec == 1 and k > 0:       # bf16-stored intermediates: gradients through two InstanceNorms are compared by direction
-            assert F.cosine_similarity(a.double().flatten(), r.double().flatten(), dim=0).item() > 0.995, k
+        if k > 0:       # gradients by direction: a LeakyReLU mask that flips on a rounding difference moves single elements by O(1)
+            assert F.cosine_similarity(a.double().flatten(), r.double().flatten(), dim=0).item() > (0.995 if prec == 1 else 0.9995), k
         else:
             assert relerr(a, r) < tol_ref, k
 
