@@ -9,6 +9,7 @@
 // In both modes a "k-block" is 4 chunks (64 bytes) per row: lane group g = lane>>4 owns chunk g, and the
 // A and B operands use the same lane->k map, so any k permutation inside a k-block cancels out.
 #pragma once
+#include "../../include/unetr_hip.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -247,6 +248,9 @@ int unetr_layernorm_bwd_partials(const float* dy, int splits, long slab, const f
 int unetr_layernorm_fwd_partials(const float* partials, int splits, long slab, const float* bias, const float* res, long ldr, int res_mod,
                                  float* xout, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd,
                                  int M, int H, float eps, void* stream);
+
+// bf16x3 Linear GEMM on fp32-stored operands through the LDS-DMA kernel (gemm_bf16.hip); UNSUPPORTED = take the generic family
+int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, float* C, float* ws, size_t ws_bytes, void* stream);
 
 int unetr_instnorm_stats_finalize2(const float* part, const float* part_b, int nchunk, int B, long V, int C, float eps,
                                    float* stats, float* stats_b, void* stream);

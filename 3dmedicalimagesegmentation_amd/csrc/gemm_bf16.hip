@@ -20,6 +20,7 @@
 // Pipeline: one barrier per 64-deep K step.  __syncthreads() drains stage kt's DMA (hipcc emits vmcnt(0) before the
 // barrier while an LDS-DMA is in flight) and orders it for every reader; stage kt+1 is issued right after it into
 // the other buffer, whose last readers finished before they reached this barrier; then fragments + MFMAs of stage kt.
+#include <type_traits>
 #include "gemm_kernel.hpp"
 
 namespace {
@@ -136,14 +137,25 @@ __device__ __forceinline__ bool tile_of(int L, int mt, int nt, int& tm, int& tn)
     return true;
 }
 
-template <int WM, int WN, int WVM, int WVN, bool BKN, int NS>
+// X3 (bf16x3 precision mode, round 4): the SAME kernel on fp32-stored operands.  A 128-byte image row is then 32 fp32 values (a K
+// stage is 32 elements), the LDS-DMA moves the raw fp32 bits, and a fragment chunk (4 consecutive k of a row) is split into the four
+// [hi | lo << 16] words of PrecBF16x3 in REGISTERS right after its ds_read_b128 (PrecBF16x3::from_raw), two MFMAs per chunk pair.  The
+// generic fp32-storage kernel (gemm_kernel.hpp: register staging, one LDS buffer, two barriers per 32-deep step) took 24-27 us per
+// launch at 432 rows against 10 us for this kernel in bf16 mode.  [K,N] operand (data gradients): no transposing read exists for
+// 4-byte elements -- four ds_read_b32 per chunk from an image of 32 reduction rows x BN columns whose 16-byte chunk c of row r sits
+// in slot c ^ (((r >> 2) & 3) << 2), so the four lane groups of a read (rows 4g + t) hit four different 64-byte segments.
+template <int WM, int WN, int WVM, int WVN, bool BKN, int NS, bool X3 = false>
 __global__ void __launch_bounds__(64 * WVM * WVN)
 gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
-                 const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep,
+                 const typename std::conditional<X3, float, uint16_t>::type* __restrict__ A, long lda,
+                 const typename std::conditional<X3, float, uint16_t>::type* __restrict__ B, long ldb, EpBf ep,
                  float* __restrict__ ws) {
-    constexpr int NT = 64 * WVM * WVN, BM = 16 * WM * WVM, BN = 16 * WN * WVN, BK = 64;
+    typedef typename std::conditional<X3, float, uint16_t>::type ET;
+    constexpr int ESZ = sizeof(ET), CE = 16 / ESZ;           // bytes per element, elements per 16-byte chunk
+    constexpr int NT = 64 * WVM * WVN, BM = 16 * WM * WVM, BN = 16 * WN * WVN, BK = 128 / ESZ;
     constexpr int A_BYTES = BM * 128;
-    constexpr int B_BYTES = BKN ? BK * BN * 2 : BN * 128;
+    constexpr int B_BYTES = BKN ? BK * BN * ESZ : BN * 128;
+    static_assert(!(X3 && BKN) || BN >= 64, "the [K,N] fp32 image needs >= 16 chunks per row for its swizzle");
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int AIT = A_BYTES / 16 / NT, BIT = B_BYTES / 16 / NT;
     static_assert(A_BYTES % (16 * NT) == 0 && B_BYTES % (16 * NT) == 0, "tile must divide into whole wave DMAs");
@@ -160,25 +172,26 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WVN, wn = wave % WVN;
 
     // per-thread source pointers of the DMA pieces at k = kbeg (advanced by BK elements / BK rows per stage)
-    const uint16_t* asrc[AIT];
-    const uint16_t* bsrc[BIT];
+    const ET* asrc[AIT];
+    const ET* bsrc[BIT];
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
         const int id = tid + i * NT, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
-        asrc[i] = A + (long)min(m0 + r, M - 1) * lda + kbeg + c * 8;
+        asrc[i] = A + (long)min(m0 + r, M - 1) * lda + kbeg + c * CE;
     }
 #pragma unroll
     for (int i = 0; i < BIT; ++i) {
         const int id = tid + i * NT;
         if constexpr (!BKN) {
             const int r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
-            bsrc[i] = B + (long)min(n0 + r, N - 1) * ldb + kbeg + c * 8;
+            bsrc[i] = B + (long)min(n0 + r, N - 1) * ldb + kbeg + c * CE;
         } else {
-            // image: BK rows (reduction index) of BN bf16, CPR 16-byte chunks per row, swizzled by bkn_x
-            constexpr int CPR = BN / 8;
+            // image: BK rows (reduction index) of BN elements, CPR 16-byte chunks per row, swizzled by bkn_x (bf16: transposing
+            // reads) / by the lane group of the 4-byte reads (X3)
+            constexpr int CPR = BN / CE;
             const int r = id / CPR, s = id % CPR;
-            const int c = s ^ bkn_x<CPR>(r);
-            bsrc[i] = B + (long)(kbeg + r) * ldb + min(n0 + c * 8, N - 8);
+            const int c = X3 ? (s ^ (((r >> 2) & 3) << 2)) : (s ^ bkn_x<CPR>(r));
+            bsrc[i] = B + (long)(kbeg + r) * ldb + min(n0 + c * CE, N - CE);
         }
     }
     auto issue = [&](int kt, int buf) {
@@ -189,7 +202,7 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + (long)kt * BK), (lds_void_t*)(la + (wave * 64 + i * NT) * 16), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
-            const uint16_t* g = BKN ? bsrc[i] + (long)kt * BK * ldb : bsrc[i] + (long)kt * BK;
+            const ET* g = BKN ? bsrc[i] + (long)kt * BK * ldb : bsrc[i] + (long)kt * BK;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(lb + (wave * 64 + i * NT) * 16), 16, 0, 0);
         }
     };
@@ -226,6 +239,12 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
             for (int j = 0; j < WN; ++j) {
                 if constexpr (!BKN) {
                     b[kb][j] = *(const u32x4*)(lb + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
+                } else if constexpr (X3) {
+                    // lane (n = lane & 15, g = lane >> 4): reduction rows kb * 16 + 4 g + t, t = 0..3, of column n
+                    const int col = (wn * WN + j) * 16 + (lane & 15), g = lane >> 4;
+                    const char* pb = lb + (kb * 16 + 4 * g) * (BN * 4) + ((((col >> 2) ^ (g << 2))) << 4) + (col & 3) * 4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[kb][j][t] = *(const uint32_t*)(pb + t * (BN * 4));
                 } else {
                     constexpr int CPR = BN / 8;
                     const int cc = lane & 15, g = lane >> 4, q = cc >> 2, p = cc & 3;
@@ -243,10 +262,20 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if constexpr (X3) {
+                // raw fp32 bits -> [hi | lo << 16] words, once per fragment
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[kb][i] = PrecBF16x3::from_raw(a[kb][i]);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[kb][j] = PrecBF16x3::from_raw(b[kb][j]);
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], b[kb][j], a[kb][i]);    // transposed tile: a lane holds 4 consecutive n of one m
+                for (int j = 0; j < WN; ++j) {
+                    if constexpr (X3) PrecBF16x3::mma(acc[i][j], b[kb][j], a[kb][i]);
+                    else PrecBF16::mma(acc[i][j], b[kb][j], a[kb][i]);    // transposed tile: a lane holds 4 consecutive n of one m
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -301,23 +330,24 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
         }
 }
 
-template <int WM, int WN, int WVM, int WVN, bool BKN, int NS>
-int launch_bf16(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep,
+template <int WM, int WN, int WVM, int WVN, bool BKN, int NS, bool X3 = false>
+int launch_bf16(int M, int N, int K, const typename std::conditional<X3, float, uint16_t>::type* A, long lda,
+                const typename std::conditional<X3, float, uint16_t>::type* B, long ldb, const EpBf& ep,
                 float* ws, size_t ws_bytes, hipStream_t st, int* partial_splits = nullptr) {
-    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN;
-    const int mt = cdiv(M, BM), nt = cdiv(N, BN), ksteps = K / 64;
+    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN, BKE = X3 ? 32 : 64;      // elements per 128-byte K stage
+    const int mt = cdiv(M, BM), nt = cdiv(N, BN), ksteps = K / BKE;
     const long tiles = (long)mt * nt;
     int splits = 1;
     // few tiles (batch-2 token counts): the kernel is latency-bound, one workgroup's time is ~ its K steps, so long K
     // ranges are cut into slabs of >= 12 steps (shorter slabs cost more in the reduce launch than they save)
-    if (tiles < 192 && ksteps >= 24) splits = std::min(ksteps / 12, (int)((512 + tiles - 1) / tiles));
+    if (tiles < 192 && ksteps >= 24) splits = std::min(ksteps / 12, (int)((512 + tiles - 1) / tiles));      // (X3: 128-byte stages are 32 elements -- a slab is >= 12 stages either way)
     if (const char* e = getenv("UNETR_GEMM_SPLITS")) { int v = atoi(e); if (v > 0) splits = std::min(v, ksteps); }
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits < 1 || ws == nullptr) splits = 1;
-    const int kper = cdiv(ksteps, splits) * 64;
+    const int kper = cdiv(ksteps, splits) * BKE;
     splits = cdiv(K, kper);
     const int per = cdiv(tiles, 8);
-    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WVM, WVN, BKN, NS>), dim3(per * 8, splits), dim3(64 * WVM * WVN), 0, st,
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, WVM, WVN, BKN, NS, X3>), dim3(per * 8, splits), dim3(64 * WVM * WVN), 0, st,
                        M, N, K, mt, nt, splits, kper, A, lda, B, ldb, ep, ws);
     // partial_splits: the caller consumes the split partials itself (unetr_gemm_bf16_ln_bwd): no reduce launch
     if (partial_splits) *partial_splits = splits;
@@ -929,6 +959,32 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
     if (env_ns == 8) BF16_GO(2, 2, true, 8);
     BF16_GO(2, 2, true, 4);
 #undef BF16_GO
+}
+
+// bf16x3 precision mode: C = A . B^T (b_kn = 0, B [N,K]) or A . B (b_kn = 1, B [K,N]) on fp32-stored operands through the LDS-DMA kernel
+// above (X3 instantiations).  Called by unetr_gemm (gemm_std.hip) for the plain Linear shapes; UNSUPPORTED = the generic family.
+int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, float* C, float* ws, size_t ws_bytes, void* stream) {
+    const int M = d->M, N = d->N, K = d->K;
+    if (M <= 0 || N <= 0 || K <= 0) return UNETR_ERR_ARG;
+    if (K % 32 || d->lda % 4 || d->ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || N % 4) return UNETR_ERR_UNSUPPORTED;
+    if (d->b_kn && N < 64) return UNETR_ERR_UNSUPPORTED;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const int vec_ok = (d->ldc % 4 == 0 && al16(C)) && (!d->bias || al16(d->bias)) && (!d->res || (d->ldr % 4 == 0 && al16(d->res))) &&
+                       (!d->pre || al16(d->pre)) && (!d->aux || (d->ldaux % 4 == 0 && al16(d->aux))) && al16(ws);
+    if (!vec_ok) return UNETR_ERR_UNSUPPORTED;
+    EpBf ep{1, C, d->ldc, nullptr, 0, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : M, d->pre, d->aux, d->ldaux, d->act,
+            d->accumulate, d->alpha, 0, 0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+#define X3_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, true>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, nullptr)
+    // tile rule of the bf16 kernel at small M (a stage is the same 16 KB); many rows: the 128 x 128 tile
+    if (M >= 1024 && N >= 128) { if (d->b_kn) X3_GO(4, 4, true, 2); X3_GO(4, 4, false, 2); }
+    if (!d->b_kn) {
+        if (K <= 1024 && N <= 1024) X3_GO(2, 1, false, 4);
+        X3_GO(2, 2, false, 4);
+    }
+    if (K <= 1024 && N % 64 == 0) X3_GO(1, 2, true, 4);
+    X3_GO(2, 2, true, 4);
+#undef X3_GO
 }
 
 extern "C" int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,

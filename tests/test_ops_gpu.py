@@ -40,6 +40,38 @@ def test_gemm_nt_nn_tn(pkg, dev, prec, M, N, K):
     assert relerr(Fn.linear_wgrad(dy.to(dev), x.to(dev), prec), dy.t() @ x) < TOL[prec]
 
 
+@pytest.mark.parametrize("M,N,K", [(432, 768, 768), (432, 2304, 768), (432, 768, 3072), (432, 3072, 768), (430, 772, 96), (33, 64, 32), (1500, 3072, 768),
+                                   (1000, 768, 3072), (864, 2304, 768), (216, 128, 64), (50, 200, 160)])
+def test_gemm_bf16x3_dma(pkg, dev, monkeypatch, M, N, K):
+    """bf16x3 Linear GEMMs on the LDS-DMA kernel (csrc/gemm_bf16.hip, X3 instantiations: raw fp32 through LDS, operands split in
+    registers at fragment time): forward with every epilogue and the [K,N]-operand data gradient (four ds_read_b32 per chunk), split-K
+    shapes, ragged M / N, 1 to 96 stages, the 128 x 128 tile at many rows -- against fp64 products and against the generic
+    fp32-storage family it replaces (UNETR_X3_GEMM_DMA=0)."""
+    Fn = pkg.functional
+    x, w, dy = g(M, K, seed=1), g(N, K, seed=2, scale=0.1), g(M, N, seed=3)
+    b, res, u = g(N, seed=4), g(M, N, seed=5), g(M, K, seed=6)
+    lin = (x.double() @ w.double().t())
+    ur = u.clone().requires_grad_(True)
+    F.gelu(ur).sum().backward()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UNETR_X3_GEMM_DMA", mode)
+        xd, wd, dyd = x.to(dev), w.to(dev), dy.to(dev)
+        y0 = Fn.linear_fwd(xd, wd, None, 2)
+        pre = torch.empty(M, N, device=dev)
+        y1 = Fn.linear_fwd(xd, wd, b.to(dev), 2, res=res.to(dev), act=1, pre=pre)
+        dx0 = Fn.linear_dgrad(dyd, wd, 2)
+        dx1 = Fn.linear_dgrad(dyd, wd, 2, aux=u.to(dev))
+        acc = torch.ones(M, N, device=dev)
+        Fn.gemm(xd, wd, acc, M, N, K, lda=K, ldb=K, ldc=N, prec=2, accumulate=True, alpha=0.5)
+        outs[mode] = [t.cpu() for t in (y0, pre, y1, dx0, dx1, acc)]
+    refs = [lin.float(), (lin + b).float(), (F.gelu(lin + b) + res).float(), (dy.double() @ w.double()).float(),
+            ((dy.double() @ w.double()) * ur.grad.double()).float(), (1 + 0.5 * lin).float()]
+    for k, (a, o, r) in enumerate(zip(outs["1"], outs["0"], refs)):
+        assert relerr(a, r) < TOL[2], k
+        assert relerr(a, o) < TOL[2], k
+
+
 @pytest.mark.parametrize("M,N,K", [(432, 768, 768), (432, 2304, 768), (432, 768, 3072), (37, 56, 64), (2000, 384, 128),
                                    (1500, 3072, 768), (8, 128, 4096), (130, 200, 192)])
 def test_gemm_bf16_storage(pkg, dev, M, N, K):
