@@ -137,6 +137,37 @@ __device__ __forceinline__ bool tile_of(int L, int mt, int nt, int& tm, int& tn)
     return true;
 }
 
+// bf16x3 operand forms straight from raw fp32 bits (the X3 instantiation below is bound by this VALU work, so it is kept minimal):
+// hi = the value TRUNCATED to bf16 (its upper 16 bits: no rounding instructions), lo = bf16(a - hi) -- the difference is exact in
+// fp32, so hi + lo carries the value to 2^-16 relative, the precision the mode's products have anyway (PrecBF16x3, common.hpp).
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float x3_rem(uint32_t r) {
+#ifdef UNETR_X3_DROP_LO
+    return 0.f;
+#else
+    return __builtin_bit_cast(float, r) - __builtin_bit_cast(float, r & 0xffff0000u);
+#endif
+}
+// the operand that enters both MFMAs as it is: four words [hi | lo << 16]
+__device__ __forceinline__ u32x4 x3_words(u32x4 r) {
+    const bf16x2_ l01 = __builtin_convertvector((f32x2_){x3_rem(r[0]), x3_rem(r[1])}, bf16x2_);
+    const bf16x2_ l23 = __builtin_convertvector((f32x2_){x3_rem(r[2]), x3_rem(r[3])}, bf16x2_);
+    const uint32_t p01 = __builtin_bit_cast(uint32_t, l01), p23 = __builtin_bit_cast(uint32_t, l23);
+    return (u32x4){__builtin_amdgcn_perm(p01, r[0], 0x05040302u), __builtin_amdgcn_perm(p01, r[1], 0x07060302u),
+                   __builtin_amdgcn_perm(p23, r[2], 0x05040302u), __builtin_amdgcn_perm(p23, r[3], 0x07060302u)};
+}
+// the operand that is duplicated: [hi, hi] words and [lo, lo] words (one v_perm / one packed convert of (d, d) per element)
+__device__ __forceinline__ void x3_dup(u32x4 r, u32x4& hh, u32x4& ll) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t re = r[e];
+        hh[e] = __builtin_amdgcn_perm(re, re, 0x03020302u);
+        const float d = x3_rem(re);
+        ll[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){d, d}, bf16x2_));
+    }
+}
+
 // X3 (bf16x3 precision mode, round 4): the SAME kernel on fp32-stored operands.  A 128-byte image row is then 32 fp32 values (a K
 // stage is 32 elements), the LDS-DMA moves the raw fp32 bits, and a fragment chunk (4 consecutive k of a row) is split into the four
 // [hi | lo << 16] words of PrecBF16x3 in REGISTERS right after its ds_read_b128 (PrecBF16x3::from_raw), two MFMAs per chunk pair.  The
@@ -263,19 +294,26 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if constexpr (X3) {
-                // raw fp32 bits -> [hi | lo << 16] words, once per fragment
+                // raw fp32 bits -> operand forms, once per fragment: A as [hi | lo] words, B duplicated ([hi, hi] / [lo, lo]);
+                // acc += B_hh . A + B_ll . A  =  b_hi a_hi + b_hi a_lo + b_lo a_hi + b_lo a_lo
+                u32x4 bh[WN], bl[WN];
 #pragma unroll
-                for (int i = 0; i < WM; ++i) a[kb][i] = PrecBF16x3::from_raw(a[kb][i]);
+                for (int i = 0; i < WM; ++i) a[kb][i] = x3_words(a[kb][i]);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) b[kb][j] = PrecBF16x3::from_raw(b[kb][j]);
+                for (int j = 0; j < WN; ++j) x3_dup(b[kb][j], bh[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        PrecBF16::mma(acc[i][j], bh[j], a[kb][i]);
+                        PrecBF16::mma(acc[i][j], bl[j], a[kb][i]);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) PrecBF16::mma(acc[i][j], b[kb][j], a[kb][i]);    // transposed tile: a lane holds 4 consecutive n of one m
             }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    if constexpr (X3) PrecBF16x3::mma(acc[i][j], b[kb][j], a[kb][i]);
-                    else PrecBF16::mma(acc[i][j], b[kb][j], a[kb][i]);    // transposed tile: a lane holds 4 consecutive n of one m
-                }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
