@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
-ABI_VERSION = 14       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 15       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -29,7 +29,7 @@ class GemmDesc(ctypes.Structure):
         ("bias", c_void_p), ("res", c_void_p),
         ("ldr", c_long), ("strideR", c_long), ("res_mod", c_int),
         ("pre", c_void_p), ("aux", c_void_p), ("ldaux", c_long),
-        ("act", c_int), ("accumulate", c_int), ("alpha", c_float), ("prec", c_int),
+        ("act", c_int), ("accumulate", c_int), ("alpha", c_float), ("prec", c_int), ("b_x3words", c_int),
     ]
 
 
@@ -86,6 +86,7 @@ _SIGNATURES = {
     "unetr_gemm_bf16_ln_bwd": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P, c_size_t, P],
     "unetr_gemm_bf16_ln_fwd": [ctypes.POINTER(GemmBf16Desc), P, P, P, P, P, c_float, P, P, P, P, P, c_size_t, P],
     "unetr_cast_bf16": [P, P, c_long, P],
+    "unetr_split_words": [P, P, c_long, P],
     "unetr_split_stack_bf16": [P, P, c_long, c_long, c_int, P],
     "unetr_split_stack_bf16_grouped": [ctypes.POINTER(SplitProblem), c_int, P],
     "unetr_ln_gemm_bf16": [ctypes.POINTER(LnGemmDesc), P],

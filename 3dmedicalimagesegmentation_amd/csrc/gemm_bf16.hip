@@ -175,18 +175,20 @@ __device__ __forceinline__ void x3_dup(u32x4 r, u32x4& hh, u32x4& ll) {
 // launch at 432 rows against 10 us for this kernel in bf16 mode.  [K,N] operand (data gradients): no transposing read exists for
 // 4-byte elements -- four ds_read_b32 per chunk from an image of 32 reduction rows x BN columns whose 16-byte chunk c of row r sits
 // in slot c ^ (((r >> 2) & 3) << 2), so the four lane groups of a read (rows 4g + t) hit four different 64-byte segments.
-template <int WM, int WN, int WVM, int WVN, bool BKN, int NS, bool X3 = false>
+// X3 = 2: B arrives as pre-split words (the optimizer-maintained word shadow of the weights: unetr_split_words) -- only the activation
+// operand is split in registers, and it becomes the duplicated one.
+template <int WM, int WN, int WVM, int WVN, bool BKN, int NS, int X3 = 0>
 __global__ void __launch_bounds__(64 * WVM * WVN)
 gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
-                 const typename std::conditional<X3, float, uint16_t>::type* __restrict__ A, long lda,
-                 const typename std::conditional<X3, float, uint16_t>::type* __restrict__ B, long ldb, EpBf ep,
+                 const typename std::conditional<X3 != 0, float, uint16_t>::type* __restrict__ A, long lda,
+                 const typename std::conditional<X3 != 0, float, uint16_t>::type* __restrict__ B, long ldb, EpBf ep,
                  float* __restrict__ ws) {
-    typedef typename std::conditional<X3, float, uint16_t>::type ET;
+    typedef typename std::conditional<X3 != 0, float, uint16_t>::type ET;
     constexpr int ESZ = sizeof(ET), CE = 16 / ESZ;           // bytes per element, elements per 16-byte chunk
     constexpr int NT = 64 * WVM * WVN, BM = 16 * WM * WVM, BN = 16 * WN * WVN, BK = 128 / ESZ;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BKN ? BK * BN * ESZ : BN * 128;
-    static_assert(!(X3 && BKN) || BN >= 64, "the [K,N] fp32 image needs >= 16 chunks per row for its swizzle");
+    static_assert(!(X3 != 0 && BKN) || BN >= 64, "the [K,N] fp32 image needs >= 16 chunks per row for its swizzle");
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int AIT = A_BYTES / 16 / NT, BIT = B_BYTES / 16 / NT;
     static_assert(A_BYTES % (16 * NT) == 0 && B_BYTES % (16 * NT) == 0, "tile must divide into whole wave DMAs");
@@ -221,7 +223,7 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
             // reads) / by the lane group of the 4-byte reads (X3)
             constexpr int CPR = BN / CE;
             const int r = id / CPR, s = id % CPR;
-            const int c = X3 ? (s ^ (((r >> 2) & 3) << 2)) : (s ^ bkn_x<CPR>(r));
+            const int c = X3 != 0 ? (s ^ (((r >> 2) & 3) << 2)) : (s ^ bkn_x<CPR>(r));
             bsrc[i] = B + (long)(kbeg + r) * ldb + min(n0 + c * CE, N - CE);
         }
     }
@@ -270,7 +272,7 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
             for (int j = 0; j < WN; ++j) {
                 if constexpr (!BKN) {
                     b[kb][j] = *(const u32x4*)(lb + lds_tile_off((wn * WN + j) * 16 + (lane & 15), kb * 4 + (lane >> 4)));
-                } else if constexpr (X3) {
+                } else if constexpr (X3 != 0) {
                     // lane (n = lane & 15, g = lane >> 4): reduction rows kb * 16 + 4 g + t, t = 0..3, of column n
                     const int col = (wn * WN + j) * 16 + (lane & 15), g = lane >> 4;
                     const char* pb = lb + (kb * 16 + 4 * g) * (BN * 4) + ((((col >> 2) ^ (g << 2))) << 4) + (col & 3) * 4;
@@ -293,7 +295,19 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            if constexpr (X3) {
+            if constexpr (X3 == 2) {
+                // B holds words already: A is the duplicated operand; acc += B . A_hh + B . A_ll
+                u32x4 ah[WM], al[WM];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) x3_dup(a[kb][i], ah[i], al[i]);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        PrecBF16::mma(acc[i][j], b[kb][j], ah[i]);
+                        PrecBF16::mma(acc[i][j], b[kb][j], al[i]);
+                    }
+            } else if constexpr (X3 == 1) {
                 // raw fp32 bits -> operand forms, once per fragment: A as [hi | lo] words, B duplicated ([hi, hi] / [lo, lo]);
                 // acc += B_hh . A + B_ll . A  =  b_hi a_hi + b_hi a_lo + b_lo a_hi + b_lo a_lo
                 u32x4 bh[WN], bl[WN];
@@ -368,11 +382,11 @@ gemm_bf16_kernel(int M, int N, int K, int mt, int nt, int splits, int kper,
         }
 }
 
-template <int WM, int WN, int WVM, int WVN, bool BKN, int NS, bool X3 = false>
-int launch_bf16(int M, int N, int K, const typename std::conditional<X3, float, uint16_t>::type* A, long lda,
-                const typename std::conditional<X3, float, uint16_t>::type* B, long ldb, const EpBf& ep,
+template <int WM, int WN, int WVM, int WVN, bool BKN, int NS, int X3 = 0>
+int launch_bf16(int M, int N, int K, const typename std::conditional<X3 != 0, float, uint16_t>::type* A, long lda,
+                const typename std::conditional<X3 != 0, float, uint16_t>::type* B, long ldb, const EpBf& ep,
                 float* ws, size_t ws_bytes, hipStream_t st, int* partial_splits = nullptr) {
-    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN, BKE = X3 ? 32 : 64;      // elements per 128-byte K stage
+    constexpr int BM = 16 * WM * WVM, BN = 16 * WN * WVN, BKE = X3 != 0 ? 32 : 64;      // elements per 128-byte K stage
     const int mt = cdiv(M, BM), nt = cdiv(N, BN), ksteps = K / BKE;
     const long tiles = (long)mt * nt;
     int splits = 1;
@@ -1001,7 +1015,7 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
 
 // bf16x3 precision mode: C = A . B^T (b_kn = 0, B [N,K]) or A . B (b_kn = 1, B [K,N]) on fp32-stored operands through the LDS-DMA kernel
 // above (X3 instantiations).  Called by unetr_gemm (gemm_std.hip) for the plain Linear shapes; UNSUPPORTED = the generic family.
-int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, float* C, float* ws, size_t ws_bytes, void* stream) {
+int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, int b_words, float* C, float* ws, size_t ws_bytes, void* stream) {
     const int M = d->M, N = d->N, K = d->K;
     if (M <= 0 || N <= 0 || K <= 0) return UNETR_ERR_ARG;
     if (K % 32 || d->lda % 4 || d->ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || N % 4) return UNETR_ERR_UNSUPPORTED;
@@ -1013,7 +1027,8 @@ int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float
     EpBf ep{1, C, d->ldc, nullptr, 0, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : M, d->pre, d->aux, d->ldaux, d->act,
             d->accumulate, d->alpha, 0, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
-#define X3_GO(WM_, WN_, BKN_, NS_) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, true>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, nullptr)
+#define X3_GO(WM_, WN_, BKN_, NS_) do { if (b_words) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, 2>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, nullptr); \
+                                        return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, 1>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, nullptr); } while (0)
     // tile rule of the bf16 kernel at small M (a stage is the same 16 KB); many rows: the 128 x 128 tile
     if (M >= 1024 && N >= 128) { if (d->b_kn) X3_GO(4, 4, true, 2); X3_GO(4, 4, false, 2); }
     if (!d->b_kn) {
@@ -1071,6 +1086,18 @@ extern "C" int unetr_cast_bf16(const float* src, void* dst, long n, void* stream
     const long n8 = al ? n / 8 : 0;
     if (n8) hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<long>(cdiv(n8, 256), 4096)), dim3(256), 0, st, src, (uint16_t*)dst, n8);
     if (n8 * 8 < n) hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3(cdiv(n - n8 * 8, 256)), dim3(256), 0, st, src, (uint16_t*)dst, n8 * 8, n);
+    return unetr_check_launch();
+}
+
+// fp32 -> split words [hi | lo << 16] (x3_words): the word shadow of a weight arena
+__global__ void __launch_bounds__(256) split_words_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) ((u32x4*)dst)[i] = x3_words(((const u32x4*)src)[i]);
+}
+
+extern "C" int unetr_split_words(const float* src, void* dst, long n, void* stream) {
+    if (!src || !dst || n <= 0) return UNETR_ERR_ARG;
+    if ((n & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return UNETR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(split_words_kernel, dim3((unsigned)std::min<long>(cdiv(n / 4, 256), 8192)), dim3(256), 0, (hipStream_t)stream, src, (uint32_t*)dst, n / 4);
     return unetr_check_launch();
 }
 

@@ -12,16 +12,19 @@ extern "C" int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float*
     if (d->act == 2 && !d->aux) return UNETR_ERR_ARG;
     const int M = d->M, N = d->N, K = d->K, bt = d->batch;
     const bool kv = (K % 8) == 0;
-    if (d->prec == UNETR_PREC_BF16X3 && bt == 1 && !d->a_trans && M >= 32 && !(getenv("UNETR_X3_GEMM_DMA") && atoi(getenv("UNETR_X3_GEMM_DMA")) == 0)) {
+    if (d->b_x3words && (d->prec != UNETR_PREC_BF16X3 || bt != 1 || d->a_trans)) return UNETR_ERR_ARG;
+    if (d->prec == UNETR_PREC_BF16X3 && bt == 1 && !d->a_trans && M >= 32 &&
+        (d->b_x3words || !(getenv("UNETR_X3_GEMM_DMA") && atoi(getenv("UNETR_X3_GEMM_DMA")) == 0))) {
         // bf16x3 Linear forward (B [N,K]) / data gradient (B [K,N]) on the LDS-DMA kernel of gemm_bf16.hip where the shape allows it
         unetr_gemm_bf16_desc q{};
         q.M = M; q.N = N; q.K = K; q.b_kn = d->b_trans ? 1 : 0;
         q.lda = d->lda; q.ldb = d->ldb; q.ldc = d->ldc; q.ldcb = 0;
         q.bias = d->bias; q.res = d->res; q.ldr = d->ldr; q.res_mod = d->res_mod;
         q.pre = d->pre; q.aux = d->aux; q.ldaux = d->ldaux; q.act = d->act; q.accumulate = d->accumulate; q.alpha = d->alpha;
-        const int rc = unetr_gemm_x3_dma(&q, A, B, C, ws, ws_bytes, stream);
-        if (rc != UNETR_ERR_UNSUPPORTED) return rc;
+        const int rc = unetr_gemm_x3_dma(&q, A, B, d->b_x3words, C, ws, ws_bytes, stream);
+        if (rc != UNETR_ERR_UNSUPPORTED || d->b_x3words) return rc;       // (only this kernel reads a word shadow)
     }
+    if (d->b_x3words) return UNETR_ERR_UNSUPPORTED;
     if (!d->a_trans && !d->b_trans) {
         if (kv && vec_ok(A, d->lda, d->strideA) && vec_ok(B, d->ldb, d->strideB)) {
             LdRow al{A, d->lda, d->strideA, M, 1};

@@ -336,8 +336,15 @@ def _rows(t):
 
 # ------------------------------------------------------------------------------------------------ wrappers
 def gemm(A, B, C, M, N, K, *, lda, ldb, ldc, prec, a_trans=False, b_trans=False, bias=None, res=None, ldr=0,
-         res_mod=0, pre=None, aux=None, ldaux=0, act=0, accumulate=False, alpha=1.0):
+         res_mod=0, pre=None, aux=None, ldaux=0, act=0, accumulate=False, alpha=1.0, b_words=None):
+    """b_words (bf16x3 mode): the pre-split word shadow of the weight B (weight_x3) -- read instead of B where the LDS-DMA kernel takes
+    the shape (M >= 32, K % 32 == 0, N % 4 == 0, plain row pitches)"""
     d = GemmDesc()
+    d.b_x3words = 0
+    if (b_words is not None and prec == _capi.PREC_BF16X3 and not a_trans and M >= 32 and K % 32 == 0 and N % 4 == 0 and lda % 4 == 0
+            and ldb % 4 == 0 and ldc % 4 == 0 and (not b_trans or N >= 64)):
+        B = b_words
+        d.b_x3words = 1
     d.M, d.N, d.K, d.batch = M, N, K, 1
     d.a_trans, d.b_trans = int(a_trans), int(b_trans)
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
@@ -454,6 +461,8 @@ def invalidate_weight_shadows():
     _WEIGHT_EPOCH[0] += 1
     for ent in _SHADOW.values():
         ent[1] = -1
+    for ent in _SHADOW_X3.values():
+        ent[1] = -1
     for ent in _PACKS.values():
         ent[1] = -1
 
@@ -470,6 +479,62 @@ def begin_forward(state=None):
         state.reset_deferred()
         state.fuse = None          # an optimizer / communication epilogue is armed AFTER the forward of the step it belongs to:
                                    # whatever a failed step left armed must not ride on the next backward
+
+
+# ---- bf16x3 mode: word shadow of the weights ---------------------------------------------------------------------------------
+# The bf16x3 Linear GEMMs split their fp32 operands into (hi, lo) bf16 pairs in registers; the weight operand of a step is constant,
+# so with flat arenas its split form is kept as a second arena of words [hi | lo << 16] (unetr_split_words: one streaming launch
+# over the parameter arena after every optimizer step, AdamW.* -> refresh_x3_shadow) and the GEMM kernel splits only the activation
+# operand.  Same freshness rule as the bf16 shadow: valid while torch has not modified the parameter (version counter, address);
+# ``.data`` writes behind torch's back need invalidate_weight_shadows().  Created on first use (an eager pass: never under capture).
+_SHADOW_X3 = {}
+
+
+def x3_words_enabled():
+    """UNETR_AMD_X3_WORDS=0 (A/B hook): the bf16x3 GEMMs split the fp32 weights in registers like the activations"""
+    return os.environ.get("UNETR_AMD_X3_WORDS", "1") != "0"
+
+
+def _split_words(src, dst, n):
+    call("unetr_split_words", src.data_ptr(), dst.data_ptr(), n, _stream())
+
+
+def weight_x3(w):
+    """the weight as split words (int32 view, same shape) when `w` lives in a flat arena; else None (the kernel splits the fp32 weight)"""
+    if not x3_words_enabled():
+        return None
+    st = _GRAD_SINK.get(w.data_ptr())
+    flat = getattr(st, "flat", None) if st is not None else None
+    if flat is None:
+        return None
+    if flat.get("shadow_x3") is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                      # (the arena must not come out of a graph's private pool)
+        arena = torch.empty(flat["total"], dtype=torch.int32, device=w.device)
+        _split_words(flat["param"], arena, flat["total"])
+        flat["shadow_x3"] = arena
+        for p, o in zip(flat["params"], flat["offsets"]):
+            _SHADOW_X3[id(p)] = [arena[o:o + p.numel()].view_as(p), p._version, weakref.ref(p), p.data_ptr(), (p.numel() + 7) // 8 * 8]
+    ent = _SHADOW_X3.get(id(w))
+    if ent is None or ent[2]() is not w or ent[3] != w.data_ptr() or ent[0].device != w.device:
+        return None
+    if ent[1] != w._version:                 # torch modified the parameter since the last derive: redo this slice (whole padded slot)
+        _split_words(w, ent[0], ent[4])
+        ent[1] = w._version
+    return ent[0]
+
+
+def refresh_x3_shadow(flat):
+    """optimizer side (flat arenas): the parameter arena has just been updated by a kernel of this package -- re-derive the word
+    shadow when the bf16x3 GEMMs have asked for one"""
+    arena = flat.get("shadow_x3") if flat is not None else None
+    if arena is None:
+        return
+    _split_words(flat["param"], arena, flat["total"])
+    for p in flat["params"]:
+        ent = _SHADOW_X3.get(id(p))
+        if ent is not None and ent[2]() is p and ent[3] == p.data_ptr():
+            ent[1] = p._version
 
 
 def register_weight_shadow(w, shadow):
@@ -628,7 +693,8 @@ def linear_fwd(x, w, bias, prec, res=None, res_mod=0, act=0, pre=None):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, prec=prec, bias=bias, res=res, ldr=N, res_mod=res_mod, act=act, pre=pre)
+    gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, prec=prec, bias=bias, res=res, ldr=N, res_mod=res_mod, act=act, pre=pre,
+         b_words=weight_x3(w) if prec == _capi.PREC_BF16X3 else None)
     return y
 
 
@@ -637,7 +703,8 @@ def linear_dgrad(dy, w, prec, aux=None):
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-    gemm(dy, w, dx, M, K, N, lda=N, ldb=K, ldc=K, prec=prec, b_trans=True, aux=aux, ldaux=K, act=2 if aux is not None else 0)
+    gemm(dy, w, dx, M, K, N, lda=N, ldb=K, ldc=K, prec=prec, b_trans=True, aux=aux, ldaux=K, act=2 if aux is not None else 0,
+         b_words=weight_x3(w) if prec == _capi.PREC_BF16X3 else None)
     return dx
 
 

@@ -123,6 +123,7 @@ class AdamW(torch.optim.Optimizer):
             self._launch_run(group, run, steps, gbase, False, 1.0, stream)
         if flat.get("shadow") is not None:           # the kernel rewrote the bf16 shadow slices of every parameter that stepped
             Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has], flat.get("state"))
+        Fn.refresh_x3_shadow(flat)                   # (bf16x3 mode: the word shadow follows the update)
         return True
 
     # ---- single-GPU fused step: AdamW of the ViT Linear weights rides on the grouped weight-gradient launch ----------------
@@ -204,6 +205,7 @@ class AdamW(torch.optim.Optimizer):
         for k, has in enumerate(pattern):
             if has:
                 self._host_steps[k] += 1
+        Fn.refresh_x3_shadow(flat)
         if flat.get("shadow") is not None:
             Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has], flat.get("state"))
         Fn.refresh_conv_packs()
@@ -238,6 +240,7 @@ class AdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def end_reduced_step(self, plan):
+        Fn.refresh_x3_shadow(self._flat)
         if self._flat.get("shadow") is not None:
             Fn.mark_flat_maintained([p for p, has in zip(self.param_groups[0]["params"], plan["pattern"]) if has], self._flat.get("state"))
         Fn.refresh_conv_packs()
@@ -263,6 +266,7 @@ class AdamW(torch.optim.Optimizer):
             if before_run is not None:
                 before_run(k, run[2], run[3])
             self._launch_run(group, run, steps, gsrc.data_ptr(), g_bf16, gscale, stream)
+        Fn.refresh_x3_shadow(self._flat)
         if self._flat.get("shadow") is not None:
             Fn.mark_flat_maintained([p for p, has in zip(params, plan["pattern"]) if has], self._flat.get("state"))
         Fn.refresh_conv_packs()

@@ -269,6 +269,7 @@ class UNETR(nn.Module):
             Fn.register_weight_shadow(p, shadow[o:o + p.numel()].view_as(p))
         self._flat = dict(param=flat_p, grad=flat_g, offsets=offs, params=params, total=n, shadow=shadow,
                           state=self._arena_state)
+        self._arena_state.flat = self._flat        # (functional.weight_x3: the bf16x3 word shadow is an arena next to these)
         return self._flat
 
     # first block of each ViT backward pass after the first, in execution order of backward (see forward_staged): passes run

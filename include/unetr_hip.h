@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 14
+#define UNETR_ABI_VERSION 15
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -59,9 +59,14 @@ typedef struct {
     int accumulate;                   /* C += result */
     float alpha;
     int prec;
+    int b_x3words;                    /* prec == UNETR_PREC_BF16X3 only: B holds pre-split words [hi | lo << 16] (unetr_split_words of the
+                                       * fp32 weight, same layout and pitch) instead of fp32 values -- the optimizer-maintained word shadow */
 } unetr_gemm_desc;
 int unetr_gemm(const unetr_gemm_desc* d, const float* A, const float* B, float* C,
                float* ws, size_t ws_bytes, void* stream);
+/* bf16x3 mode: dst[i] = [hi | lo << 16] with hi = src[i] truncated to bf16, lo = bf16(src[i] - hi) (n % 4 == 0, 16-byte aligned):
+ * the word shadow of a weight arena, re-derived after every optimizer step, that unetr_gemm reads with b_x3words = 1 */
+int unetr_split_words(const float* src, void* dst, long n, void* stream);
 
 /* ---- bf16-STORED operand GEMM (LDS-DMA staged): the same nn.Linear forward / data-gradient calls as unetr_gemm
  * (MONAI ViT Linear layers built at unetr.py:78-89) for the bf16 precision mode, where LayerNorm / attention / GELU

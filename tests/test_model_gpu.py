@@ -281,6 +281,54 @@ def test_bf16x3_flat_arena_weight_gradients(pkg, dev):
     pkg.functional.clear_grad_sinks(flat["state"])
 
 
+def test_bf16x3_weight_word_shadow(pkg, dev, monkeypatch):
+    """bf16x3 mode with flat arenas: the Linear GEMMs read the weights from the word shadow (functional.weight_x3: [hi | lo << 16]
+    words next to the parameter arena, re-derived by one launch after every AdamW step).  Forward / backward with the shadow equal the
+    in-register split of the fp32 weights (UNETR_AMD_X3_WORDS=0) to rounding; the shadow follows an optimizer step, an in-place torch
+    write (version counter) and load_state_dict."""
+    from oracle.unetr_oracle import synthetic_volume
+    Fn = pkg.functional
+    torch.manual_seed(7)
+    m = pkg.UNETRLogits(**C1).to(dev)
+    m.precision = "bf16x3"
+    flat = m.use_flat_buffers()
+    opt = pkg.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-2, flat=flat)
+    crit = pkg.DiceCELoss(to_onehot_y=True, softmax=True)
+    x, y = synthetic_volume(2, 1, 32, 2, seed=8)
+    x, y = x.to(dev), y.to(dev)
+
+    def fwd_bwd(words):
+        monkeypatch.setenv("UNETR_AMD_X3_WORDS", words)
+        opt.zero_grad(set_to_none=True)
+        out = m(x)
+        crit(out, y).backward()
+        return out.detach().clone(), flat["grad"].clone()
+
+    def words_match():
+        w = m.vit.blocks[0].mlp.linear1.weight
+        sh = Fn.weight_x3(w)
+        assert sh is not None and sh.dtype == torch.int32 and sh.shape == w.shape
+        hi = (sh << 16).view(torch.float32)
+        lo = (sh & -65536).view(torch.float32)
+        assert relerr(hi + lo, w) < 2e-5
+
+    for phase in range(4):
+        o1, g1 = fwd_bwd("1")
+        assert flat.get("shadow_x3") is not None
+        words_match()
+        o0, g0 = fwd_bwd("0")
+        assert relerr(o1, o0) < 1e-5 and relerr(g1, g0) < 1e-4, phase
+        if phase == 0:
+            opt.step()                                         # AdamW kernels write the arena: the optimizer re-derives the words
+        elif phase == 1:
+            with torch.no_grad():
+                m.vit.blocks[0].mlp.linear1.weight.mul_(1.25)  # torch writes a parameter: version counter
+        elif phase == 2:
+            sd = {k: v * 0.9 for k, v in m.state_dict().items()}
+            m.load_state_dict(sd)
+    Fn.clear_grad_sinks(flat["state"])
+
+
 @pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
 def test_data_parallel_arena_update(pkg, dev, comm_dtype):
     """The N>1 update of bench.py on one device: AdamW.step_reduced reads the 'all-reduced' gradient SUM of a simulated
