@@ -151,6 +151,9 @@ __device__ __forceinline__ float x3_rem(uint32_t r) {
 }
 // the operand that enters both MFMAs as it is: four words [hi | lo << 16]
 __device__ __forceinline__ u32x4 x3_words(u32x4 r) {
+#ifdef UNETR_X3_DROP_LO
+    return PrecBF16x3::from_raw(r);            // (diagnostic build: round-to-nearest hi, zero lo -- bf16 x 1 operands)
+#endif
     const bf16x2_ l01 = __builtin_convertvector((f32x2_){x3_rem(r[0]), x3_rem(r[1])}, bf16x2_);
     const bf16x2_ l23 = __builtin_convertvector((f32x2_){x3_rem(r[2]), x3_rem(r[3])}, bf16x2_);
     const uint32_t p01 = __builtin_bit_cast(uint32_t, l01), p23 = __builtin_bit_cast(uint32_t, l23);
@@ -159,6 +162,14 @@ __device__ __forceinline__ u32x4 x3_words(u32x4 r) {
 }
 // the operand that is duplicated: [hi, hi] words and [lo, lo] words (one v_perm / one packed convert of (d, d) per element)
 __device__ __forceinline__ void x3_dup(u32x4 r, u32x4& hh, u32x4& ll) {
+#ifdef UNETR_X3_DROP_LO
+    {
+        const u32x4 w = PrecBF16x3::from_raw(r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hh[e] = __builtin_amdgcn_perm(w[e], w[e], 0x01000100u); ll[e] = 0u; }
+        return;
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t re = r[e];
@@ -392,7 +403,8 @@ int launch_bf16(int M, int N, int K, const typename std::conditional<X3 != 0, fl
     int splits = 1;
     // few tiles (batch-2 token counts): the kernel is latency-bound, one workgroup's time is ~ its K steps, so long K
     // ranges are cut into slabs of >= 12 steps (shorter slabs cost more in the reduce launch than they save)
-    if (tiles < 192 && ksteps >= 24) splits = std::min(ksteps / 12, (int)((512 + tiles - 1) / tiles));      // (X3: 128-byte stages are 32 elements -- a slab is >= 12 stages either way)
+    const int min_steps = (X3 != 0 && getenv("UNETR_X3_SPLIT_K768") == nullptr) ? 48 : 24;       // (X3: 32-element stages; K = 768 stays whole as in bf16 mode)
+    if (tiles < 192 && ksteps >= min_steps) splits = std::min(ksteps / (min_steps / 2), (int)((512 + tiles - 1) / tiles));
     if (const char* e = getenv("UNETR_GEMM_SPLITS")) { int v = atoi(e); if (v > 0) splits = std::min(v, ksteps); }
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits < 1 || ws == nullptr) splits = 1;
