@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
-ABI_VERSION = 15       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 16       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -59,7 +59,8 @@ class GroupedProblem(ctypes.Structure):
 
 class AdamWArena(ctypes.Structure):
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("m", c_void_p), ("v", c_void_p), ("shadow_bf16", c_void_p), ("steps", c_void_p),
-                ("total", c_long), ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float)]
+                ("total", c_long), ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+                ("shadow_x3", c_void_p)]
 
 
 class PackProblem(ctypes.Structure):
@@ -156,7 +157,7 @@ _SIGNATURES = {
     "unetr_ranking_loss_fwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, c_size_t, P],
     "unetr_ranking_loss_bwd": [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "unetr_adamw": [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],
-    "unetr_adamw_reduced": [P, P, c_int, c_float, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P],
+    "unetr_adamw_reduced": [P, P, c_int, c_float, P, P, c_long, c_float, c_float, c_float, c_float, c_float, P, P, P, P],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("unetr_conv3_packed_bytes", "unetr_conv3_packed_1x1_bytes", "unetr_ranking_workspace_floats",

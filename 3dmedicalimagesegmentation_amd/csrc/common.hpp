@@ -103,6 +103,48 @@ struct PrecBF16x3 {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
 };
+// bf16x3 operand forms straight from raw fp32 bits (the X3 instantiation below is bound by this VALU work, so it is kept minimal):
+// hi = the value TRUNCATED to bf16 (its upper 16 bits: no rounding instructions), lo = bf16(a - hi) -- the difference is exact in
+// fp32, so hi + lo carries the value to 2^-16 relative, the precision the mode's products have anyway (PrecBF16x3, common.hpp).
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float x3_rem(uint32_t r) {
+#ifdef UNETR_X3_DROP_LO
+    return 0.f;
+#else
+    return __builtin_bit_cast(float, r) - __builtin_bit_cast(float, r & 0xffff0000u);
+#endif
+}
+// the operand that enters both MFMAs as it is: four words [hi | lo << 16]
+__device__ __forceinline__ u32x4 x3_words(u32x4 r) {
+#ifdef UNETR_X3_DROP_LO
+    return PrecBF16x3::from_raw(r);            // (diagnostic build: round-to-nearest hi, zero lo -- bf16 x 1 operands)
+#endif
+    const bf16x2_ l01 = __builtin_convertvector((f32x2_){x3_rem(r[0]), x3_rem(r[1])}, bf16x2_);
+    const bf16x2_ l23 = __builtin_convertvector((f32x2_){x3_rem(r[2]), x3_rem(r[3])}, bf16x2_);
+    const uint32_t p01 = __builtin_bit_cast(uint32_t, l01), p23 = __builtin_bit_cast(uint32_t, l23);
+    return (u32x4){__builtin_amdgcn_perm(p01, r[0], 0x05040302u), __builtin_amdgcn_perm(p01, r[1], 0x07060302u),
+                   __builtin_amdgcn_perm(p23, r[2], 0x05040302u), __builtin_amdgcn_perm(p23, r[3], 0x07060302u)};
+}
+// the operand that is duplicated: [hi, hi] words and [lo, lo] words (one v_perm / one packed convert of (d, d) per element)
+__device__ __forceinline__ void x3_dup(u32x4 r, u32x4& hh, u32x4& ll) {
+#ifdef UNETR_X3_DROP_LO
+    {
+        const u32x4 w = PrecBF16x3::from_raw(r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hh[e] = __builtin_amdgcn_perm(w[e], w[e], 0x01000100u); ll[e] = 0u; }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t re = r[e];
+        hh[e] = __builtin_amdgcn_perm(re, re, 0x03020302u);
+        const float d = x3_rem(re);
+        ll[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){d, d}, bf16x2_));
+    }
+}
+
 // one contraction element per lane (the K = 4 shape of v_mfma_f32_16x16x4_f32: lane group g supplies element g): kernels that
 // feed the fp32 MFMA element by element collect FOUR steps into one chunk for the policies whose MFMA wants a whole chunk
 template <class P> struct ElemMma {

@@ -137,48 +137,6 @@ __device__ __forceinline__ bool tile_of(int L, int mt, int nt, int& tm, int& tn)
     return true;
 }
 
-// bf16x3 operand forms straight from raw fp32 bits (the X3 instantiation below is bound by this VALU work, so it is kept minimal):
-// hi = the value TRUNCATED to bf16 (its upper 16 bits: no rounding instructions), lo = bf16(a - hi) -- the difference is exact in
-// fp32, so hi + lo carries the value to 2^-16 relative, the precision the mode's products have anyway (PrecBF16x3, common.hpp).
-typedef float f32x2_ __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float x3_rem(uint32_t r) {
-#ifdef UNETR_X3_DROP_LO
-    return 0.f;
-#else
-    return __builtin_bit_cast(float, r) - __builtin_bit_cast(float, r & 0xffff0000u);
-#endif
-}
-// the operand that enters both MFMAs as it is: four words [hi | lo << 16]
-__device__ __forceinline__ u32x4 x3_words(u32x4 r) {
-#ifdef UNETR_X3_DROP_LO
-    return PrecBF16x3::from_raw(r);            // (diagnostic build: round-to-nearest hi, zero lo -- bf16 x 1 operands)
-#endif
-    const bf16x2_ l01 = __builtin_convertvector((f32x2_){x3_rem(r[0]), x3_rem(r[1])}, bf16x2_);
-    const bf16x2_ l23 = __builtin_convertvector((f32x2_){x3_rem(r[2]), x3_rem(r[3])}, bf16x2_);
-    const uint32_t p01 = __builtin_bit_cast(uint32_t, l01), p23 = __builtin_bit_cast(uint32_t, l23);
-    return (u32x4){__builtin_amdgcn_perm(p01, r[0], 0x05040302u), __builtin_amdgcn_perm(p01, r[1], 0x07060302u),
-                   __builtin_amdgcn_perm(p23, r[2], 0x05040302u), __builtin_amdgcn_perm(p23, r[3], 0x07060302u)};
-}
-// the operand that is duplicated: [hi, hi] words and [lo, lo] words (one v_perm / one packed convert of (d, d) per element)
-__device__ __forceinline__ void x3_dup(u32x4 r, u32x4& hh, u32x4& ll) {
-#ifdef UNETR_X3_DROP_LO
-    {
-        const u32x4 w = PrecBF16x3::from_raw(r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { hh[e] = __builtin_amdgcn_perm(w[e], w[e], 0x01000100u); ll[e] = 0u; }
-        return;
-    }
-#endif
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t re = r[e];
-        hh[e] = __builtin_amdgcn_perm(re, re, 0x03020302u);
-        const float d = x3_rem(re);
-        ll[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){d, d}, bf16x2_));
-    }
-}
-
 // X3 (bf16x3 precision mode, round 4): the SAME kernel on fp32-stored operands.  A 128-byte image row is then 32 fp32 values (a K
 // stage is 32 elements), the LDS-DMA moves the raw fp32 bits, and a fragment chunk (4 consecutive k of a row) is split into the four
 // [hi | lo << 16] words of PrecBF16x3 in REGISTERS right after its ds_read_b128 (PrecBF16x3::from_raw), two MFMAs per chunk pair.  The
@@ -705,7 +663,7 @@ static int big_tile_width(int M, int N, int K) {
 constexpr int GW_MAX = 64;     // 12 blocks x 4 Linear layers + patch embedding in ONE launch
 struct GwProblem { const uint16_t* dy; const uint16_t* x; float* dw; int M, N, K, tile0, ntn, step_idx; };
 // FUSE: the arenas of the fused optimizer epilogue (dw then only NAMES the arena slice: element offset = dw - gb)
-struct GwFuse { float* pb; const float* gb; float* mb; float* vb; uint16_t* sb; const float* steps; float lr, b1, b2, eps, wd; };
+struct GwFuse { float* pb; const float* gb; float* mb; float* vb; uint16_t* sb; const float* steps; float lr, b1, b2, eps, wd; uint32_t* sw; };
 struct GwArgs { int n; GwFuse f; GwProblem p[GW_MAX]; };
 
 template <int NS, int BKT, int FUSE>                        // BKT = tokens per stage (64 or 32); FUSE: 0 store dW, 1 AdamW, 2 store bf16(dW)
@@ -873,6 +831,7 @@ gemm_bf16_grouped_wgrad_kernel(GwArgs ga) {
                     __builtin_nontemporal_store(mv[u], (f32x4*)(f.mb + idx[u]));
                     __builtin_nontemporal_store(vv[u], (f32x4*)(f.vb + idx[u]));
                     if (f.sb) *(bf16x4*)(f.sb + idx[u]) = __builtin_convertvector(pv[u], bf16x4);
+                    if (f.sw) *(u32x4*)(f.sw + idx[u]) = x3_words(__builtin_bit_cast(u32x4, pv[u]));      // (bf16x3 mode: the word shadow)
                 }
             }
         }
@@ -1190,7 +1149,8 @@ static int grouped_wgrad_bf16(const unetr_grouped_problem* probs, int n, const u
         GwArgs ga;
         ga.n = std::min(GW_MAX, n - base);
         ga.f = GwFuse{};
-        if (a) ga.f = GwFuse{a->param, a->grad, a->m, a->v, (uint16_t*)a->shadow_bf16, a->steps, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay};
+        if (a) ga.f = GwFuse{a->param, a->grad, a->m, a->v, (uint16_t*)a->shadow_bf16, a->steps, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay,
+                             b16 ? nullptr : (uint32_t*)a->shadow_x3};
         int tiles = 0;
         for (int i = 0; i < ga.n; ++i) {
             const unetr_grouped_problem& q = probs[base + i];
@@ -1223,7 +1183,7 @@ extern "C" int unetr_gemm_bf16_grouped_wgrad(const unetr_grouped_problem* probs,
 extern "C" int unetr_gemm_bf16_grouped_wgrad_bf16out(const unetr_grouped_problem* probs, int n, const float* grad_arena, void* out_bf16_arena,
                                                      long total, void* stream) {
     unetr_adamw_arena a{};
-    a.grad = grad_arena; a.shadow_bf16 = out_bf16_arena; a.total = total;
+    a.grad = grad_arena; a.shadow_bf16 = out_bf16_arena; a.total = total; a.shadow_x3 = nullptr;
     return grouped_wgrad_bf16(probs, n, &a, nullptr, stream, true);
 }
 

@@ -1693,7 +1693,7 @@ template <bool GB16>
 __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale, float* __restrict__ m, float* __restrict__ v,
              long n4, long n, float lr, float b1, float b2, float eps, float wd, const float* __restrict__ step_dev,
-             uint16_t* __restrict__ shadow) {
+             uint16_t* __restrict__ shadow, uint32_t* __restrict__ words) {
     const AdamWCoef c = adamw_coef(lr, b1, b2, eps, wd, *step_dev);
     auto grad1 = [&](long i) -> float {
         if (GB16) { uint32_t u = (uint32_t)((const uint16_t*)gsrc)[i] << 16; return __builtin_bit_cast(float, u) * gscale; }
@@ -1712,6 +1712,7 @@ adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale,
         }
         __builtin_nontemporal_store(pv, (f32x4*)p + i); __builtin_nontemporal_store(mv, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i);
         if (shadow) ((bf16x4*)shadow)[i] = __builtin_convertvector(pv, bf16x4);
+        if (words) ((u32x4*)words)[i] = x3_words(__builtin_bit_cast(u32x4, pv));        // (bf16x3 mode: the word shadow of the arena)
     }
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
@@ -1720,6 +1721,7 @@ adamw_kernel(float* __restrict__ p, const void* __restrict__ gsrc, float gscale,
         adamw_elem(pe, me, ve, grad1(i), c);
         p[i] = pe; m[i] = me; v[i] = ve;
         if (shadow) { __bf16 h = (__bf16)p[i]; shadow[i] = __builtin_bit_cast(uint16_t, h); }
+        if (words) { const u32x4 w4 = x3_words((u32x4){__builtin_bit_cast(uint32_t, p[i]), 0u, 0u, 0u}); words[i] = w4[0]; }
     }
 }
 
@@ -1728,7 +1730,7 @@ constexpr int AR_BLOCK = 4096;
 __global__ void __launch_bounds__(256)
 adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                     uint16_t* __restrict__ shadow, const float* __restrict__ steps, const long* __restrict__ table, int nr,
-                    float lr, float b1, float b2, float eps, float wd) {
+                    float lr, float b1, float b2, float eps, float wd, uint32_t* __restrict__ words) {
     int lo_r = 0, hi_r = nr - 1;
     const long blk = blockIdx.x;
     while (lo_r < hi_r) {                                  // last range whose first block <= blk (uniform: scalar loads)
@@ -1749,6 +1751,7 @@ adamw_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
         }
         __builtin_nontemporal_store(pv, (f32x4*)p + i); __builtin_nontemporal_store(mv, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i);
         if (shadow) ((bf16x4*)shadow)[i] = __builtin_convertvector(pv, bf16x4);
+        if (words) ((u32x4*)words)[i] = x3_words(__builtin_bit_cast(u32x4, pv));
     }
 }
 
@@ -2282,8 +2285,8 @@ extern "C" int unetr_outconv_in_bwd(const float* dlogits, const void* c2, long l
 }
 
 static int adamw_launch(float* p, const void* g, int g_bf16, float gscale, float* m, float* v, long n, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, const float* step_dev, void* shadow_bf16, void* stream) {
-    if (!p || !g || !m || !v || !step_dev || n <= 0 || (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)) return UNETR_ERR_ARG;
+                        float beta2, float eps, float weight_decay, const float* step_dev, void* shadow_bf16, void* shadow_x3, void* stream) {
+    if (!p || !g || !m || !v || !step_dev || n <= 0 || (reinterpret_cast<uintptr_t>(shadow_bf16) & 7) || (reinterpret_cast<uintptr_t>(shadow_x3) & 15)) return UNETR_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) return UNETR_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(g) & (g_bf16 ? 7 : 15)) return UNETR_ERR_ARG;
     long n4 = n >> 2;
@@ -2295,24 +2298,25 @@ static int adamw_launch(float* p, const void* g, int g_bf16, float gscale, float
     dim3 grid(grid_for(std::max<long>(n4, 1), 256, cap));
     if (g_bf16)
         hipLaunchKernelGGL(adamw_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g, gscale, m, v, n4, n, lr, beta1, beta2, eps,
-                           weight_decay, step_dev, (uint16_t*)shadow_bf16);
+                           weight_decay, step_dev, (uint16_t*)shadow_bf16, (uint32_t*)shadow_x3);
     else
         hipLaunchKernelGGL(adamw_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p, g, gscale, m, v, n4, n, lr, beta1, beta2, eps,
-                           weight_decay, step_dev, (uint16_t*)shadow_bf16);
+                           weight_decay, step_dev, (uint16_t*)shadow_bf16, (uint32_t*)shadow_x3);
     return unetr_check_launch();
 }
 
 extern "C" int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, const float* step_dev, void* shadow_bf16, void* stream) {
-    return adamw_launch(p, g, 0, 1.0f, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_bf16, stream);
+    return adamw_launch(p, g, 0, 1.0f, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_bf16, nullptr, stream);
 }
 
 extern "C" int unetr_adamw_ranges(const unetr_adamw_arena* a, const long* table_dev, int n_ranges, long n_blocks, void* stream) {
     if (!a || !a->param || !a->grad || !a->m || !a->v || !a->steps || !table_dev || n_ranges <= 0 || n_blocks <= 0) return UNETR_ERR_ARG;
-    if (((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->m | (uintptr_t)a->v) & 15 || ((uintptr_t)a->shadow_bf16 & 7)) return UNETR_ERR_ARG;
+    if (((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)a->shadow_x3) & 15 || ((uintptr_t)a->shadow_bf16 & 7)) return UNETR_ERR_ARG;
     if (n_blocks > 0x7fffffffL) return UNETR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(adamw_ranges_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, a->param, a->grad, a->m, a->v,
-                       (uint16_t*)a->shadow_bf16, a->steps, table_dev, n_ranges, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay);
+                       (uint16_t*)a->shadow_bf16, a->steps, table_dev, n_ranges, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay,
+                       (uint32_t*)a->shadow_x3);
     return unetr_check_launch();
 }
 
@@ -2320,6 +2324,6 @@ extern "C" int unetr_adamw_ranges(const unetr_adamw_arena* a, const long* table_
 // (gscale = 1 / world size) inside the update, so no copy back into the gradient arena is needed
 extern "C" int unetr_adamw_reduced(float* p, const void* g, int g_is_bf16, float gscale, float* m, float* v, long n, float lr,
                                    float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
-                                   void* shadow_bf16, void* stream) {
-    return adamw_launch(p, g, g_is_bf16, gscale, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_bf16, stream);
+                                   void* shadow_bf16, void* shadow_x3, void* stream) {
+    return adamw_launch(p, g, g_is_bf16, gscale, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, shadow_bf16, shadow_x3, stream);
 }

@@ -524,13 +524,15 @@ def weight_x3(w):
     return ent[0]
 
 
-def refresh_x3_shadow(flat):
-    """optimizer side (flat arenas): the parameter arena has just been updated by a kernel of this package -- re-derive the word
-    shadow when the bf16x3 GEMMs have asked for one"""
+def refresh_x3_shadow(flat, written=False):
+    """optimizer side (flat arenas): the parameter arena has just been updated by kernels of this package.  written: those kernels
+    wrote the word shadow themselves (AdamW arena launches take its pointer); otherwise one derive launch over the arena -- when the
+    bf16x3 GEMMs have asked for a word shadow at all"""
     arena = flat.get("shadow_x3") if flat is not None else None
     if arena is None:
         return
-    _split_words(flat["param"], arena, flat["total"])
+    if not written:
+        _split_words(flat["param"], arena, flat["total"])
     for p in flat["params"]:
         ent = _SHADOW_X3.get(id(p))
         if ent is not None and ent[2]() is p and ent[3] == p.data_ptr():

@@ -47,6 +47,7 @@ class AdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         stream = torch.cuda.current_stream().cuda_stream
+        per_tensor = False
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             params = group["params"]
@@ -56,6 +57,7 @@ class AdamW(torch.optim.Optimizer):
             dev = next(p for p in params if p.grad is not None).device
             if self._flat is not None and self._flat_step(group, params, pattern, dev, stream):
                 continue
+            per_tensor = True
             steps = self._advance_steps(gi, params, pattern, dev)
             for i, p in enumerate(params):
                 g = p.grad
@@ -74,6 +76,8 @@ class AdamW(torch.optim.Optimizer):
                 call("unetr_adamw", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                      group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.data_ptr() + 4 * i,
                      Fn.shadow_ptr_for_update(p), stream)
+        if self._flat is not None and per_tensor:
+            Fn.refresh_x3_shadow(self._flat)      # (per-tensor launches do not write the bf16x3 word shadow: one derive launch)
         Fn.refresh_conv_packs()          # one grouped launch: packed conv weights follow the update
         return loss
 
@@ -103,9 +107,11 @@ class AdamW(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         shadow = flat.get("shadow")            # bf16 copy of the arena read by the bf16-storage GEMMs, refreshed in the same kernel
         sptr = shadow.data_ptr() + lo * 2 if shadow is not None else None
+        words = flat.get("shadow_x3")          # bf16x3 mode: the word shadow (functional.weight_x3), written by the same kernel
+        wptr = words.data_ptr() + lo * 4 if words is not None else None
         call("unetr_adamw_reduced", flat["param"].data_ptr() + lo * 4, gptr + lo * (2 if g_bf16 else 4), int(g_bf16), gscale,
              m.data_ptr() + lo * 4, v.data_ptr() + lo * 4, hi - lo, group["lr"], b1, b2, group["eps"], group["weight_decay"],
-             steps.data_ptr() + 4 * i, sptr, stream)
+             steps.data_ptr() + 4 * i, sptr, wptr, stream)
         for k in range(i, j + 1):
             self._host_steps[k] += 1
 
@@ -123,7 +129,7 @@ class AdamW(torch.optim.Optimizer):
             self._launch_run(group, run, steps, gbase, False, 1.0, stream)
         if flat.get("shadow") is not None:           # the kernel rewrote the bf16 shadow slices of every parameter that stepped
             Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has], flat.get("state"))
-        Fn.refresh_x3_shadow(flat)                   # (bf16x3 mode: the word shadow follows the update)
+        Fn.refresh_x3_shadow(flat, written=True)     # (bf16x3 mode: the optimizer kernels wrote the word shadow)
         return True
 
     # ---- single-GPU fused step: AdamW of the ViT Linear weights rides on the grouped weight-gradient launch ----------------
@@ -155,9 +161,10 @@ class AdamW(torch.optim.Optimizer):
         m, v = self._flat_state
         shadow = flat.get("shadow")
         b1, b2 = group["betas"]
+        words = flat.get("shadow_x3")
         arena = _capi.AdamWArena(flat["param"].data_ptr(), flat["grad"].data_ptr(), m.data_ptr(), v.data_ptr(),
                                  shadow.data_ptr() if shadow is not None else None, steps.data_ptr(), flat["param"].numel(),
-                                 group["lr"], b1, b2, group["eps"], group["weight_decay"])
+                                 group["lr"], b1, b2, group["eps"], group["weight_decay"], words.data_ptr() if words is not None else None)
         gbase = flat["grad"].data_ptr()
         index = {gbase + o * 4: i for i, (o, has) in enumerate(zip(flat["offsets"], pattern)) if has}
         self._fused = dict(pattern=pattern, arena=arena, index=index, done=[], keep=(m, v, steps))
@@ -205,7 +212,7 @@ class AdamW(torch.optim.Optimizer):
         for k, has in enumerate(pattern):
             if has:
                 self._host_steps[k] += 1
-        Fn.refresh_x3_shadow(flat)
+        Fn.refresh_x3_shadow(flat, written=True)
         if flat.get("shadow") is not None:
             Fn.mark_flat_maintained([p for p, has in zip(params, pattern) if has], flat.get("state"))
         Fn.refresh_conv_packs()
@@ -240,7 +247,7 @@ class AdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def end_reduced_step(self, plan):
-        Fn.refresh_x3_shadow(self._flat)
+        Fn.refresh_x3_shadow(self._flat, written=True)
         if self._flat.get("shadow") is not None:
             Fn.mark_flat_maintained([p for p, has in zip(self.param_groups[0]["params"], plan["pattern"]) if has], self._flat.get("state"))
         Fn.refresh_conv_packs()
@@ -266,7 +273,7 @@ class AdamW(torch.optim.Optimizer):
             if before_run is not None:
                 before_run(k, run[2], run[3])
             self._launch_run(group, run, steps, gsrc.data_ptr(), g_bf16, gscale, stream)
-        Fn.refresh_x3_shadow(self._flat)
+        Fn.refresh_x3_shadow(self._flat, written=True)
         if self._flat.get("shadow") is not None:
             Fn.mark_flat_maintained([p for p, has in zip(params, plan["pattern"]) if has], self._flat.get("state"))
         Fn.refresh_conv_packs()

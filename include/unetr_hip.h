@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 15
+#define UNETR_ABI_VERSION 16
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -424,7 +424,8 @@ int unetr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, 
  * (fp32, or bf16 when g_is_bf16), gscale = 1 / world size is applied on the fly. */
 int unetr_adamw_reduced(float* p, const void* g, int g_is_bf16, float gscale, float* m, float* v, long n, float lr,
                         float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
-                        void* shadow_bf16, void* stream);
+                        void* shadow_bf16, void* shadow_x3 /* optional: bf16x3 word shadow of the updated p (unetr_split_words), or NULL */,
+                        void* stream);
 
 /* ---- the single-GPU step's optimizer fused into the producer of the gradients (train_step.TrainStep(fuse_update=True)) ------
  * The four arenas (parameters, gradients, both moments; fp32, `total` elements, identical layout) and the optional bf16 shadow
@@ -432,6 +433,7 @@ int unetr_adamw_reduced(float* p, const void* g, int g_is_bf16, float gscale, fl
 typedef struct {
     float* param; const float* grad; float* m; float* v; void* shadow_bf16; const float* steps; long total;
     float lr, beta1, beta2, eps, weight_decay;
+    void* shadow_x3;                  /* optional arena of bf16x3 words (unetr_split_words layout), written next to shadow_bf16; or NULL */
 } unetr_adamw_arena;
 /* grouped ViT weight gradients (unetr_gemm_bf16_grouped_wgrad) whose epilogue APPLIES AdamW instead of storing dW: every
  * probs[i].dw must address a slice of a->grad (it is not written); the parameter / moment / shadow slices at the same arena
