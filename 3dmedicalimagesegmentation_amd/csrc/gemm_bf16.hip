@@ -483,12 +483,28 @@ __device__ __forceinline__ void big_epilogue(f32x4 (&acc)[8][WN], const EpBf& ep
 // WN = 16-column MFMA tiles per wave: the tile is 256 rows x 64 WN columns (256 / 192 / 128).  Narrower tiles exist for the
 // tile COUNT: [6912 x 3072] is 324 tiles of 256 x 256 (two rounds of 256 CUs, the second 27 % full) but 432 of 256 x 192, and
 // N = 768 is 81 / 162 tiles at WN 4 / 2.  The B region of a K tile is 64 WN rows = WN DMA pieces per thread.
-// the K loop of the large-tile kernels: acc = A[m0 .. m0+255, k0 .. k0 + 64 nk) . B[n0 .. n0 + 64 WN, same k]^T (accumulators zeroed here).
-// Every wave leaves having executed the same number of s_barrier; the K-tile buffers are free for the epilogue (see below).
 template <int WN>
-__device__ __forceinline__ void big_kloop(f32x4 (&acc)[8][WN], const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb,
-                                          int M, int N, int m0, int n0, int k0, int nk, char* lds, int tid, int lane, int wave, int wr, int wc) {
+__global__ void __launch_bounds__(512, 2)
+gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
+                     const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep) {
     constexpr int NT = 512, HALF = 128 * 128, BN = 64 * WN, BUFB = 2 * HALF + BN * 128;
+    constexpr int LDSB = 2 * BUFB > 8 * 16384 ? 2 * BUFB : 8 * 16384;      // (the epilogue stages 16 KB per wave)
+    __shared__ __attribute__((aligned(1024))) char lds[LDSB];
+
+    // tile order: workgroup L runs on XCD L % 8; an XCD gets a contiguous run of tiles, fastest along the operand whose re-use
+    // saves more traffic (n_fast: the run shares A rows and walks the weight columns; else the other way round)
+    int tm, tn;
+    {
+        const int T = mt * nt, per = (T + 7) >> 3, L = blockIdx.x;
+        const int t = (L & 7) * per + (L >> 3);
+        if ((L >> 3) >= per || t >= T) return;
+        if (n_fast) { tn = t % nt; tm = t / nt; } else { tm = t % mt; tn = t / mt; }
+    }
+    const int m0 = tm * 256, n0 = tn * BN;
+    const int nk = K / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
+
     // DMA sources: piece i of a region covers row (tid + i * 512) >> 3 of the region, chunk (id & 7) ^ ((r >> 1) & 7).  A: two
     // half-tiles of 128 rows (2 pieces each); B: one region of BN rows (WN pieces)
     const uint16_t* asrc[2][2];
@@ -498,12 +514,12 @@ __device__ __forceinline__ void big_kloop(f32x4 (&acc)[8][WN], const uint16_t* _
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * NT, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
-            asrc[h][i] = A + (long)min(m0 + h * 128 + r, M - 1) * lda + k0 + c * 8;
+            asrc[h][i] = A + (long)min(m0 + h * 128 + r, M - 1) * lda + c * 8;
         }
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
         const int id = tid + i * NT, r = id >> 3, c = (id & 7) ^ ((r >> 1) & 7);
-        bsrc[i] = B + (long)min(n0 + r, N - 1) * ldb + k0 + c * 8;
+        bsrc[i] = B + (long)min(n0 + r, N - 1) * ldb + c * 8;
     }
     auto dma = [&](const uint16_t* const (&src)[2], int T, char* dst) __attribute__((always_inline)) {
 #pragma unroll
@@ -521,6 +537,7 @@ __device__ __forceinline__ void big_kloop(f32x4 (&acc)[8][WN], const uint16_t* _
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) off[kh] = lds_tile_off(lane & 15, kh * 4 + (lane >> 4));
 
+    f32x4 acc[8][WN];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -598,117 +615,8 @@ __device__ __forceinline__ void big_kloop(f32x4 (&acc)[8][WN], const uint16_t* _
 #undef BIG_MEM_END
 #undef BIG_CMP_END
 #undef BIG_HALF
-}
 
-template <int WN>
-__global__ void __launch_bounds__(512, 2)
-gemm_bf16_big_kernel(int M, int N, int K, int mt, int nt, int n_fast,
-                     const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep) {
-    constexpr int HALF = 128 * 128, BN = 64 * WN, BUFB = 2 * HALF + BN * 128;
-    constexpr int LDSB = 2 * BUFB > 8 * 16384 ? 2 * BUFB : 8 * 16384;      // (the epilogue stages 16 KB per wave)
-    __shared__ __attribute__((aligned(1024))) char lds[LDSB];
-
-    // tile order: workgroup L runs on XCD L % 8; an XCD gets a contiguous run of tiles, fastest along the operand whose re-use
-    // saves more traffic (n_fast: the run shares A rows and walks the weight columns; else the other way round)
-    int tm, tn;
-    {
-        const int T = mt * nt, per = (T + 7) >> 3, L = blockIdx.x;
-        const int t = (L & 7) * per + (L >> 3);
-        if ((L >> 3) >= per || t >= T) return;
-        if (n_fast) { tn = t % nt; tm = t / nt; } else { tm = t % mt; tn = t / mt; }
-    }
-    const int m0 = tm * 256, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
-    f32x4 acc[8][WN];
-    big_kloop<WN>(acc, A, lda, B, ldb, M, N, m0, n0, 0, K / 64, lds, tid, lane, wave, wr, wc);
     big_epilogue<WN>(acc, ep, lds, M, N, m0, n0, wave, lane, wr, wc);
-}
-
-// ---- stream-K form of the 256 x 256 kernel (round 4) ------------------------------------------------------------------------------
-// [6912 x 3072 x 768] is 324 tiles (two rounds of 256 CUs, the second 27 % full), [6912 x 768 x 3072] is 81: either way 3888 K-tile
-// units.  Here gridDim.x (<= 256, all resident: one workgroup per CU) workgroups each take a CONTIGUOUS range of units: the tail of
-// one tile's K range first, whole tiles, the head of a last tile's K range last.  A segment that does not start at k = 0 is a PART:
-// its accumulators go to memory as they are (lane-linear 16-byte pieces: every wave-instruction writes whole 128-byte lines) and one
-// lane adds 1 to the tile's counter; the segment that starts at k = 0 of a split tile is the tile's FINISHER: it runs last in its
-// workgroup, waits until the counter says every part has arrived, adds the parts in a fixed order and runs the epilogue.  Parts are
-// computed FIRST by the workgroups that follow the finisher, so nobody waits for work that has not started long ago; no cycle exists
-// (a finisher only waits for higher-numbered workgroups' first segments).
-// Hand-off across CUs (MI355X_MICROARCH 'Workgroup dispatch, XCD placement & inter-workgroup visibility', third row of its table): parts
-// are stored `sc1` (global_store_dwordx4), every storing wave waits vmcnt(0), a workgroup barrier, ONE lane's agent-scope atomic add;
-// the finisher polls the counter with an sc1 load (one lane, bounded: a counter that never arrives ends the wait and raises the error
-// flag instead of hanging the GPU), a workgroup barrier, then sc1 loads of the parts.  The finisher zeroes the counter again.
-__device__ __forceinline__ void sc1_store16(void* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-struct SkArgs { float* part; int* counters; int* err; int maxp; };
-
-__global__ void __launch_bounds__(512, 2)
-gemm_bf16_sk_kernel(int M, int N, int K, int mt, int nt, int n_fast,
-                    const uint16_t* __restrict__ A, long lda, const uint16_t* __restrict__ B, long ldb, EpBf ep, SkArgs sk) {
-    constexpr int WN = 4, LDSB = 2 * (2 * 128 * 128 + 256 * 128);
-    __shared__ __attribute__((aligned(1024))) char lds[LDSB];
-    __shared__ int poll_ok;
-    const int nk = K / 64, T = mt * nt;
-    const long U = (long)T * nk, G = gridDim.x, c = blockIdx.x;
-    const long u0 = c * U / G, u1 = (c + 1) * U / G;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
-    auto owner = [&](long u) { return (int)(((u + 1) * G + U - 1) / U - 1); };       // the workgroup whose range holds unit u
-    f32x4 acc[8][WN];
-    for (long u = u0; u < u1;) {
-        const int tile = (int)(u / nk), ka = (int)(u - (long)tile * nk), kb = (int)std::min<long>(nk, ka + (u1 - u));
-        int tm, tn;
-        if (n_fast) { tn = tile % nt; tm = tile / nt; } else { tm = tile % mt; tn = tile / mt; }
-        const int m0 = tm * 256, n0 = tn * 256;
-        big_kloop<WN>(acc, A, lda, B, ldb, M, N, m0, n0, ka * 64, kb - ka, lds, tid, lane, wave, wr, wc);
-        if (ka != 0) {
-            // a part: accumulators out as they are
-            const int pidx = (int)c - owner((long)tile * nk) - 1;
-            char* dst = (char*)sk.part + ((long)tile * sk.maxp + pidx) * 262144L + ((long)(wave * 32) * 64 + lane) * 16;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) sc1_store16(dst + (long)(i * 4 + j) * 1024, acc[i][j]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(sk.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (kb < nk) {
-                // the finisher of a split tile (last segment of this workgroup)
-                const int nparts = owner((long)tile * nk + nk - 1) - (int)c;
-                if (tid == 0) {
-                    int ok = 0;
-                    for (int it = 0; it < (1 << 20); ++it) {
-                        if (__hip_atomic_load(sk.counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nparts) { ok = 1; break; }
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    poll_ok = ok;
-                    if (!ok) __hip_atomic_store(sk.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                if (poll_ok) {
-                    for (int p = 0; p < nparts; ++p) {
-                        const char* src = (const char*)sk.part + ((long)tile * sk.maxp + p) * 262144L + ((long)(wave * 32) * 64 + lane) * 16;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            f32x4 t0, t1, t2, t3;
-                            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-                                         "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                                         : "v"(src + (long)(i * 4 + 0) * 1024), "v"(src + (long)(i * 4 + 1) * 1024),
-                                           "v"(src + (long)(i * 4 + 2) * 1024), "v"(src + (long)(i * 4 + 3) * 1024)
-                                         : "memory");
-                            acc[i][0] += t0; acc[i][1] += t1; acc[i][2] += t2; acc[i][3] += t3;
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(sk.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            big_epilogue<WN>(acc, ep, lds, M, N, m0, n0, wave, lane, wr, wc);
-            __syncthreads();                        // (the epilogue stages through the K-tile buffers the next segment's DMA fills)
-        }
-        u += kb - ka;
-    }
 }
 
 static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep, hipStream_t st, int wn) {
@@ -723,30 +631,6 @@ static int launch_bf16_big(int M, int N, int K, const uint16_t* A, long lda, con
 #define BIG_GO(W_) hipLaunchKernelGGL(gemm_bf16_big_kernel<W_>, dim3(per * 8), dim3(512), 0, st, M, N, K, mt, nt, n_fast, A, lda, B, ldb, ep)
     if (wn == 2) BIG_GO(2); else if (wn == 3) BIG_GO(3); else BIG_GO(4);
 #undef BIG_GO
-    return unetr_check_launch();
-}
-
-// stream-K launch of the 256 x 256 kernel: when the tile count leaves the second round of 256 CUs mostly empty (324 tiles) or the
-// first one mostly idle (81), at the many-row shapes it was measured on.  flags: >= 4096 zero-initialised ints owned by the caller
-// (tile counters, self-cleaning; [4095] = sticky error flag: a part that never arrived).  0 = not taken.
-static int launch_bf16_sk(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, const EpBf& ep, float* ws, size_t ws_bytes,
-                          int* flags, hipStream_t st, bool* taken) {
-    *taken = false;
-    const int mt = cdiv(M, 256), nt = cdiv(N, 256), nk = K / 64;
-    const long tiles = (long)mt * nt, U = tiles * nk;
-    const char* e = getenv("UNETR_GEMM_SK");
-    const int mode = e ? atoi(e) : 1;               // 0 off, 1 by the rule, 2 wherever it can run
-    if (!flags || !ws || mode == 0 || !ep.vec_ok || tiles > 4094 || nk < 2) return UNETR_OK;
-    const bool rule = M >= 4096 && ((tiles > 256 && tiles < 448) || (tiles >= 32 && tiles < 192 && nk >= 24));
-    if (!(rule || mode == 2)) return UNETR_OK;
-    const long G = std::min<long>(256, std::max<long>(1, U / 2));
-    const int maxp = (int)std::min<long>(nk, (long)nk * G / U + 2);
-    if ((size_t)tiles * maxp * 65536 * sizeof(float) > ws_bytes) return UNETR_OK;
-    const long cost_m = (long)M * std::min(8, nt) + N, cost_n = M + (long)N * std::min(8, mt);
-    const int n_fast = cost_n < cost_m;
-    SkArgs sk{ws, flags, flags + 4095, maxp};
-    hipLaunchKernelGGL(gemm_bf16_sk_kernel, dim3((unsigned)G), dim3(512), 0, st, M, N, K, mt, nt, n_fast, A, lda, B, ldb, ep, sk);
-    *taken = true;
     return unetr_check_launch();
 }
 
@@ -1060,11 +944,6 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
     const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
     // the 256 x 256 ping-pong kernel: many rows, weights as stored ([N, K]); K tiles of 64 (checked above).  Narrow outputs
     // (N = 768 at 6912 rows: 81 tiles for 256 CUs) keep the 128 x 128 tile, which fills the chip
-    if (!d->b_kn && d->tc_cout <= 0 && env_cfg == 0 && M >= 1024) {
-        bool taken = false;
-        const int rc = launch_bf16_sk(M, N, K, a, d->lda, b, d->ldb, ep, ws, ws_bytes, (int*)d->sk_flags, st, &taken);
-        if (taken || rc != UNETR_OK) return rc;
-    }
     if (!d->b_kn && d->tc_cout <= 0 && (env_cfg == 256 || (env_cfg == 0 && M >= 1024))) {
         const int wn = env_cfg == 256 ? (getenv("UNETR_GEMM_BIG_WN") ? big_tile_width(M, N, K) : 4) : big_tile_width(M, N, K);
         if (wn) return launch_bf16_big(M, N, K, a, d->lda, b, d->ldb, ep, st, wn);

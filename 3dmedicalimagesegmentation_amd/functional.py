@@ -369,35 +369,11 @@ def cast_bf16(src, out=None):
     return out
 
 
-_SK_FLAGS = {}
-
-
-def sk_flags(device):
-    """the stream-K tile counters of the large-tile GEMM (include/unetr_hip.h: unetr_gemm_bf16_desc.sk_flags): 4096 zeroed ints per
-    device, self-cleaning; element 4095 is the sticky error flag (sk_error).  None while a graph is being captured before the first
-    eager use (the buffer must not come out of a graph's private pool): the kernel then runs its data-parallel form."""
-    key = (device.type, device.index)
-    t = _SK_FLAGS.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        t = _SK_FLAGS[key] = torch.zeros(4096, dtype=torch.int32, device=device)
-    return t
-
-
-def sk_error(device):
-    """True when a stream-K launch on this device gave up waiting for a partial tile (its result is wrong); host-synchronising"""
-    t = _SK_FLAGS.get((device.type, device.index))
-    return bool(t is not None and int(t[4095].item()) != 0)
-
-
 def gemm_bf16(A, B, M, N, K, *, b_kn=False, C=None, Cb=None, lda=None, ldb=None, bias=None, res=None, ldr=0, res_mod=0,
               pre=None, aux=None, ldaux=0, act=0, accumulate=False, alpha=1.0, ldcb=None, tc=None):
     """C / Cb [M,N] = epilogue(A[M,K] @ (B[N,K]^T | B[K,N])) with bf16-stored operands (csrc/gemm_bf16.hip)"""
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     d = GemmBf16Desc()
-    _skf = sk_flags(A.device)
-    d.sk_flags = _skf.data_ptr() if _skf is not None else None
     d.M, d.N, d.K, d.b_kn = M, N, K, int(b_kn)
     d.lda = lda if lda is not None else K
     d.ldb = ldb if ldb is not None else (N if b_kn else K)
@@ -806,8 +782,6 @@ def gemm_bf16_ln_fwd(A, B, M, N, K, C, gamma, beta, y_bf16, bias=None, res=None,
     unetr_gemm_bf16_ln_fwd -- the LayerNorm of the NEXT layer rides on the split-K reduction of this GEMM"""
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     d = GemmBf16Desc()
-    _skf = sk_flags(A.device)
-    d.sk_flags = _skf.data_ptr() if _skf is not None else None
     d.M, d.N, d.K, d.b_kn = M, N, K, 0
     d.lda, d.ldb, d.ldc, d.ldcb = K, K, N, N
     d.bias = bias.data_ptr() if bias is not None else None
@@ -850,8 +824,6 @@ def gemm_ln_bwd_params(A, Bw, M, N, K, x, w, b, mean, rstd, dres=None, dx_bf16=N
     slabs the LayerNorm kernel sums them itself, so the separate split-K reduce launch disappears (bit-identical)."""
     assert A.dtype == torch.bfloat16 and Bw.dtype == torch.bfloat16
     d = GemmBf16Desc()
-    _skf = sk_flags(A.device)
-    d.sk_flags = _skf.data_ptr() if _skf is not None else None
     d.M, d.N, d.K, d.b_kn = M, N, K, 1
     d.lda, d.ldb, d.ldc, d.ldcb = K, N, N, N
     d.alpha = 1.0

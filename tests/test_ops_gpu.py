@@ -40,42 +40,6 @@ def test_gemm_nt_nn_tn(pkg, dev, prec, M, N, K):
     assert relerr(Fn.linear_wgrad(dy.to(dev), x.to(dev), prec), dy.t() @ x) < TOL[prec]
 
 
-@pytest.mark.parametrize("M,N,K,mode", [(6912, 3072, 768, "1"), (6912, 768, 3072, "1"), (6912, 768, 4096, "1"), (1030, 520, 192, "2"), (2100, 772, 128, "2"),
-                                        (1300, 256, 3072, "2"), (4100, 1000, 640, "2"), (1024, 512, 64, "2")])
-def test_gemm_bf16_stream_k(pkg, dev, monkeypatch, M, N, K, mode):
-    """Stream-K form of the 256 x 256 large-tile kernel (csrc/gemm_bf16.hip: gemm_bf16_sk_kernel): contiguous K-tile unit ranges per
-    workgroup, partial tiles handed from CU to CU through memory (sc1 stores, one agent-scope counter add per part, sc1 poll + loads).
-    The rule's own shapes (encoder MLP / patch-embedding GEMMs at batch 32) and forced (UNETR_GEMM_SK=2) ragged ones -- tiles split
-    over 2 to 20 workgroups, M / N tails, a single K tile per unit range -- three launches in a row on the same counters, every
-    epilogue kind, against fp64 products and bit for bit against the data-parallel kernel where the K split is trivial; the counters
-    are zero again afterwards and the error flag never rises."""
-    Fn = pkg.functional
-    monkeypatch.setenv("UNETR_GEMM_SK", mode)
-    x, w = g(M, K, seed=1).bfloat16(), g(N, K, seed=2, scale=0.1).bfloat16()
-    b, res = g(N, seed=3), g(M, N, seed=4)
-    xd, wd = x.to(dev), w.to(dev)
-    lin = (x.double() @ w.double().t()).float()
-    y = torch.full((M, N), float("nan"), device=dev)
-    yb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    outs = []
-    for rep in range(3):
-        y.fill_(float("nan"))
-        Fn.gemm_bf16(xd, wd, M, N, K, C=y, Cb=yb, bias=b.to(dev), res=res.to(dev), ldr=N)
-        outs.append(y.clone())
-        assert relerr(y, lin + b + res) < 2e-5
-        assert torch.equal(yb.cpu(), y.cpu().bfloat16())
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])        # fixed summation order
-    Fn.gemm_bf16(xd, wd, M, N, K, Cb=yb, bias=b.to(dev), act=1)
-    assert relerr(yb.float(), F.gelu(lin + b)) < 5e-3
-    flags = Fn.sk_flags(dev)
-    torch.cuda.synchronize()
-    assert int(flags.abs().sum().item()) == 0 and not Fn.sk_error(dev)
-    monkeypatch.setenv("UNETR_GEMM_SK", "0")
-    y0 = torch.empty(M, N, device=dev)
-    Fn.gemm_bf16(xd, wd, M, N, K, C=y0, bias=b.to(dev), res=res.to(dev), ldr=N)
-    assert relerr(outs[0], y0) < 2e-6
-
-
 @pytest.mark.parametrize("M,N,K", [(432, 768, 768), (432, 2304, 768), (432, 768, 3072), (432, 3072, 768), (430, 772, 96), (33, 64, 32), (1500, 3072, 768),
                                    (1000, 768, 3072), (864, 2304, 768), (216, 128, 64), (50, 200, 160)])
 def test_gemm_bf16x3_dma(pkg, dev, monkeypatch, M, N, K):
