@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_fused", "conv3_dgrad_fused", "conv3_wgrad3", "gemm", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd", "tconv_fwd", "tconv_dgrad", "tconv_wgrad"])
+    ap.add_argument("kernel", choices=["conv3_fwd", "conv3_dgrad", "conv3_wgrad", "conv3_fused", "conv3_dgrad_fused", "conv3_wgrad3", "gemm", "gemm_x3w", "gemm_dgrad", "gemm_wgrad", "gemm_bf16", "gemm_bf16_dgrad", "instnorm", "encoder_fwd", "tconv_fwd", "tconv_dgrad", "tconv_wgrad"])
     ap.add_argument("--cin", type=int, default=16)
     ap.add_argument("--cout", type=int, default=16)
     ap.add_argument("--size", type=int, default=96)
@@ -36,7 +36,7 @@ def main():
     pkg = importlib.import_module("3dmedicalimagesegmentation_amd")
     Fn = pkg.functional
     dev = torch.device("cuda:0")
-    prec = {"fp32": 0, "bf16": 1}[a.prec]
+    prec = {"fp32": 0, "bf16": 1, "bf16x3": 2}[a.prec]
     g = torch.Generator(device="cpu").manual_seed(0)
     S, B = a.size, a.batch
     dims = (B, S, S, S)
@@ -87,7 +87,11 @@ def main():
         yob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         if a.kernel.startswith("gemm_bf16"):
             nbytes = 2.0 * (M * K + N * K) + (2.0 if a.bf16_out else 4.0) * M * N
+        ww = torch.empty(N, K, dtype=torch.int32, device=dev)          # bf16x3: the weight as pre-split words (the optimizer-maintained shadow)
+        if a.kernel == "gemm_x3w":
+            Fn._split_words(w, ww, N * K)
         fn = {"gemm_bf16": (lambda: Fn.gemm_bf16(xb, wb, M, N, K, Cb=yob)) if a.bf16_out else (lambda: Fn.gemm_bf16(xb, wb, M, N, K, C=yo)),
+              "gemm_x3w": lambda: Fn.gemm(x, w, yo, M, N, K, lda=K, ldb=K, ldc=N, prec=2, b_words=ww),
               "gemm_bf16_dgrad": lambda: Fn.gemm_bf16(dyb, wb, M, K, N, b_kn=True, C=dxo),
               "gemm": lambda: Fn.linear_fwd(x, w, None, prec), "gemm_dgrad": lambda: Fn.linear_dgrad(dy, w, prec),
               "gemm_wgrad": lambda: Fn.linear_wgrad(dy, x, prec)}[a.kernel]

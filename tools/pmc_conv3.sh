@@ -12,8 +12,9 @@ CIN=${CIN:-16}
 COUT=${COUT:-16}
 # KARGS: the kernel_bench arguments after the kernel name (default: the conv shape); e.g. KERNEL=gemm_bf16 KARGS="--m 432 --n 2304 --k 768"
 KARGS=${KARGS:---cin $CIN --cout $COUT --size 96 --batch 2}
-ARGS="$KERNEL $KARGS --prec bf16 --iters 3 --warmup 1"
-python3 $R/tools/kernel_bench.py $KERNEL $KARGS --prec bf16 --iters 20 --graph > $O/time.json 2>/dev/null
+PREC=${PREC:-bf16}      # precision mode of the benchmarked kernel (bf16 | fp32 | bf16x3)
+ARGS="$KERNEL $KARGS --prec $PREC --iters 3 --warmup 1"
+python3 $R/tools/kernel_bench.py $KERNEL $KARGS --prec $PREC --iters 20 --graph > $O/time.json 2>/dev/null
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   T=$(echo $C | cut -d' ' -f1)
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$T -- python3 $R/tools/kernel_bench.py $ARGS > $O/$T.log 2>&1 || echo "pmc $T failed"
