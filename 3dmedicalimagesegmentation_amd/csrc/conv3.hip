@@ -1602,7 +1602,8 @@ conv3_wgrad_kernel(const void* __restrict__ x, long ldx, const typename ActOf<P>
 //     dw += dy_hi x_hi + dy_hi x_lo + dy_lo x_hi        (v_mfma_f32_16x16x32_bf16, fp32 accumulate; the lo-lo term is 2^-16 of the sum)
 // four ds_read_b64_tr_b16 per 3 MFMAs over 32 voxels instead of eight ds_read_b32 per 4 MFMAs.  16-channel input slab, 16-channel
 // output tile, one partial row per workgroup -- grid and partial layout of conv3_wgrad_kernel<P, ., ., HAS3, 1, .>.
-template <bool HAS3>
+// XS: fewer than four input channels (the image in front of encoder1): the window is read channel by channel.
+template <bool HAS3, bool XS = false>
 __global__ void __launch_bounds__(256, 2)
 conv3_wgrad_x3_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy, float* __restrict__ part,
                       const float* __restrict__ dy3, long lddy3, float* __restrict__ part3,
@@ -1702,8 +1703,16 @@ conv3_wgrad_x3_kernel(const float* __restrict__ x, long ldx, const float* __rest
                 const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1, cc = ci0 + 4 * qd;
                 const bool ok = (it0 + j < XIT) && hv < NHALO && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
                                 (unsigned)gx < (unsigned)W && cc < Cin;
-                const f32x4 t = *(const f32x4*)(ok ? x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + cc : x);
-                xb[j] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (XS) {
+                    const float* q = ok ? x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + cc : x;
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { const bool oke = ok && cc + e < Cin; const float u = *(oke ? q + e : x); t[e] = oke ? u : 0.f; }
+                    xb[j] = t;
+                } else {
+                    const f32x4 t = *(const f32x4*)(ok ? x + ((((long)b * D + gz) * H + gy) * W + gx) * ldx + cc : x);
+                    xb[j] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
@@ -2233,9 +2242,10 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
         // bf16x3: the (hi, lo) bf16-image kernel (conv3_wgrad_x3_kernel) wherever rows of x / dy / dy3 are whole 16-byte quads of channels
         // (UNETR_X3_WGRAD_TR16=0: the 4-byte fragment path below, kept for A/B runs and for the shapes this form declines)
         const char* e = getenv("UNETR_X3_WGRAD_TR16");
-        const bool q16 = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy3) & 15) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (Cin & 3) == 0 &&
-                         (Cout & 3) == 0 && (!dy3 || (lddy3 & 3) == 0);
-        if (q16 && Cin >= 8 && !(e && atoi(e) == 0)) {
+        const bool yq16 = (((uintptr_t)dy | (uintptr_t)dy3) & 15) == 0 && (lddy & 3) == 0 && (Cout & 3) == 0 && (!dy3 || (lddy3 & 3) == 0);
+        const bool xq16 = ((uintptr_t)x & 15) == 0 && (ldx & 3) == 0 && (Cin & 3) == 0;
+        const bool xs = Cin < 4;                 // the image: scalar window loads
+        if (yq16 && (xq16 || xs) && !(e && atoi(e) == 0)) {
             const int nci = cdiv(Cin, 16), nco = cdiv(Cout, 16);
             const long n = 27L * Cin * Cout, n3 = dy3 ? (long)Cin * Cout : 0;
             long G = std::min<long>(ntiles, std::max<long>(1, 512 / ((long)nci * nco)));
@@ -2246,10 +2256,11 @@ int wgrad_t(const void* x, long ldx, const void* dyv, long lddy, float* dw, cons
             if (nci > 65535 || nco > 65535) return UNETR_ERR_ARG;
             if (rows_used) *rows_used = G;
             float* ws3 = ws + (size_t)G * n;
-            if (dy3) hipLaunchKernelGGL((conv3_wgrad_x3_kernel<true>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, ws,
-                                        (const float*)dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);
-            else hipLaunchKernelGGL((conv3_wgrad_x3_kernel<false>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, ws,
-                                    (const float*)nullptr, 0L, (float*)nullptr, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles);
+#define X3W_GO(H3_, XS_) hipLaunchKernelGGL((conv3_wgrad_x3_kernel<H3_, XS_>), dim3((unsigned)G, nci, nco), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, ws, \
+                                            (const float*)dy3, lddy3, ws3, D, H, W, Cin, Cout, ntx, nty, ntz, (int)ntiles)
+            if (dy3) { if (xs) X3W_GO(true, true); else X3W_GO(true, false); }
+            else { if (xs) X3W_GO(false, true); else X3W_GO(false, false); }
+#undef X3W_GO
             const int blocks = (int)std::min<long>((n + 31) / 32, 16384);
             const int blocks3 = dy3 ? (int)std::min<long>((n3 + 31) / 32, 16384) : 0;
             if (!parts_only)

@@ -488,11 +488,13 @@ def test_conv3_halo(pkg, dev, monkeypatch, prec, B, dims3, cin, cout):
 @pytest.mark.parametrize("B,dims3,cin,cout,with3,pitch2,max_wg", [(2, (8, 8, 16), 16, 16, True, False, 0), (1, (9, 7, 19), 32, 16, True, True, 0),
                                                                    (1, (5, 6, 7), 8, 16, False, False, 0), (1, (12, 12, 12), 64, 32, True, False, 0),
                                                                    (2, (4, 4, 16), 256, 128, False, False, 0), (1, (10, 9, 33), 48, 48, True, True, 0),
-                                                                   (3, (16, 16, 32), 16, 16, True, False, 4), (1, (6, 5, 20), 20, 12, True, False, 0)])
+                                                                   (3, (16, 16, 32), 16, 16, True, False, 4), (1, (6, 5, 20), 20, 12, True, False, 0),
+                                                                   (2, (9, 7, 19), 1, 16, True, False, 0), (1, (8, 8, 16), 3, 16, True, False, 0),
+                                                                   (1, (8, 8, 16), 4, 16, False, False, 0)])
 def test_conv3_wgrad_bf16x3_split_images(pkg, dev, monkeypatch, B, dims3, cin, cout, with3, pitch2, max_wg):
     """bf16x3 weight gradient on (hi, lo) bf16 images and transposing reads (csrc/conv3.hip: conv3_wgrad_x3_kernel): 3x3x3 and the
-    1x1x1 branch's gradient from the same pass, ragged volumes, 8 / 20 / 48 channels (masked slabs), x read through a wider pitch (the
-    concatenation buffer), a workgroup walking many tiles -- against torch fp32, and against the 4-byte fragment path it replaces
+    1x1x1 branch's gradient from the same pass, ragged volumes, 8 / 20 / 48 channels (masked slabs), the image block's 1 / 3 / 4 input
+    channels (scalar window loads), x read through a wider pitch (the concatenation buffer), a workgroup walking many tiles -- against torch fp32, and against the 4-byte fragment path it replaces
     (UNETR_X3_WGRAD_TR16=0)."""
     Fn = pkg.functional
     D, H, W = dims3
