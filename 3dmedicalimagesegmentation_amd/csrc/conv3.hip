@@ -1189,6 +1189,145 @@ conv3_c1_fwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wp
     }
 }
 
+// the same kernel for the bf16x3 mode (fp32 feature maps, split weights): the window travels as two bf16 arrays (hi, lo), the 27-tap
+// contraction is three MFMAs (w_hi x_hi + w_hi x_lo + w_lo x_hi), the 1x1x1 branch an fp32 product of the recombined halves.  The
+// generic slab kernel spent 112 us on this layer (one real channel in a 16-channel slab, 27 MFMA pairs per row).
+__global__ void __launch_bounds__(256, 4)
+conv3_c1_fwd_x3_kernel(const float* __restrict__ x, const uint32_t* __restrict__ wp, float* __restrict__ y, long ldy,
+                    int D, int H, int W, int ntx, int nty, int ntz, int ntiles, float* __restrict__ part,
+                    const uint32_t* __restrict__ wp3, float* __restrict__ y3, float* __restrict__ part3) {
+    constexpr int Cout = 16, NPT = (NHALO + 255) / 256;
+    __shared__ uint16_t win[NHALO + 8], winl[NHALO + 8];          // the window's hi and lo bf16 halves
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
+    const bool has3 = wp3 != nullptr;
+    // weight fragment (first MFMA operand: rows = channels): lane (co = r, g) holds taps 8g .. 8g+7 of channel r
+    // (packed weights of this mode: one word [hi | lo << 16] per element, [tap][co][16 k] with the single input channel at k = 0)
+    u32x4 wfrag, wfragl;
+    {
+        uint32_t wv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = 8 * g + j;
+            wv8[j] = tap < 27 ? wp[((long)tap * Cout + r) * 16] : 0u;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            wfrag[d] = (wv8[2 * d] & 0xffffu) | (wv8[2 * d + 1] << 16);
+            wfragl[d] = (wv8[2 * d] >> 16) | (wv8[2 * d + 1] & 0xffff0000u);
+        }
+    }
+    float w3f[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t t = wp3[(long)(4 * g + e) * 16];
+            w3f[e] = __builtin_bit_cast(float, t << 16) + __builtin_bit_cast(float, t & 0xffff0000u);
+        }
+    }
+    // window offsets (elements) of this lane's eight taps relative to voxel (plane wv, row 0, column r); taps 27..31 (zero weights)
+    // read the centre tap: any finite value
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int tap = 8 * g + j < 27 ? 8 * g + j : 13;
+        toff[j] = ((tap / 9) * HY + (tap % 9) / 3) * HX + tap % 3;
+    }
+    const int base0 = (wv * HY) * HX + r;
+    const int cen = (HY + 1) * HX + 1;                    // centre tap
+    // InstanceNorm partial sums (see stats_add / stats_flush)
+    f32x4 rs1[1] = {{0.f, 0.f, 0.f, 0.f}}, rs2[1] = {{0.f, 0.f, 0.f, 0.f}}, rt1[1] = {{0.f, 0.f, 0.f, 0.f}}, rt2[1] = {{0.f, 0.f, 0.f, 0.f}};
+    int cur_b = -1;
+    const long srows = (long)gridDim.x;
+    __shared__ float sred[128];
+    {
+        const int nb = ntiles / (ntx * nty * ntz);
+        stats_zero_rows<1>(part, nb, srows, Cout, 0);
+        if (has3) stats_zero_rows<1>(part3, nb, srows, Cout, 0);
+    }
+    const long item = (long)D * H * W;
+    // this thread's window pieces of tile (b_, z_, y_, x_): image values, 0 outside the volume
+    float nxt[NPT];
+    auto wload = [&](int b_, int z_, int y_, int x_) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            const int hz = id / (HY * HX), rem = id - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z_ - 1 + hz, gy = y_ - 1 + hy, gx = x_ - 1 + hx;
+            const bool ok = id < NHALO && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            float t = 0.f;
+            if (ok) t = x[b_ * item + ((long)gz * H + gy) * W + gx];
+            nxt[j] = t;
+        }
+    };
+    TileTable tt;
+    int kt = 0, tx = 0, ty = 0, tz = 0, b = 0;
+    if ((int)blockIdx.x < ntiles) {
+        tt.get(0, ntiles, ntx, nty, ntz, tx, ty, tz, b);
+        wload(b, tz * TZ, ty * TY, tx * TX);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++kt) {
+        int ax = tx, ay = ty, az = tz, ab = b;
+        const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+        if (b != cur_b) {
+            if (cur_b >= 0) {
+                stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
+                if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
+            }
+            cur_b = b;
+        }
+        __syncthreads();                                     // every wave is done with the previous window
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int id = threadIdx.x + j * 256;
+            if (id < NHALO) { const uint32_t t = PrecBF16x3::split(nxt[j]); win[id] = (uint16_t)t; winl[id] = (uint16_t)(t >> 16); }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) {                // the next tile's window is in flight during this tile's work
+            tt.get(kt + 1, ntiles, ntx, nty, ntz, ax, ay, az, ab);
+            wload(ab, az * TZ, ay * TY, ax * TX);
+        }
+        const int zo = z0 + wv, xo = x0 + r;
+        f32x4 acc[4][1], acc3[4][1];
+        bool okv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint16_t* wb = win + base0 + i * HX;
+            const uint16_t* wbl = winl + base0 + i * HX;
+            uint16_t a8[8], l8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a8[j] = wb[toff[j]]; l8[j] = wbl[toff[j]]; }
+            u32x4 af, afl;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                af[d] = (uint32_t)a8[2 * d] | ((uint32_t)a8[2 * d + 1] << 16);
+                afl[d] = (uint32_t)l8[2 * d] | ((uint32_t)l8[2 * d + 1] << 16);
+            }
+            acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            PrecBF16::mma(acc[i][0], wfrag, af);            // w_hi x_hi + w_hi x_lo + w_lo x_hi
+            PrecBF16::mma(acc[i][0], wfrag, afl);
+            PrecBF16::mma(acc[i][0], wfragl, af);
+            const float xc = __builtin_bit_cast(float, (uint32_t)wb[cen] << 16) + __builtin_bit_cast(float, (uint32_t)wbl[cen] << 16);
+            acc3[i][0] = (f32x4){xc * w3f[0], xc * w3f[1], xc * w3f[2], xc * w3f[3]};
+            okv[i] = zo < D && y0 + i < H && xo < W;
+        }
+        const long tb = (((long)b * D + zo) * H + y0) * W + xo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (okv[i]) {
+                Io<float>::st4(y + (tb + (long)i * W) * ldy + 4 * g, acc[i][0]);
+                if (has3 && y3) Io<float>::st4(y3 + (tb + (long)i * W) * ldy + 4 * g, acc3[i][0]);      // (y3 == nullptr: statistics only)
+            }
+        }
+        stats_add<1>(acc, okv, rs1, rs2);
+        if (has3) stats_add<1>(acc3, okv, rt1, rt2);
+        tx = ax; ty = ay; tz = az; b = ab;
+    }
+    if (cur_b >= 0) {
+        stats_flush<1>(rs1, rs2, part + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
+        if (has3) stats_flush<1>(rt1, rt2, part3 + (((long)cur_b * srows) + blockIdx.x) * 2 * Cout, Cout, 0, r, g, wv, sred);
+    }
+}
+
 // 1x1x1 weights w3[Cout][Cin] in the B-fragment layout the fused kernel reads at the centre tap:
 // pair mode: wp3[n][32], k = 16 + ci (the tap-13 half of pair 6), zero elsewhere; slab mode: wp3[slab][n][SL], k = ci - slab*SL
 // transposed = 1 (data gradient): rows n are INPUT channels of the conv and k its output channels: element = w3[k][n]
@@ -2110,6 +2249,21 @@ int fwd_t(const void* x, long ldx, const void* wp, void* yv, long ldy, int accum
             fz->rows = (int)gx;
             hipLaunchKernelGGL(conv3_c1_fwd_kernel, dim3(gx), dim3(256), 0, st, (const float*)x, (const uint16_t*)wp, (uint16_t*)y, ldy, D, H, W,
                                ntx, nty, ntz, (int)spatial, fz->part, (const uint16_t*)fz->wp3, (uint16_t*)fz->y3, fz->part3);
+            return unetr_check_launch();
+        }
+    }
+    if constexpr (std::is_same<P, PrecBF16x3>::value) {
+        // bf16x3: the same single-channel form on split operands
+        if (conv_pipe_enabled() && Cin == 1 && Cout == 16 && ldx == 1 && fz && fz->k3 == 0 && !accumulate && ntx < 256 && nty < 256 && ntz < 256 &&
+            B < 256 && (ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (long)D * H * W < (1L << 31) &&
+            (!fz->y3 || (((uintptr_t)fz->y3 & 15) == 0 && fz->ldy3 == ldy)) && !getenv("UNETR_CONV_C1_OFF")) {
+            long cap = 1024;
+            if (const char* e = getenv("UNETR_TEST_MAX_WG")) { if (atoi(e) > 0) cap = std::min<long>(cap, atoi(e)); }
+            if (cap < spatial) cap = std::max<long>(8, cap / 8 * 8);
+            const unsigned gx = (unsigned)std::min<long>(spatial, cap);
+            fz->rows = (int)gx;
+            hipLaunchKernelGGL(conv3_c1_fwd_x3_kernel, dim3(gx), dim3(256), 0, st, (const float*)x, (const uint32_t*)wp, (float*)y, ldy, D, H, W,
+                               ntx, nty, ntz, (int)spatial, fz->part, (const uint32_t*)fz->wp3, (float*)fz->y3, fz->part3);
             return unetr_check_launch();
         }
     }
