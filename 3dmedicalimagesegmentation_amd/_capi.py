@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("UNETR_AMD_LIB") or os.path.join(_HERE, "libunetr_hip.
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_BF16X3 = 2      # fp32 storage, operands split into bf16 (hi, lo) pairs inside the kernels (csrc/common.hpp: PrecBF16x3)
-ABI_VERSION = 16       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
+ABI_VERSION = 17       # = UNETR_ABI_VERSION of include/unetr_hip.h this table of signatures was written against
 
 _ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "unsupported shape/configuration",
         4: "workspace too small"}
@@ -40,7 +40,7 @@ class GemmBf16Desc(ctypes.Structure):
         ("bias", c_void_p), ("res", c_void_p), ("ldr", c_long), ("res_mod", c_int),
         ("pre", c_void_p), ("aux", c_void_p), ("ldaux", c_long),
         ("act", c_int), ("accumulate", c_int), ("alpha", c_float),
-        ("tc_d", c_int), ("tc_h", c_int), ("tc_w", c_int), ("tc_cout", c_int),
+        ("tc_d", c_int), ("tc_h", c_int), ("tc_w", c_int), ("tc_cout", c_int), ("x3", c_int),
     ]
 
 

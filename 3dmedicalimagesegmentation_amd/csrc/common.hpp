@@ -292,7 +292,8 @@ int unetr_layernorm_fwd_partials(const float* partials, int splits, long slab, c
                                  int M, int H, float eps, void* stream);
 
 // bf16x3 Linear GEMM on fp32-stored operands through the LDS-DMA kernel (gemm_bf16.hip); UNSUPPORTED = take the generic family
-int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, int b_words, float* C, float* ws, size_t ws_bytes, void* stream);
+int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, int b_words, float* C, float* ws, size_t ws_bytes, void* stream,
+                      int* psp = nullptr);
 
 int unetr_instnorm_stats_finalize2(const float* part, const float* part_b, int nchunk, int B, long V, int C, float eps,
                                    float* stats, float* stats_b, void* stream);

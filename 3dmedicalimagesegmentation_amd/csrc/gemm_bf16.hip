@@ -920,6 +920,11 @@ __global__ void __launch_bounds__(256) cast_bf16_tail_kernel(const float* __rest
 static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
                           float* ws, size_t ws_bytes, void* stream, int* psp) {
     if (!d || !A || !B || (!C && !Cb)) return UNETR_ERR_ARG;
+    if (d->x3) {
+        // bf16x3 mode through the same entry points (the LayerNorm-riding forms below): fp32 A, B fp32 (x3 = 1) or pre-split words (2)
+        if (Cb || !C || d->tc_cout > 0 || (d->x3 != 1 && d->x3 != 2)) return UNETR_ERR_ARG;
+        return unetr_gemm_x3_dma(d, (const float*)A, (const float*)B, d->x3 == 2, C, ws, ws_bytes, stream, psp);
+    }
     const int M = d->M, N = d->N, K = d->K;
     if (M <= 0 || N <= 0 || K <= 0) return UNETR_ERR_ARG;
     // whole 64-deep K stages, 16-byte aligned rows; the transposed-B form also needs whole 8-column chunks
@@ -986,7 +991,8 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
 
 // bf16x3 precision mode: C = A . B^T (b_kn = 0, B [N,K]) or A . B (b_kn = 1, B [K,N]) on fp32-stored operands through the LDS-DMA kernel
 // above (X3 instantiations).  Called by unetr_gemm (gemm_std.hip) for the plain Linear shapes; UNSUPPORTED = the generic family.
-int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, int b_words, float* C, float* ws, size_t ws_bytes, void* stream) {
+int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float* B, int b_words, float* C, float* ws, size_t ws_bytes, void* stream,
+                      int* psp) {
     const int M = d->M, N = d->N, K = d->K;
     if (M <= 0 || N <= 0 || K <= 0) return UNETR_ERR_ARG;
     if (K % 32 || d->lda % 4 || d->ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || N % 4) return UNETR_ERR_UNSUPPORTED;
@@ -998,8 +1004,8 @@ int unetr_gemm_x3_dma(const unetr_gemm_bf16_desc* d, const float* A, const float
     EpBf ep{1, C, d->ldc, nullptr, 0, d->bias, d->res, d->ldr, d->res_mod > 0 ? d->res_mod : M, d->pre, d->aux, d->ldaux, d->act,
             d->accumulate, d->alpha, 0, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
-#define X3_GO(WM_, WN_, BKN_, NS_) do { if (b_words) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, 2>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, nullptr); \
-                                        return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, 1>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, nullptr); } while (0)
+#define X3_GO(WM_, WN_, BKN_, NS_) do { if (b_words) return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, 2>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, psp); \
+                                        return launch_bf16<WM_, WN_, 2, 2, BKN_, NS_, 1>(M, N, K, A, d->lda, B, d->ldb, ep, ws, ws_bytes, st, psp); } while (0)
     // tile rule of the bf16 kernel at small M (a stage is the same 16 KB); many rows: the 128 x 128 tile
     if (M >= 1024 && N >= 128) { if (d->b_kn) X3_GO(4, 4, true, 2); X3_GO(4, 4, false, 2); }
     if (!d->b_kn) {

@@ -777,11 +777,21 @@ def layernorm_bwd_params(dy, x, w, b, mean, rstd, dres=None, dx_bf16=None):
     return dx, _ret(w, ow, deferred=True), _ret(b, ob, deferred=True)
 
 
-def gemm_bf16_ln_fwd(A, B, M, N, K, C, gamma, beta, y_bf16, bias=None, res=None, ldr=0):
+def x3_ride_ok(M, N, K):
+    """shapes the bf16x3 LDS-DMA GEMM takes (csrc/gemm_bf16.hip: unetr_gemm_x3_dma) -- where the LayerNorm-riding forms can be used"""
+    return M >= 32 and K % 32 == 0 and N % 4 == 0 and N >= 64 and os.environ.get("UNETR_X3_GEMM_DMA", "1") != "0"
+
+
+def gemm_bf16_ln_fwd(A, B, M, N, K, C, gamma, beta, y_bf16, bias=None, res=None, ldr=0, y=None, b_words=None):
     """C[M,N] = A[M,K] @ B[N,K]^T + bias + res, and y_bf16 = LayerNorm(C) (gamma, beta) with its (mean, rstd):
-    unetr_gemm_bf16_ln_fwd -- the LayerNorm of the NEXT layer rides on the split-K reduction of this GEMM"""
-    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
+    unetr_gemm_bf16_ln_fwd -- the LayerNorm of the NEXT layer rides on the split-K reduction of this GEMM.
+    bf16x3 mode: A / B fp32 (B optionally as its word shadow b_words), the normalised rows go to the fp32 tensor ``y``."""
+    x3 = A.dtype == torch.float32
+    assert x3 or (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16)
     d = GemmBf16Desc()
+    d.x3 = (2 if b_words is not None else 1) if x3 else 0
+    if b_words is not None:
+        B = b_words
     d.M, d.N, d.K, d.b_kn = M, N, K, 0
     d.lda, d.ldb, d.ldc, d.ldcb = K, K, N, N
     d.bias = bias.data_ptr() if bias is not None else None
@@ -791,7 +801,7 @@ def gemm_bf16_ln_fwd(A, B, M, N, K, C, gamma, beta, y_bf16, bias=None, res=None,
     rstd = torch.empty(M, dtype=torch.float32, device=C.device)
     ws = workspace(C.device)
     call("unetr_gemm_bf16_ln_fwd", ctypes.byref(d), A.data_ptr(), B.data_ptr(), C.data_ptr(), gamma.data_ptr(), beta.data_ptr(), LN_EPS,
-         None, y_bf16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
+         _p(y), _p(y_bf16), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream())
     return mean, rstd
 
 
@@ -818,12 +828,16 @@ def _stashed_ln(x, gamma, beta):
     return st[0], st[1], st[2]
 
 
-def gemm_ln_bwd_params(A, Bw, M, N, K, x, w, b, mean, rstd, dres=None, dx_bf16=None):
+def gemm_ln_bwd_params(A, Bw, M, N, K, x, w, b, mean, rstd, dres=None, dx_bf16=None, b_words=None):
     """(dx, grad_w, grad_b) of a LayerNorm whose output gradient is dy = A[M,K] @ Bw[K,N] (the data gradient of the Linear
     layer behind it, bf16-stored operands, Bw read as the [K, N] operand): unetr_gemm_bf16_ln_bwd -- when the GEMM is cut into K
     slabs the LayerNorm kernel sums them itself, so the separate split-K reduce launch disappears (bit-identical)."""
-    assert A.dtype == torch.bfloat16 and Bw.dtype == torch.bfloat16
+    x3 = A.dtype == torch.float32              # bf16x3 mode: fp32 operands (Bw optionally as its word shadow b_words)
+    assert x3 or (A.dtype == torch.bfloat16 and Bw.dtype == torch.bfloat16)
     d = GemmBf16Desc()
+    d.x3 = (2 if b_words is not None else 1) if x3 else 0
+    if b_words is not None:
+        Bw = b_words
     d.M, d.N, d.K, d.b_kn = M, N, K, 1
     d.lda, d.ldb, d.ldc, d.ldcb = K, N, N, N
     d.alpha = 1.0
@@ -1440,14 +1454,23 @@ def _tblock_forward(x, n1w, n1b, wqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, B, L, h
         twins = (y1b, attb, y2b, ab)          # bf16 operands of the weight-gradient GEMMs
     else:
         twins = None
-        y1, m1, r1 = layernorm_fwd(x, n1w, n1b)
+        x3ride = prec == _capi.PREC_BF16X3 and ln_ride_enabled() and x3_ride_ok(M, hid, mlp)
+        pre = _stashed_ln(x, n1w, n1b) if x3ride else None      # (bf16x3: norm1(x) may have ridden on the GEMM that produced x)
+        y1, m1, r1 = pre if pre is not None else layernorm_fwd(x, n1w, n1b)
         qkv = linear_fwd(y1, wqkv, None, prec)
         att, lse = attention_fwd(qkv, B, L, heads, dh, prec)
         x1 = linear_fwd(att, wp, bp, prec, res=x)
         y2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
         u = torch.empty(M, mlp, dtype=torch.float32, device=x.device)
         a = linear_fwd(y2, w1, b1, prec, act=1, pre=u)
-        x2 = linear_fwd(a, w2, b2, prec, res=x1)
+        if x3ride and next_ln is not None:
+            # the next block's norm1 rides on the split-K sum of linear2 (as in bf16 mode): no reduce launch, no LayerNorm launch
+            x2 = torch.empty(M, hid, dtype=torch.float32, device=x.device)
+            xn = torch.empty_like(x2)
+            mn, rn = gemm_bf16_ln_fwd(a, w2, M, hid, mlp, x2, next_ln[0], next_ln[1], None, bias=b2, res=x1, ldr=hid, y=xn, b_words=weight_x3(w2))
+            _stash_ln(x2, next_ln[0], next_ln[1], xn, mn, rn)
+        else:
+            x2 = linear_fwd(a, w2, b2, prec, res=x1)
     return x2, (y1, m1, r1, qkv, att, lse, x1, y2, m2, r2, u, a), twins
 
 
@@ -1510,9 +1533,13 @@ class TransformerBlockFn(torch.autograd.Function):
             dx1b = bf16_like(x)
             dx1, dn2w, dn2b = gemm_ln_bwd_params(dub, weight_bf16(w1), M, hid, mlp, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
         else:
-            dy2 = linear_dgrad(du, w1, prec)
             dx1b = None
-            dx1, dn2w, dn2b = layernorm_bwd_params(dy2, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
+            if prec == _capi.PREC_BF16X3 and ln_ride_enabled() and x3_ride_ok(M, hid, mlp):
+                # (bf16x3: LayerNorm backward sums the K slabs of the data-gradient GEMM itself, as in bf16 mode)
+                dx1, dn2w, dn2b = gemm_ln_bwd_params(du, w1, M, hid, mlp, x1, n2w, n2b, m2, r2, dres=dx2, b_words=weight_x3(w1))
+            else:
+                dy2 = linear_dgrad(du, w1, prec)
+                dx1, dn2w, dn2b = layernorm_bwd_params(dy2, x1, n2w, n2b, m2, r2, dres=dx2, dx_bf16=dx1b)
         # attention
         b16att = fast and qkv.dtype == torch.bfloat16
         if b16att:
@@ -1536,9 +1563,12 @@ class TransformerBlockFn(torch.autograd.Function):
             dxb = bf16_like(x)
             dx, dn1w, dn1b = gemm_ln_bwd_params(dqkvb, weight_bf16(wqkv), M, hid, 3 * hid, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         else:
-            dy1 = linear_dgrad(dqkv, wqkv, prec)
             dxb = None
-            dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
+            if prec == _capi.PREC_BF16X3 and ln_ride_enabled() and x3_ride_ok(M, hid, 3 * hid):
+                dx, dn1w, dn1b = gemm_ln_bwd_params(dqkv, wqkv, M, hid, 3 * hid, x, n1w, n1b, m1, r1, dres=dx1, b_words=weight_x3(wqkv))
+            else:
+                dy1 = linear_dgrad(dqkv, wqkv, prec)
+                dx, dn1w, dn1b = layernorm_bwd_params(dy1, x, n1w, n1b, m1, r1, dres=dx1, dx_bf16=dxb)
         if fast:
             _attach_twin(dx, dxb)      # the block below picks its bf16 operand up from here (functional._twin)
         return (dx, dn1w, dn1b, dwqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None, None, None, None, None)

@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever an exported signature or a descriptor struct changes.  A binding (3dmedicalimagesegmentation_amd/_capi.py, or a
  * C caller) must compare unetr_abi_version() with the UNETR_ABI_VERSION it was written against before its first call: a stale
  * .so would otherwise shift arguments silently (a stream pointer in an int slot). */
-#define UNETR_ABI_VERSION 16
+#define UNETR_ABI_VERSION 17
 int unetr_abi_version(void);
 
 /* ---- generic MFMA GEMM: C[M,N] = epilogue(A[M,K] * B[K,N]) ------------------------------------------
@@ -93,6 +93,11 @@ typedef struct {
      * tap-major weight pack, kind 4 of unetr_conv3_pack_grouped), and the value goes to Cb[outvox(m, tap) * ldcb + co] with
      * outvox = (b, 2z + tap/4, 2y + (tap/2)%2, 2x + tap%2) of the output grid.  bf16 output only (C and pre NULL). */
     int tc_d, tc_h, tc_w, tc_cout;
+    /* x3 != 0: bf16x3 precision mode through these entry points (what the LayerNorm-riding forms unetr_gemm_bf16_ln_fwd / _ln_bwd need):
+     * A is fp32 [M,K], B fp32 (x3 = 1) or pre-split words (x3 = 2: unetr_split_words), both in the b_kn layout rule above; C fp32 only;
+     * K % 32 == 0, pitches % 4 == 0.  UNETR_ERR_UNSUPPORTED when the LDS-DMA kernel declines the shape (use unetr_gemm + the plain
+     * LayerNorm entry points then). */
+    int x3;
 } unetr_gemm_bf16_desc;
 int unetr_gemm_bf16(const unetr_gemm_bf16_desc* d, const void* A, const void* B, float* C, void* Cb,
                     float* ws, size_t ws_bytes, void* stream);
