@@ -333,7 +333,7 @@ colsum_grouped_kernel(ColsumArgs a) {
 // conv3_wgrad_reduce_kernel (32 outputs x 8 row phases per workgroup, eight loads of a phase in flight, phases added in order);
 // a workgroup finds its problem by binary search over the kernel-argument table.  Fourteen ~6 us launches per step before.
 constexpr int RR_MAX = 48;
-struct RrProblem { const float* part; float* dst; long n; int G; int blk0; int nblk; };
+struct RrProblem { const float* part; float* dst; long n; int G; int blk0; int nblk; int vec; };
 struct RrArgs { int n; RrProblem p[RR_MAX]; };
 __global__ void __launch_bounds__(256) reduce_rows_grouped_kernel(RrArgs a) {
     int pi = 0, hi_ = a.n - 1;
@@ -346,8 +346,38 @@ __global__ void __launch_bounds__(256) reduce_rows_grouped_kernel(RrArgs a) {
     float* __restrict__ dw = pr.dst;
     const long n = pr.n;
     const int G = pr.G, bx = (int)blockIdx.x - pr.blk0, nbx = pr.nblk;
-    __shared__ float sm[8][33];
     const int o = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    if (pr.vec) {
+        // 16-byte loads: a lane owns FOUR consecutive elements (a block iteration covers 128), same eight row phases and the same
+        // summation tree per element as the scalar form below, so both give the same bits (with one 4-byte load per lane the launch
+        // read its 130 MB of partial rows at 2 TB/s: issue-bound, as the column sums were before they went to 16-byte loads)
+        __shared__ f32x4 sm4[8][33];
+        for (long i0 = (long)bx * 128; i0 < n; i0 += (long)nbx * 128) {
+            const long i = i0 + 4 * o;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) {
+                int gI = ph;
+                for (; gI + 56 < G; gI += 64) {
+                    f32x4 t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(part + (long)(gI + 8 * u) * n + i);
+                    s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+                }
+                for (; gI < G; gI += 8) s += *(const f32x4*)(part + (long)gI * n + i);
+            }
+            sm4[ph][o] = s;
+            __syncthreads();
+            if (ph == 0 && i < n) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < 8; ++p) t += sm4[p][o];
+                *(f32x4*)(dw + i) = t;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    __shared__ float sm[8][33];
     for (long i0 = (long)bx * 32; i0 < n; i0 += (long)nbx * 32) {
         const long i = i0 + o;
         float s = 0.f;
@@ -1869,8 +1899,9 @@ extern "C" int unetr_reduce_rows_grouped(const unetr_reduce_problem* probs, int 
         for (int i = 0; i < a.n; ++i) {
             const unetr_reduce_problem& q = probs[base + i];
             if (!q.part || !q.dst || q.rows <= 0 || q.n <= 0) return UNETR_ERR_ARG;
-            const int nb = (int)std::min<long>((q.n + 31) / 32, 8192);
-            a.p[i] = RrProblem{q.part, q.dst, q.n, q.rows, blocks, nb};
+            const int vec = (q.n % 4 == 0 && (((uintptr_t)q.part | (uintptr_t)q.dst) & 15) == 0) ? 1 : 0;      // whole 16-byte quads per row
+            const int nb = (int)std::min<long>(vec ? (q.n + 127) / 128 : (q.n + 31) / 32, 8192);
+            a.p[i] = RrProblem{q.part, q.dst, q.n, q.rows, blocks, nb, vec};
             blocks += nb;
         }
         hipLaunchKernelGGL(reduce_rows_grouped_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -485,6 +485,29 @@ def test_conv3_halo(pkg, dev, monkeypatch, prec, B, dims3, cin, cout):
     assert relerr(Fn.conv3_wgrad(xd, cin, dyd, cout, dims, cin, cout, prec), wr.grad) < TOL[prec]
 
 
+@pytest.mark.parametrize("n,G", [(6912, 512), (432, 1024), (884736, 4), (16, 300), (27 * 48 * 48, 37), (1000, 64), (35, 9)])
+def test_reduce_rows_grouped(pkg, dev, n, G):
+    """dst[i] = sum over rows of part[row][i], every weight-gradient reduction of a backward pass in one launch: the 16-byte form
+    (rows of whole quads) and the scalar form give the same bits (same row phases, same summation tree), both == the fp64 sum."""
+    import ctypes
+    capi = pkg._capi
+    part = g(G, n, seed=1).to(dev)
+    outs = []
+    for mis in (0, 1):                                  # a destination one float off a 16-byte boundary takes the scalar form
+        buf = torch.zeros(n + 8, device=dev)
+        dst = buf[mis:mis + n]
+        arr = (capi.ReduceProblem * 2)()
+        arr[0].part, arr[0].dst, arr[0].n, arr[0].rows = part.data_ptr(), dst.data_ptr(), n, G
+        half = torch.zeros(n + 8, device=dev)
+        arr[1].part, arr[1].dst, arr[1].n, arr[1].rows = part.data_ptr(), half[mis:mis + n].data_ptr(), n, max(1, G // 2)
+        capi.call("unetr_reduce_rows_grouped", arr, 2, torch.cuda.current_stream().cuda_stream)
+        outs.append((dst.clone(), half[mis:mis + n].clone()))
+        assert float(buf[n + mis:].abs().sum()) == 0.0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert relerr(outs[0][0], part.double().sum(0).float()) < 1e-5
+    assert relerr(outs[0][1], part[:max(1, G // 2)].double().sum(0).float()) < 1e-5
+
+
 @pytest.mark.parametrize("B,dims3,cin,cout,with3,pitch2,max_wg", [(2, (8, 8, 16), 16, 16, True, False, 0), (1, (9, 7, 19), 32, 16, True, True, 0),
                                                                    (1, (5, 6, 7), 8, 16, False, False, 0), (1, (12, 12, 12), 64, 32, True, False, 0),
                                                                    (2, (4, 4, 16), 256, 128, False, False, 0), (1, (10, 9, 33), 48, 48, True, True, 0),
