@@ -967,6 +967,19 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
         cfg = 6464;
         if (env_cfg == 0 && K <= 1024 && N <= 1024) cfg = d->b_kn ? 3264 : 6432;
         if (env_cfg == 0 && K <= 1024 && d->b_kn && N > 1024 && N % 64 == 0) cfg = 3264;
+        // 512 < M < 1024 (batch 4 at 96^3: 864 rows, the ranking pre-training step; 160^3: 1000 rows): two 64 x 64 tiles per CU move
+        // more bytes per CU than one wider tile.  Measured (tools/probe_encoder.py PROBE_M=864 / 1000, us): linear1 64x96 13.1 / 13.7
+        // < 64x128 15.4 / 15.8 < 64x64 16.1 / 16.5; qkv at 1000 rows 64x96 10.6 < 64x128 12.5 < 64x64 14.1 (at 864: 64x64 9.8 <
+        // 64x96 10.4); linear2 64x32 unsplit 14.7 / 15.6 < 64x64 + split-K 19.7 / 16.2; data gradients: K = 3072 64x128 + split-K
+        // 21.0 / 21.2 < 64x64 23.3 / 30.3, N = 3072 64x128 19.6 / 19.9 < 32x64 20.4 / 21.5
+        if (env_cfg == 0 && M > 512) {
+            if (!d->b_kn) {
+                if (N >= 3072 || (N >= 2304 && M >= 960)) cfg = 6496;
+                else if (K >= 2048 && N <= 1024) cfg = 6432;
+            } else if (N % 128 == 0) {
+                if ((K >= 2048 && N <= 1024) || (K <= 1024 && N > 1024)) cfg = 64128;
+            }
+        }
     }
     if (!d->b_kn) {
         if (big) { if (env_ns == 3) BF16_GO(4, 4, false, 3); if (env_ns == 4) BF16_GO(4, 4, false, 4); BF16_GO(4, 4, false, 2); }
