@@ -946,7 +946,10 @@ static int gemm_bf16_impl(const unetr_gemm_bf16_desc* d, const void* A, const vo
     const uint16_t* b = (const uint16_t*)B;
     const int env_cfg = getenv("UNETR_GEMM_CFG") ? atoi(getenv("UNETR_GEMM_CFG")) : 0;   // tuning hooks
     const int env_ns = getenv("UNETR_GEMM_STAGES") ? atoi(getenv("UNETR_GEMM_STAGES")) : 0;
-    const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128);
+    // (short reductions with few 128 x 128 tiles -- the GEMM-form transposed convs at 12^3 x 2 = 3456 voxels: [3456 x 128 x 512] is 27
+    // tiles, [3456 x 512 x 64 / 128] 108 -- take the small-M tiles: 20-24 us per launch on 27-108 workgroups with the 128 x 128 family)
+    const bool few128 = K <= 512 && (long)cdiv(M, 128) * cdiv(N, 128) < 128 && !getenv("UNETR_GEMM_FEW128_OFF");
+    const bool big = env_cfg == 128 || (env_cfg == 0 && M >= 1024 && N >= 128 && !few128);
     // the 256 x 256 ping-pong kernel: many rows, weights as stored ([N, K]); K tiles of 64 (checked above).  Narrow outputs
     // (N = 768 at 6912 rows: 81 tiles for 256 CUs) keep the 128 x 128 tile, which fills the chip
     if (!d->b_kn && d->tc_cout <= 0 && (env_cfg == 256 || (env_cfg == 0 && M >= 1024))) {
