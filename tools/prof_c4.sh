@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel stats of the ranking pre-training step (bench.py --config c4): bash tools/prof_c4.sh -> gpurun_out/c4_kernel_stats.csv
+# per-kernel stats of the 160^3 step with encoder checkpointing (bench.py --config c4): bash tools/prof_c4.sh -> gpurun_out/c4_kernel_stats.csv
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_c4
